@@ -119,3 +119,95 @@ def test_normalisation():
     np.testing.assert_allclose(qn, g["q_norm_init0"], atol=1e-5, rtol=1e-5)
     un = O.unnormalize_samples(g["zz"], mu, sd, circ, 4)
     np.testing.assert_allclose(un, g["zz_unnorm_init4"], atol=1e-5, rtol=1e-5)
+
+
+# --------------------------------------------------------------------------- C oracle ----
+from oracle import c_oracle as CO  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[4:-4] for p in CASES])
+class TestCOracleGolden:
+    def test_forward_loss_grad(self, path, dtype):
+        g, n, D, K, H, B = load(path)
+        blob = O.blob_from_state_dict(sd_of(g, "p0"), D)
+        assert CO.param_count(D, K, H) == blob.size
+        z, ld = CO.forward(g["x"], blob, K, H, B, dtype=dtype)
+        np.testing.assert_allclose(z, g["z"], atol=ATOL, rtol=RTOL)
+        np.testing.assert_allclose(ld, g["logdet"], atol=2e-5, rtol=RTOL)
+        loss, grad, lp, _ = CO.nll_grad(g["x"], blob, K, H, B, dtype=dtype)
+        assert abs(loss - float(g["loss"])) < 2e-5 * max(1, abs(float(g["loss"])))
+        np.testing.assert_allclose(lp - ld, g["prior_logprob"], atol=3e-5, rtol=RTOL)
+        gref = O.blob_from_state_dict(sd_of(g, "g0"), D)
+        np.testing.assert_allclose(grad, gref, atol=ATOL, rtol=1e-3)
+
+    def test_adam_trajectory(self, path, dtype):
+        g, n, D, K, H, B = load(path)
+        blob = O.blob_from_state_dict(sd_of(g, "p0"), D)
+        for steps in (1, 2, 10):
+            b, losses, iters, _, _ = CO.train(g["x"], blob, K, H, B, lr=float(g["adam_lr"]), max_iters=steps,
+                                              early_stop=False, dtype=dtype)
+            assert iters == steps
+            ref = O.blob_from_state_dict(sd_of(g, "p%d" % steps), D)
+            np.testing.assert_allclose(b, ref, atol=2e-4, rtol=1e-3)
+            np.testing.assert_allclose(losses, g["adam_losses"][:steps], atol=1e-4, rtol=1e-4)
+
+    def test_inverse(self, path, dtype):
+        g, n, D, K, H, B = load(path)
+        blob = O.blob_from_state_dict(sd_of(g, "p0"), D)
+        xr, ld = CO.inverse(g["zlat"], None, blob, K, H, B, dtype=dtype)
+        np.testing.assert_allclose(xr, g["zlat_inv_x"], atol=5e-5, rtol=RTOL)
+        np.testing.assert_allclose(ld, g["zlat_inv_logdet"], atol=5e-5, rtol=RTOL)
+        for Ds in (1, 3):
+            if "igs%d_x" % Ds in g:
+                xf, _ = CO.inverse(g["zlat"][:, Ds:], g["x"][:, :Ds], blob, K, H, B, dtype=dtype)
+                np.testing.assert_allclose(xf, g["igs%d_x" % Ds], atol=5e-5, rtol=RTOL)
+
+
+@pytest.mark.parametrize("L", [1, 2, 4])
+def test_c_oracle_multilayer_matches_autograd(L):
+    """Multi-layer flows have no usable reference: the C oracle's analytic
+    backward (incl. d/dx through spline and conditioner) is checked against autograd of the
+    torch oracle, in float64."""
+    torch.manual_seed(100 + L)
+    n, D, K, H, B = 48, 5, 6, 8, 5.0
+    gen = torch.Generator().manual_seed(7 + L)
+    blob = torch.cat([O.init_blob(D, K, H, gen) for _ in range(L)]).double()
+    blob = blob + 0.3 * torch.randn(blob.shape, generator=gen, dtype=torch.float64)
+    x = 1.6 * torch.randn(n, D, generator=gen, dtype=torch.float64)
+    x[0, 0] = 5.5; x[1, 2] = -5.0; x[2, 4] = 5.0
+    xr = x.clone().requires_grad_(True); br = blob.clone().requires_grad_(True)
+    loss = O.nll(xr, br, K, H, B, L)
+    gb, gx = torch.autograd.grad(loss, [br, xr])
+    l2, grad, lp, gx2 = CO.nll_grad(x.numpy(), blob.numpy(), K, H, B, L, dtype=np.float64, want_gx=True)
+    assert abs(l2 - loss.item()) < 1e-10
+    np.testing.assert_allclose(grad, gb.numpy(), atol=1e-10, rtol=1e-8)
+    np.testing.assert_allclose(gx2, gx.numpy(), atol=1e-10, rtol=1e-8)
+    # generic VJP
+    gz = torch.randn(n, D, generator=gen, dtype=torch.float64); gl = torch.randn(n, generator=gen, dtype=torch.float64)
+    z, ld = O.forward(xr, br, K, H, B, L)
+    gb3, gx3 = torch.autograd.grad((z * gz).sum() + (ld * gl).sum(), [br, xr])
+    grad4, gx4 = CO.backward(x.numpy(), blob.numpy(), gz.numpy(), gl.numpy(), K, H, B, L, dtype=np.float64)
+    np.testing.assert_allclose(grad4, gb3.numpy(), atol=1e-9, rtol=1e-8)
+    np.testing.assert_allclose(gx4, gx3.numpy(), atol=1e-9, rtol=1e-8)
+    # round trip
+    zf, ldf = CO.forward(x.numpy(), blob.numpy(), K, H, B, L, dtype=np.float64)
+    xb, ldb = CO.inverse(zf, None, blob.numpy(), K, H, B, L, dtype=np.float64)
+    inside = np.abs(x.numpy()).max(1) < 4.9
+    np.testing.assert_allclose(xb[inside], x.numpy()[inside], atol=1e-8)
+    np.testing.assert_allclose((ldf + ldb)[inside], 0, atol=1e-8)
+
+
+def test_c_oracle_early_stop_matches_torch_oracle():
+    torch.manual_seed(3)
+    n, D, K, H, B = 200, 3, 5, 8, 5.0
+    gen = torch.Generator().manual_seed(5)
+    blob = O.init_blob(D, K, H, gen)
+    x = torch.randn(n, D, generator=gen)
+    x[:, 1] = x[:, 0] ** 2 - 1 + 0.3 * x[:, 1]
+    bt, lt, it = O.train(x, blob, K, H, B, lr=0.03, max_iters=400, average_window=20, loss_delta_tol=5e-3)
+    bc, lc, ic, _, _ = CO.train(x.numpy(), blob.numpy(), K, H, B, lr=0.03, max_iters=400, average_window=20,
+                                loss_delta_tol=5e-3, dtype=np.float32)
+    assert it == ic and it < 400 and it % 20 == 0
+    np.testing.assert_allclose(lc[:ic], lt.numpy()[:it], atol=2e-3)
+    assert np.all(lc[ic:] == 0)

@@ -1,0 +1,156 @@
+/*
+ * nfisam_hip.h — C ABI of the MI355X (gfx950) implementation of NF-iSAM's per-clique
+ * normalizing-flow hot path (autoregressive rational-quadratic neural spline flow).
+ *
+ * The reference (MarineRoboticsGroup/NF-iSAM) has no FFI for this path: its boundary is the
+ * Python module surface `flows.*` + the solver hooks of `slam.NFiSAM`.  This
+ * header is what a binding for that surface links against; `nf-isam_amd/nfisam_hip/` is the
+ * ctypes binding and INTEGRATION.md shows the stub a reference maintainer would add.  Each
+ * entry point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - All `float*`/`uint8_t*` data arguments are DEVICE pointers (HBM), contiguous, row-major,
+ *    borrowed for the duration of the enqueued work.  `int32_t* map` of the layout helper and
+ *    everything documented "host" are host pointers.
+ *  - `stream` is a `hipStream_t` passed as `void*` (0 = the null stream).  Work is enqueued
+ *    on it; no entry point synchronises with the host unless its comment says so.
+ *  - Return value: NFISAM_OK or an error code below; on NFISAM_ERR_LAUNCH the HIP error is
+ *    left readable through `nfisam_last_hip_error()`.
+ *  - No global mutable state except the last-error word; re-entrant across streams/devices.
+ *  - There is NO CPU fallback anywhere behind this ABI.
+ *
+ * Symbols: n particles, D clique dimension (columns = [obs | separator | frontal]),
+ * Ds leading columns that are given in conditional sampling, K spline bins (`num_knots`),
+ * H hidden width, Po = 3K-1, B tail bound (5.0 in the reference, flows.py:51), L flow layers.
+ *
+ * Parameter storage ("kernel layout", float32, one block of `nfisam_nsf_kparam_count`
+ * floats per flow layer, layers concatenated).  With PoP = Po rounded up to a multiple of 4:
+ *     init_param[PoP]
+ *     for i = 1..D-1:  W0t[i][H]  b0[H]  W1t[H][H]  b1[H]  W2t[H][PoP]  b2[PoP]
+ * where W*t are the TRANSPOSES ([in][out]) of the reference's nn.Linear weights
+ * (flows.py:31-37), so that every weight row a wavefront consumes is contiguous and can be
+ * fetched with scalar loads.  Padding entries are zero and stay zero under training.
+ * `nfisam_nsf_layout_map` gives the permutation to/from the reference's parameter order
+ * (init_param, layers.{i-1}.network.{0,2,4}.{weight,bias}; flows.py:57-59).
+ */
+#ifndef NFISAM_HIP_H
+#define NFISAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFISAM_OK 0
+#define NFISAM_ERR_ARG 1          /* bad shape / NULL pointer / unsupported (K,H)  (ValueError) */
+#define NFISAM_ERR_LAUNCH 2       /* HIP launch or runtime failure                              */
+#define NFISAM_ERR_DOMAIN 3       /* numerical domain error flagged by a kernel (utils.py:74-76,133) */
+#define NFISAM_ERR_NO_DEVICE 4    /* no usable gfx950 device                                    */
+
+typedef void* nfisam_stream_t;
+
+/* ABI version of this header (major*1000 + minor). */
+int nfisam_abi_version(void);
+/* Last HIP error code recorded by a failing call on this thread (0 if none). */
+int nfisam_last_hip_error(void);
+/* 1 if the (K, H) pair has a compiled kernel instantiation, else 0.  K in {2..16}, H in {4,8,16}. */
+int nfisam_nsf_supported(int K, int H);
+
+/* ---- layout (host-only helpers, no GPU needed) ---------------------------------------- */
+/* Parameters per layer in the reference's order = numel of NSF_AR.parameters() (flows.py:51-60). */
+size_t nfisam_nsf_param_count(int D, int K, int H);
+/* Floats per layer in kernel layout (>= param_count because of padding). */
+size_t nfisam_nsf_kparam_count(int D, int K, int H);
+/* host: map[kidx] = index into the reference-order blob, or -1 for padding. map has kparam_count entries. */
+int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map);
+
+/* ---- inference ------------------------------------------------------------------------ */
+/* NSF_AR.forward chained over L layers + prior log-prob (flows.py:65-93, models.py:11-24),
+ * in the CORRECT layout (the reference returns a scrambled one).
+ *   x[n,D] -> z[n,D] (nullable), logdet[n] (nullable), logprob[n] (nullable)
+ *   logprob = -0.5|z|^2 - D/2 log(2 pi) + logdet                                           */
+int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
+                       int L, float* z, float* logdet, float* logprob, nfisam_stream_t stream);
+
+/* NSF_AR.inverse / inverse_given_separator (flows.py:95-137) fused with the adapter's
+ * normalisation of the given columns and un-normalisation + angle wrap of the result
+ * (NormalizingFlowModelWithSeparator.{normalize_samples,inverse_given_separator,
+ *  unnormalize_samples}, slam/NFiSAM.py:96-118,140-155).
+ *   z[n,D-Ds] latent draws; x_sep[n,Ds] RAW (un-normalised) given columns, NULL iff Ds==0
+ *   mean[D], std[D], circular[D] (1 = angle column): NULL mean => data already normalised and
+ *   the output is left normalised (plain NSF_AR.inverse_given_separator).
+ *   x_out[n,D-Ds]; logdet[n] nullable (sum of -log|dz/dx| over the solved columns, as NSF_AR.inverse)
+ * For L>1 every layer is conditioned on the same x_sep (slam/NFiSAM.py:151-152).           */
+int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds,
+                       int K, int H, float B, int L, const float* mean, const float* std,
+                       const uint8_t* circular, float* x_out, float* logdet, nfisam_stream_t stream);
+
+/* ---- training -------------------------------------------------------------------------- */
+/* Vector-Jacobian product of the L-layer flow (what torch autograd computes for
+ * `loss.backward()` in slam/NFiSAM.py:474): kgrad[L*kparam_count] += d<gz,z>/dtheta + d<gl,logdet>/dtheta,
+ * gx[n,D] (nullable) = the same w.r.t. x.  nll_mode=1 ignores gz/gl and uses
+ * sum_p(0.5|z_p|^2 - logdet_p) (the un-normalised NLL of NFiSAM.py:470-472; divide by n and add
+ * D/2 log 2pi for the reference's loss); loss_sum[1] += that sum (nullable).
+ * kgrad / loss_sum are ACCUMULATED into (caller zeroes them).                               */
+int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
+                        const float* gz, const float* gl, int nll_mode, float* kgrad, float* gx,
+                        float* loss_sum, nfisam_stream_t stream);
+
+/* Device-resident control block of one clique's training run. */
+typedef struct nfisam_train_state {
+    int32_t step;        /* iterations completed so far                                      */
+    int32_t stop;        /* set by the device when the early-stop rule fired                 */
+    int32_t have_avg;    /* a previous window mean exists                                    */
+    float   loss_avg;    /* previous window mean (NFiSAM.py:481-491)                         */
+    float   loss_acc;    /* running sum_p(0.5|z|^2 - logdet) of the iteration in flight      */
+    int32_t domain_err;  /* non-zero if a kernel saw a non-finite loss                       */
+    int32_t reserved[10];
+} nfisam_train_state;
+
+typedef struct nfisam_adam_cfg {
+    float lr, beta1, beta2, eps;      /* torch.optim.Adam defaults: betas .9/.999, eps 1e-8 (NFiSAM.py:425) */
+    int32_t max_iters;                /* flow_iterations                                      */
+    int32_t average_window;           /* <=0 disables early stopping                          */
+    float loss_delta_tol;
+    int32_t reserved;
+} nfisam_adam_cfg;
+
+/* One clique of a training batch: everything device-resident. */
+typedef struct nfisam_clique {
+    const float* x;              /* [n,D] normalised training batch (NFiSAM.py:379)           */
+    float* kparams;              /* [L*kparam_count]                                          */
+    float* adam_m;               /* [L*kparam_count] zero-initialised                         */
+    float* adam_v;               /* [L*kparam_count] zero-initialised                         */
+    float* kgrad;                /* [L*kparam_count] workspace, zero-initialised              */
+    float* iter_loss;            /* [max_iters] zero-initialised; per-iteration loss (NFiSAM.py:473) */
+    nfisam_train_state* state;   /* zero-initialised                                          */
+    int32_t n, D;
+} nfisam_clique;
+
+/* One full-batch training iteration of `n_cliques` independent cliques (grid.y = clique):
+ * forward + analytic backward + gradient reduction, then a fused Adam update that also records
+ * iter_loss[step], evaluates the reference's window early-stop rule on the device and advances
+ * state->step.  Cliques whose state->stop is set or whose step reached max_iters are skipped, so
+ * the call can be replayed (e.g. from a hipGraph) without host intervention.
+ * `cliques` is a DEVICE array unless n_cliques==1 and `cliques_on_host` is non-zero.
+ * All cliques share K, H, B, L and the Adam configuration; n and D may differ.             */
+int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                          int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
+                          nfisam_stream_t stream);
+
+/* Convenience loop == the `for i in range(flow_iterations)` loop of NFiSAM.fit_clique_density_model
+ * (slam/NFiSAM.py:451-491) for a batch of independent cliques.  Enqueues iterations in chunks of
+ * `average_window` (captured once as a hipGraph and replayed) and SYNCHRONISES WITH THE HOST after
+ * each chunk to read the stop flags.  host_cliques: HOST array of descriptors (device pointers
+ * inside); dev_cliques: the same array in device memory.  iters_run[n_cliques] (host) receives the
+ * iterations each clique ran.                                                                */
+int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,
+                          int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int use_graph,
+                          int32_t* iters_run, nfisam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFISAM_HIP_H */

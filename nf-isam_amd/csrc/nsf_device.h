@@ -1,0 +1,267 @@
+// nsf_device.h — per-lane device math of the autoregressive rational-quadratic spline flow
+// for gfx950 (wave64).  One lane = one particle; everything here is straight-line register
+// code with compile-time K (bins) and H (hidden width).
+//
+// What it computes (reference, paths relative to the NF-iSAM root):
+//   conditioner  theta_i = W2 tanh(W1 tanh(W0 x[:i] + b0) + b1) + b2      src/flows/flows.py:26-41,82-83
+//   knots        softmax -> min-size mix -> cumsum -> [-B,B], ends pinned src/flows/utils.py:85-103
+//   derivatives  1e-3 + softplus(logit), boundary logits = const (slope 1) src/flows/utils.py:41-44,94
+//   bin search   last knot j with v >= knot_j (last knot bumped 1e-6)      src/flows/utils.py:17-22
+//   RQ forward / inverse / log|det|                                        src/flows/utils.py:123-164
+//   tails        |v| > B (or NaN): identity, log-det 0                     src/flows/utils.py:31-49
+// The backward formulas are hand-derived (DESIGN.md "Backward"); the reference uses autograd.
+//
+// Weights are wave-uniform: they are read through the scalar cache (address space 4 ->
+// s_load_dwordx{8,16}) and used as SGPR operands of v_fma, so they cost neither VGPRs nor
+// LDS bandwidth.  The per-particle row x[0..i) lives in LDS, dimension-major [k][64].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsf {
+
+typedef const __attribute__((address_space(4))) float cfloat;   // scalar-path (invariant) memory
+
+constexpr float kMinBin = 1e-3f;      // DEFAULT_MIN_BIN_WIDTH / HEIGHT (utils.py:12-13)
+constexpr float kMinDeriv = 1e-3f;    // DEFAULT_MIN_DERIVATIVE (utils.py:14)
+constexpr float kBoundLogit = 0.53974175453186035f;  // log(exp(1 - 1e-3) - 1)  (utils.py:42)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int TILE = 64;              // particles per wave-tile (one per lane)
+
+__host__ __device__ constexpr int pad4(int v) { return (v + 3) & ~3; }
+
+// ---- kernel-layout offsets (see include/nfisam_hip.h) --------------------------------------
+template <int K, int H>
+struct Layout {
+    static constexpr int Po = 3 * K - 1;
+    static constexpr int PoP = pad4(Po);
+    static constexpr int kFixed = H + H * H + H + H * PoP + PoP;   // block size without W0t
+    __host__ __device__ static constexpr int block(int i) { return i * H + kFixed; }
+    __host__ __device__ static constexpr int off(int i) {          // offset of dim i's block, i >= 1
+        return PoP + (i - 1) * kFixed + H * ((i - 1) * i / 2);
+    }
+    __host__ __device__ static constexpr int count(int D) { return off(D); }
+    // offsets inside dim i's block
+    __host__ __device__ static constexpr int oW0(int) { return 0; }
+    __host__ __device__ static constexpr int ob0(int i) { return i * H; }
+    __host__ __device__ static constexpr int oW1(int i) { return i * H + H; }
+    __host__ __device__ static constexpr int ob1(int i) { return i * H + H + H * H; }
+    __host__ __device__ static constexpr int oW2(int i) { return i * H + H + H * H + H; }
+    __host__ __device__ static constexpr int ob2(int i) { return i * H + H + H * H + H + H * PoP; }
+};
+
+// ---- fast scalar math (1-ulp hardware transcendentals) --------------------------------------
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float ftanh(float x) {
+    // 1 - 2/(1+e^{2x}); saturates correctly for |x| large (e -> inf gives 1, e -> 0 gives -1)
+    const float e = __builtin_amdgcn_exp2f(x * (2.0f * kLog2e));
+    return 1.0f - 2.0f * frcp(1.0f + e);
+}
+__device__ __forceinline__ float fsoftplus(float x) {   // max(x,0) + log(1 + e^{-|x|})
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * kLog2e);
+    return fmaxf(x, 0.0f) + flog(1.0f + e);
+}
+__device__ __forceinline__ float fsigmoid(float x) { return frcp(1.0f + fexp(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- conditioner ----------------------------------------------------------------------------
+// xs: LDS, dimension-major: xs[k * TILE + lane] = x_k of this lane's particle.
+template <int K, int H>
+__device__ __forceinline__ void cond_hidden(cfloat* blk, int i, const float* xs, int lane,
+                                            float (&h1)[H], float (&h2)[H]) {
+    using LY = Layout<K, H>;
+    float a[H];
+    cfloat* b0 = blk + LY::ob0(i);
+#pragma unroll
+    for (int j = 0; j < H; ++j) a[j] = b0[j];
+    cfloat* W0 = blk;
+    for (int k = 0; k < i; ++k) {
+        const float xk = xs[k * TILE + lane];
+#pragma unroll
+        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(W0[k * H + j], xk, a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j) h1[j] = ftanh(a[j]);
+    cfloat* b1 = blk + LY::ob1(i);
+    cfloat* W1 = blk + LY::oW1(i);
+#pragma unroll
+    for (int j = 0; j < H; ++j) a[j] = b1[j];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(W1[k * H + j], h1[k], a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j) h2[j] = ftanh(a[j]);
+}
+
+template <int K, int H>
+__device__ __forceinline__ void cond_theta(cfloat* blk, int i, const float (&h2)[H],
+                                           float (&th)[Layout<K, H>::PoP]) {
+    using LY = Layout<K, H>;
+    cfloat* b2 = blk + LY::ob2(i);
+    cfloat* W2 = blk + LY::oW2(i);
+#pragma unroll
+    for (int o = 0; o < LY::PoP; ++o) th[o] = b2[o];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+#pragma unroll
+        for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(W2[k * LY::PoP + o], h2[k], th[o]);
+    }
+}
+
+// ---- spline ----------------------------------------------------------------------------------
+template <int K>
+struct Spline {
+    float pw[K], ph[K];               // softmax probabilities of widths / heights
+    float Xk, dx, Yk, dy, d0, d1;     // selected bin: left knots, sizes, end derivatives
+    float ud0, ud1;                   // derivative logits at knots k, k+1
+    float t;                          // position inside the bin
+    int k;
+    bool inside;
+};
+
+template <int K, int PoP, bool INV>
+__device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], float B, Spline<K>& S,
+                                            float& out, float& lad) {
+    S.inside = (v >= -B) && (v <= B);             // false for NaN (utils.py:31)
+    const float vs = S.inside ? v : 0.0f;
+    float mw = th[0], mh = th[K];
+#pragma unroll
+    for (int j = 1; j < K; ++j) { mw = fmaxf(mw, th[j]); mh = fmaxf(mh, th[K + j]); }
+    float sw = 0.0f, sh = 0.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        S.pw[j] = fexp(th[j] - mw); sw += S.pw[j];
+        S.ph[j] = fexp(th[K + j] - mh); sh += S.ph[j];
+    }
+    const float iw = frcp(sw), ih = frcp(sh);
+    const float mix = 1.0f - kMinBin * (float)K, twoB = 2.0f * B;
+    float cx = 0.0f, cy = 0.0f, Xl = -B, Yl = -B;
+    S.k = 0; S.Xk = -B; S.Yk = -B; S.dx = 1.0f; S.dy = 1.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        S.pw[j] *= iw; S.ph[j] *= ih;
+        cx += kMinBin + mix * S.pw[j];
+        cy += kMinBin + mix * S.ph[j];
+        const float Xr = (j == K - 1) ? B : twoB * cx - B;     // last knot pinned (utils.py:90-91)
+        const float Yr = (j == K - 1) ? B : twoB * cy - B;
+        const bool sel = INV ? (vs >= Yl) : (vs >= Xl);         // monotone knots: last true wins
+        if (sel) { S.k = j; S.Xk = Xl; S.dx = Xr - Xl; S.Yk = Yl; S.dy = Yr - Yl; }
+        Xl = Xr; Yl = Yr;
+    }
+    S.ud0 = kBoundLogit; S.ud1 = kBoundLogit;
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        const float dj = th[2 * K + j];
+        if (S.k == j + 1) S.ud0 = dj;
+        if (S.k == j) S.ud1 = dj;
+    }
+    S.d0 = kMinDeriv + fsoftplus(S.ud0);
+    S.d1 = kMinDeriv + fsoftplus(S.ud1);
+    const float idx = frcp(S.dx);
+    const float s = S.dy * idx, sig = S.d0 + S.d1 - 2.0f * s;
+    float t;
+    if (INV) {
+        const float dl = vs - S.Yk;
+        const float a = dl * sig + S.dy * (s - S.d0);
+        const float b = S.dy * S.d0 - dl * sig;
+        const float c = -s * dl;
+        const float disc = fmaxf(b * b - 4.0f * a * c, 0.0f);
+        t = (2.0f * c) * frcp(-b - __builtin_sqrtf(disc));
+        out = t * S.dx + S.Xk;
+    } else {
+        t = (vs - S.Xk) * idx;
+    }
+    S.t = t;
+    const float q = t * (1.0f - t), omt = 1.0f - t;
+    const float den = s + sig * q;
+    const float M = S.d1 * t * t + 2.0f * s * q + S.d0 * omt * omt;
+    const float l = flog(s * s * M) - 2.0f * flog(den);
+    if (INV) {
+        lad = -l;
+    } else {
+        out = S.Yk + S.dy * (s * t * t + S.d0 * q) * frcp(den);
+        lad = l;
+    }
+    if (!S.inside) { out = v; lad = 0.0f; }
+}
+
+// Backward of the forward spline.  Upstream gz = dL/dz, gl = dL/dlogdet.  Writes gth[0..Po)
+// (gth[Po..PoP) = 0) and returns dL/dx through the spline's own argument.
+template <int K, int PoP>
+__device__ __forceinline__ float spline_backward(const Spline<K>& S, float B, float gz, float gl,
+                                                 float (&gth)[PoP]) {
+    const int k = S.k;
+    const float w = S.dx, h = S.dy, d0 = S.d0, d1 = S.d1, t = S.t;
+    const float iw = frcp(w);
+    const float s = h * iw, sig = d0 + d1 - 2.0f * s, q = t * (1.0f - t), omt = 1.0f - t, o2t = 1.0f - 2.0f * t;
+    const float N = s * t * t + d0 * q, den = s + sig * q;
+    const float iden = frcp(den), u = N * iden, iden2 = iden * iden;
+    const float u_t = ((2.0f * s * t + d0 * o2t) * den - N * sig * o2t) * iden2;
+    const float u_s = (t * t * den - N * (1.0f - 2.0f * q)) * iden2;
+    const float u_d0 = q * (den - N) * iden2;
+    const float u_d1 = -N * q * iden2;
+    const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
+    const float iM = frcp(M);
+    const float M_t = 2.0f * d1 * t + 2.0f * s * o2t - 2.0f * d0 * omt;
+    const float ld_t = M_t * iM - 2.0f * sig * o2t * iden;
+    const float ld_s = 2.0f * frcp(s) + 2.0f * q * iM - 2.0f * (1.0f - 2.0f * q) * iden;
+    const float ld_d0 = omt * omt * iM - 2.0f * q * iden;
+    const float ld_d1 = t * t * iM - 2.0f * q * iden;
+    const float gzh = gz * h;
+    const float G_t = gzh * u_t + gl * ld_t;
+    const float G_s = gzh * u_s + gl * ld_s;
+    const float G_d0 = gzh * u_d0 + gl * ld_d0;
+    const float G_d1 = gzh * u_d1 + gl * ld_d1;
+    const float g_x = G_t * iw;
+    const float g_w = -(G_t * t + G_s * s) * iw;          // d/d(bin width)  at fixed left knot
+    const float g_h = gz * u + G_s * iw;                  // d/d(bin height) at fixed left knot
+    const bool lo = (k >= 1), hi = (k + 1 <= K - 1);      // end knots are pinned: no gradient
+    const float gXk = lo ? (-g_x - g_w) : 0.0f, gXk1 = hi ? g_w : 0.0f;
+    const float gYk = lo ? (gz - g_h) : 0.0f, gYk1 = hi ? g_h : 0.0f;
+    const float scale = 2.0f * B * (1.0f - kMinBin * (float)K);
+    const float cw1 = scale * (gXk + gXk1), cw2 = scale * gXk1;
+    const float ch1 = scale * (gYk + gYk1), ch2 = scale * gYk1;
+    float dotw = 0.0f, doth = 0.0f;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const float cw = (m < k) ? cw1 : ((m == k) ? cw2 : 0.0f);
+        const float ch = (m < k) ? ch1 : ((m == k) ? ch2 : 0.0f);
+        dotw = __builtin_fmaf(S.pw[m], cw, dotw);
+        doth = __builtin_fmaf(S.ph[m], ch, doth);
+    }
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const float cw = (m < k) ? cw1 : ((m == k) ? cw2 : 0.0f);
+        const float ch = (m < k) ? ch1 : ((m == k) ? ch2 : 0.0f);
+        gth[m] = S.pw[m] * (cw - dotw);
+        gth[K + m] = S.ph[m] * (ch - doth);
+    }
+    const float gd0 = G_d0 * fsigmoid(S.ud0), gd1 = G_d1 * fsigmoid(S.ud1);
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        float v = 0.0f;
+        if (k == j + 1) v = gd0;
+        if (k == j) v = gd1;
+        gth[2 * K + j] = v;
+    }
+#pragma unroll
+    for (int o = 3 * K - 1; o < PoP; ++o) gth[o] = 0.0f;
+    if (!S.inside) {
+#pragma unroll
+        for (int o = 0; o < PoP; ++o) gth[o] = 0.0f;
+        return gz;
+    }
+    return g_x;
+}
+
+}  // namespace nsf

@@ -1,0 +1,770 @@
+// nsf_kernels.hip — gfx950 kernels and the C ABI (include/nfisam_hip.h) of the NF-iSAM
+// per-clique normalizing-flow hot path.  Written for CDNA4 only: 64-lane wavefronts, scalar-path
+// weights, LDS-resident particle tiles, cross-lane butterflies; no CUDA/compat paths.
+//
+// Work decomposition:
+//   training   grid = (ceil(n/64), n_cliques); block = W waves over ONE 64-particle tile;
+//              wave w owns the autoregressive dims i = w, w+W, ... of every layer, because in the
+//              density-estimation direction all D conditioners depend only on the layer input
+//              (src/flows/flows.py:77-83) and are independent.  Layers are sequential: layer
+//              inputs live in LDS (dimension-major [k][64]) and waves meet at __syncthreads().
+//   inverse    one wave per 64 particles, dims sequential (true data dependence, flows.py:115-137).
+//   Adam       one block per clique; also evaluates the reference's early-stop rule on device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/nfisam_hip.h"
+#include "nsf_device.h"
+
+using namespace nsf;
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) {                         \
+            g_last_hip_error = (int)e_;                 \
+            return NFISAM_ERR_LAUNCH;                   \
+        }                                               \
+    } while (0)
+
+// =============================================================================================
+// cross-lane reduce-scatter: on return lane l holds the wave total of input v[l & (N-1)].
+// log2(N) exchange steps move N-1 values in total (vs 6 per value for a plain wave reduction).
+// =============================================================================================
+template <int N>
+__device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
+#pragma unroll
+    for (int half = N / 2; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int t = 0; t < half; ++t) {
+            const float lo = v[t], hi = v[t + half];   // load first: keeps v[] in registers (no select-of-address)
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            v[t] = keep + __shfl_xor(send, half, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int off = N; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
+    return r;
+}
+
+// =============================================================================================
+// training / VJP kernel
+// =============================================================================================
+struct TrainArgs {
+    const nfisam_clique* cliques;   // device array (batched) or nullptr
+    nfisam_clique single;           // by-value descriptor when cliques == nullptr
+    const float* gz;                // VJP mode: upstream dL/dz [n,D]
+    const float* gl;                // VJP mode: upstream dL/dlogdet [n] (nullable => 0)
+    float* gx;                      // optional dL/dx [n,D]
+    float* loss_sum;                // optional accumulator when no train state is attached
+    float B;
+    int L;
+    int max_iters;
+    int nll_mode;
+};
+
+template <int K, int H>
+__device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, int lane,
+                                           float (&h1)[H], float (&h2)[H],
+                                           float (&th)[Layout<K, H>::PoP]) {
+    using LY = Layout<K, H>;
+    if (i == 0) {
+#pragma unroll
+        for (int o = 0; o < LY::PoP; ++o) th[o] = lp[o];
+    } else {
+        cfloat* blk = lp + LY::off(i);
+        cond_hidden<K, H>(blk, i, xin, lane, h1, h2);
+        cond_theta<K, H>(blk, i, h2, th);
+    }
+}
+
+template <int K, int H>
+__global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
+    const float* x = batched ? cp->x : a.single.x;
+    float* kparams = batched ? cp->kparams : a.single.kparams;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int L = a.L;
+    const float B = a.B;
+
+    const int p0 = blockIdx.x * TILE;
+    if (p0 >= n) return;
+    if (st != nullptr) {
+        if (st->stop != 0 || st->step >= a.max_iters) return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int gp = p0 + lane;
+    const bool valid = gp < n;
+    const int DT = D * TILE;
+
+    float* xs = smem;                 // [L][D][TILE] layer inputs
+    float* g0 = xs + L * DT;          // [D][TILE]
+    float* g1 = g0 + DT;              // [D][TILE]
+
+    // ---- coalesced load of the particle tile, transposed into LDS -------------------------
+    for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+        const int p = e / D, k = e - p * D;
+        const int q = p0 + p;
+        xs[k * TILE + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
+    }
+    __syncthreads();
+
+    cfloat* kp = (cfloat*)kparams;
+    const int Pk = LY::count(D);
+
+    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    for (int l = 0; l + 1 < L; ++l) {
+        cfloat* lp = kp + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        float* xout = xs + (l + 1) * DT;
+        for (int i = w; i < D; i += W) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            Spline<K> S;
+            float z, lad;
+            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, z, lad);
+            xout[i * TILE + lane] = z;
+        }
+        __syncthreads();
+    }
+
+    // ---- backward with recompute, last layer first ------------------------------------------
+    float lossv = 0.0f;
+    float* gcur = g0;
+    float* gprev = g1;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const bool need_gx = (l > 0) || (a.gx != nullptr);
+        cfloat* lp = kp + (size_t)l * Pk;
+        float* Gl = G + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        if (need_gx) {
+            for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
+            __syncthreads();
+        }
+        for (int i = w; i < D; i += W) {
+            float h1[H], h2[H], th[PoP], gth[PoP];
+            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            Spline<K> S;
+            float z, lad;
+            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, z, lad);
+            float gz, gl;
+            if (a.nll_mode) {
+                gl = -1.0f;
+                gz = last ? z : gcur[i * TILE + lane];
+                if (valid) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+            } else {
+                gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * TILE + lane];
+            }
+            if (!valid) { gz = 0.0f; gl = 0.0f; }
+            const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
+            if (need_gx) atomicAdd(&gprev[i * TILE + lane], gxs);
+
+            if (i == 0) {
+                constexpr int N0 = (PoP <= 32) ? 32 : 64;
+                float v[N0];
+#pragma unroll
+                for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+                const float r = butterfly<N0>(v, lane);
+                if (lane < PoP) atomicAdd(&Gl[lane], r);
+                continue;
+            }
+            cfloat* blk = lp + LY::off(i);
+            float* Gb = Gl + LY::off(i);
+            // ---- layer 3: W2t[H][PoP] | b2[PoP] are contiguous -> flat index f = k*PoP + o
+            float gh2[H];
+            {
+                cfloat* W2 = blk + LY::oW2(i);
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(W2[k * PoP + o], gth[o], acc);
+                    gh2[k] = acc;
+                }
+                constexpr int TOT = (H + 1) * PoP;
+                float* Gw = Gb + LY::oW2(i);
+#pragma unroll
+                for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                    float v[64];
+#pragma unroll
+                    for (int t = 0; t < 64; ++t) {
+                        const int f = c * 64 + t;
+                        const int k = f / PoP, o = f % PoP;
+                        v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
+                    }
+                    const float r = butterfly<64>(v, lane);
+                    if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                }
+            }
+            // ---- layer 2: W1t[H][H] | b1[H] contiguous -> f = k*H + j
+            float ga2[H], ga1[H];
+#pragma unroll
+            for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
+            {
+                cfloat* W1 = blk + LY::oW1(i);
+                float gh1[H];
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W1[k * H + j], ga2[j], acc);
+                    gh1[k] = acc;
+                }
+#pragma unroll
+                for (int k = 0; k < H; ++k) ga1[k] = gh1[k] * (1.0f - h1[k] * h1[k]);
+                constexpr int TOT = (H + 1) * H;
+                float* Gw = Gb + LY::oW1(i);
+#pragma unroll
+                for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                    float v[64];
+#pragma unroll
+                    for (int t = 0; t < 64; ++t) {
+                        const int f = c * 64 + t;
+                        const int k = f / H, j = f % H;
+                        v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
+                    }
+                    const float r = butterfly<64>(v, lane);
+                    if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                }
+            }
+            // ---- layer 1: W0t[i][H] | b0[H] contiguous -> f = k*H + j, k <= i (k == i: bias)
+            {
+                cfloat* W0 = blk;
+                float* Gw = Gb;
+                constexpr int RPC = 64 / H;                 // k-rows per 64-value chunk
+                const int tot = (i + 1) * H;
+                for (int kc = 0; kc <= i; kc += RPC) {
+                    float v[64];
+#pragma unroll
+                    for (int r_ = 0; r_ < RPC; ++r_) {
+                        const int k = kc + r_;
+                        const float xk = (k < i) ? xin[k * TILE + lane] : ((k == i) ? 1.0f : 0.0f);
+#pragma unroll
+                        for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
+                    }
+                    const float r = butterfly<64>(v, lane);
+                    if (kc * H + lane < tot) atomicAdd(&Gw[kc * H + lane], r);
+                }
+                if (need_gx) {
+                    for (int k = 0; k < i; ++k) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W0[k * H + j], ga1[j], acc);
+                        atomicAdd(&gprev[k * TILE + lane], acc);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
+        for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+            const int p = e / D, k = e - p * D;
+            const int q = p0 + p;
+            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * TILE + p];
+        }
+    }
+    if (a.nll_mode) {
+        const float tot = wave_sum(lossv);
+        if (lane == 0) {
+            float* dst = (st != nullptr) ? &st->loss_acc : a.loss_sum;
+            if (dst != nullptr) atomicAdd(dst, tot);
+        }
+    }
+}
+
+// =============================================================================================
+// Adam (torch.optim.Adam defaults, src/slam/NFiSAM.py:425,475) + loss record + window early stop
+// (NFiSAM.py:473,481-491).  One block per clique.
+// =============================================================================================
+struct AdamArgs {
+    const nfisam_clique* cliques;
+    nfisam_clique single;
+    nfisam_adam_cfg cfg;
+    float log_b1, log_b2;   // ln(beta), computed on the host in double
+    int L, K, H;
+};
+
+__global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
+    float* theta = batched ? cp->kparams : a.single.kparams;
+    float* m = batched ? cp->adam_m : a.single.adam_m;
+    float* v = batched ? cp->adam_v : a.single.adam_v;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    float* iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+
+    __shared__ int s_step, s_stop;
+    if (threadIdx.x == 0) { s_step = st->step; s_stop = st->stop; }
+    __syncthreads();
+    if (s_stop != 0 || s_step >= a.cfg.max_iters) return;
+    const int t = s_step + 1;
+
+    const int PoP = pad4(3 * a.K - 1);
+    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
+    const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
+
+    const float b1 = a.cfg.beta1, b2 = a.cfg.beta2;
+    const float bc1 = -expm1f((float)t * a.log_b1);
+    const float bc2 = -expm1f((float)t * a.log_b2);
+    const float step_size = a.cfg.lr / bc1;
+    const float inv_bc2s = 1.0f / sqrtf(bc2);
+    const float inv_n = 1.0f / (float)n;
+    for (int j = threadIdx.x; j < P; j += blockDim.x) {
+        const float g = G[j] * inv_n;
+        const float mj = b1 * m[j] + (1.0f - b1) * g;
+        const float vj = b2 * v[j] + (1.0f - b2) * g * g;
+        m[j] = mj;
+        v[j] = vj;
+        const float denom = sqrtf(vj) * inv_bc2s + a.cfg.eps;
+        theta[j] -= step_size * mj / denom;
+        G[j] = 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        const float loss = st->loss_acc * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
+        iter_loss[t - 1] = loss;
+        st->loss_acc = 0.0f;
+        st->step = t;
+        if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; st->stop = 1; }
+        const int wnd = a.cfg.average_window;
+        if (wnd > 0 && (t % wnd) == 0) {
+            float s = 0.0f;
+            for (int j = t - wnd; j < t; ++j) s += iter_loss[j];
+            const float nw = s / (float)wnd;
+            if (st->have_avg != 0 && st->loss_avg != 0.0f) {
+                const float delta = fabsf(1.0f - nw / st->loss_avg);
+                if (delta < a.cfg.loss_delta_tol) st->stop = 1;
+            }
+            st->loss_avg = nw;
+            st->have_avg = 1;
+        }
+    }
+}
+
+// =============================================================================================
+// inference: forward (density direction)
+// =============================================================================================
+template <int K, int H>
+__global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restrict__ x, const float* kparams,
+                                                           int n, int D, float B, int L,
+                                                           float* __restrict__ z, float* __restrict__ logdet,
+                                                           float* __restrict__ logprob) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int p0 = blockIdx.x * TILE;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int DT = D * TILE;
+    float* xa = smem;            // [D][TILE]
+    float* xb = xa + DT;         // [D][TILE]
+    float* ldacc = xb + DT;      // [TILE]
+    for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+        const int p = e / D, k = e - p * D;
+        const int q = p0 + p;
+        xa[k * TILE + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
+    }
+    if (threadIdx.x < TILE) ldacc[threadIdx.x] = 0.0f;
+    __syncthreads();
+    cfloat* kp = (cfloat*)kparams;
+    const int Pk = LY::count(D);
+    float* xin = xa;
+    float* xout = xb;
+    for (int l = 0; l < L; ++l) {
+        cfloat* lp = kp + (size_t)l * Pk;
+        float ld = 0.0f;
+        for (int i = w; i < D; i += W) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            Spline<K> S;
+            float zz, lad;
+            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, zz, lad);
+            xout[i * TILE + lane] = zz;
+            ld += lad;
+        }
+        atomicAdd(&ldacc[lane], ld);
+        __syncthreads();
+        float* tmp = xin; xin = xout; xout = tmp;
+    }
+    // xin holds z
+    if (z != nullptr) {
+        for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+            const int p = e / D, k = e - p * D;
+            const int q = p0 + p;
+            if (q < n) z[(size_t)q * D + k] = xin[k * TILE + p];
+        }
+    }
+    if (threadIdx.x < TILE && p0 + (int)threadIdx.x < n) {
+        const int q = p0 + threadIdx.x;
+        const float ld = ldacc[threadIdx.x];
+        if (logdet != nullptr) logdet[q] = ld;
+        if (logprob != nullptr) {
+            float zz = 0.0f;
+            for (int k = 0; k < D; ++k) { const float t = xin[k * TILE + threadIdx.x]; zz += t * t; }
+            logprob[q] = -0.5f * zz - 0.5f * (float)D * 1.8378770664093453f + ld;
+        }
+    }
+}
+
+// =============================================================================================
+// inference: inverse / conditional sampling (one wave per 64 particles, dims sequential)
+// =============================================================================================
+__device__ __forceinline__ float wrap_pi(float t) {   // src/utils/Functions.py:20-21 (python % semantics)
+    const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+    float r = fmodf(t + pi, two_pi);
+    if (r < 0.0f) r += two_pi;
+    return r - pi;
+}
+
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict__ zin, const float* __restrict__ x_sep,
+                                                         const float* kparams, int n, int D, int Ds, float B, int L,
+                                                         const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                         const uint8_t* __restrict__ circ,
+                                                         float* __restrict__ x_out, float* __restrict__ logdet) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int p0 = blockIdx.x * TILE;
+    const int F = D - Ds;
+    float* xs = smem;                 // [D][TILE]  row being reconstructed
+    float* zs = xs + D * TILE;        // [F][TILE]  latent of the current layer
+    // given columns: normalise (NFiSAM.py:96-106)
+    for (int e = lane; e < Ds * TILE; e += TILE) {
+        const int p = e / Ds, k = e - p * Ds;
+        const int q = p0 + p;
+        float v = (q < n) ? x_sep[(size_t)q * Ds + k] : 0.0f;
+        if (mean != nullptr) {
+            const float d = v - mean[k];
+            v = ((circ != nullptr && circ[k]) ? wrap_pi(d) : d) / stdv[k];
+        }
+        xs[k * TILE + p] = v;
+    }
+    for (int e = lane; e < F * TILE; e += TILE) {
+        const int p = e / F, k = e - p * F;
+        const int q = p0 + p;
+        zs[k * TILE + p] = (q < n) ? zin[(size_t)q * F + k] : 0.0f;
+    }
+    __syncthreads();
+    cfloat* kp = (cfloat*)kparams;
+    const int Pk = LY::count(D);
+    float ld = 0.0f;
+    for (int l = L - 1; l >= 0; --l) {
+        cfloat* lp = kp + (size_t)l * Pk;
+        for (int i = Ds; i < D; ++i) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H>(lp, i, xs, lane, h1, h2, th);
+            Spline<K> S;
+            float xi, lad;
+            spline_eval<K, PoP, true>(zs[(i - Ds) * TILE + lane], th, B, S, xi, lad);
+            xs[i * TILE + lane] = xi;     // only this lane reads its own column entries
+            ld += lad;
+        }
+        if (l > 0) for (int i = Ds; i < D; ++i) zs[(i - Ds) * TILE + lane] = xs[i * TILE + lane];
+    }
+    __syncthreads();
+    for (int e = lane; e < F * TILE; e += TILE) {
+        const int p = e / F, k = e - p * F;
+        const int q = p0 + p;
+        if (q < n) {
+            float v = xs[(Ds + k) * TILE + p];
+            if (mean != nullptr) {
+                v = v * stdv[Ds + k] + mean[Ds + k];
+                if (circ != nullptr && circ[Ds + k]) v = wrap_pi(v);
+            }
+            x_out[(size_t)q * F + k] = v;
+        }
+    }
+    if (logdet != nullptr && p0 + lane < n) logdet[p0 + lane] = ld;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+#define NSF_DISPATCH(K_, H_, CALL)                                  \
+    do {                                                            \
+        if ((H_) == 8 && (K_) == 5) { constexpr int KK = 5, HH = 8; CALL; }       \
+        else if ((H_) == 8 && (K_) == 9) { constexpr int KK = 9, HH = 8; CALL; }  \
+        else if ((H_) == 8 && (K_) == 12) { constexpr int KK = 12, HH = 8; CALL; } \
+        else if ((H_) == 8 && (K_) == 6) { constexpr int KK = 6, HH = 8; CALL; }  \
+        else return NFISAM_ERR_ARG;                                 \
+    } while (0)
+
+extern "C" int nfisam_abi_version(void) { return 1000; }
+extern "C" int nfisam_last_hip_error(void) { return g_last_hip_error; }
+extern "C" int nfisam_nsf_supported(int K, int H) {
+    return (H == 8 && (K == 5 || K == 6 || K == 9 || K == 12)) ? 1 : 0;
+}
+
+static size_t torch_block(int i, int K, int H) {
+    const size_t Po = 3 * (size_t)K - 1;
+    return (size_t)i * H + H + (size_t)H * H + H + (size_t)H * Po + Po;
+}
+extern "C" size_t nfisam_nsf_param_count(int D, int K, int H) {
+    if (D < 1 || K < 1 || H < 1) return 0;
+    size_t c = 3 * (size_t)K - 1;
+    for (int i = 1; i < D; ++i) c += torch_block(i, K, H);
+    return c;
+}
+static size_t kcount(int D, int K, int H) {
+    const size_t PoP = (size_t)pad4(3 * K - 1);
+    const size_t kfixed = (size_t)H + (size_t)H * H + H + (size_t)H * PoP + PoP;
+    return PoP + (size_t)(D - 1) * kfixed + (size_t)H * ((size_t)(D - 1) * D / 2);
+}
+extern "C" size_t nfisam_nsf_kparam_count(int D, int K, int H) {
+    if (D < 1 || K < 1 || H < 1) return 0;
+    return kcount(D, K, H);
+}
+extern "C" int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map) {
+    if (D < 1 || K < 1 || H < 1 || map == nullptr) return NFISAM_ERR_ARG;
+    const int Po = 3 * K - 1, PoP = pad4(Po);
+    const size_t Pk = kcount(D, K, H);
+    for (size_t j = 0; j < Pk; ++j) map[j] = -1;
+    for (int o = 0; o < Po; ++o) map[o] = o;
+    size_t toff = Po, koff = PoP;
+    for (int i = 1; i < D; ++i) {
+        const size_t tW0 = toff, tb0 = tW0 + (size_t)H * i, tW1 = tb0 + H, tb1 = tW1 + (size_t)H * H,
+                     tW2 = tb1 + H, tb2 = tW2 + (size_t)Po * H;
+        const size_t kW0 = koff, kb0 = kW0 + (size_t)i * H, kW1 = kb0 + H, kb1 = kW1 + (size_t)H * H,
+                     kW2 = kb1 + H, kb2 = kW2 + (size_t)H * PoP;
+        for (int k = 0; k < i; ++k) for (int j = 0; j < H; ++j) map[kW0 + (size_t)k * H + j] = (int32_t)(tW0 + (size_t)j * i + k);
+        for (int j = 0; j < H; ++j) map[kb0 + j] = (int32_t)(tb0 + j);
+        for (int k = 0; k < H; ++k) for (int j = 0; j < H; ++j) map[kW1 + (size_t)k * H + j] = (int32_t)(tW1 + (size_t)j * H + k);
+        for (int j = 0; j < H; ++j) map[kb1 + j] = (int32_t)(tb1 + j);
+        for (int k = 0; k < H; ++k) for (int o = 0; o < Po; ++o) map[kW2 + (size_t)k * PoP + o] = (int32_t)(tW2 + (size_t)o * H + k);
+        for (int o = 0; o < Po; ++o) map[kb2 + o] = (int32_t)(tb2 + o);
+        toff += torch_block(i, K, H);
+        koff = kb2 + PoP;
+    }
+    return (koff == Pk) ? NFISAM_OK : NFISAM_ERR_ARG;
+}
+
+static int pick_waves(int D) { return D < 1 ? 1 : (D > 8 ? 8 : D); }
+
+template <typename KernelT>
+static int set_lds(KernelT kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return NFISAM_ERR_ARG;
+    if (bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
+                                  int L, float* z, float* logdet, float* logprob, nfisam_stream_t stream) {
+    if (x == nullptr || kparams == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0)) return NFISAM_ERR_ARG;
+    if (n == 0) return NFISAM_OK;
+    const int W = pick_waves(D);
+    const size_t lds = ((size_t)2 * D * TILE + TILE) * sizeof(float);
+    NSF_DISPATCH(K, H, {
+        int rc = set_lds(nsf_forward_kernel<KK, HH>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nsf_forward_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64 * W), lds,
+                           (hipStream_t)stream, x, kparams, n, D, B, L, z, logdet, logprob);
+    });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds,
+                                  int K, int H, float B, int L, const float* mean, const float* stdv,
+                                  const uint8_t* circular, float* x_out, float* logdet, nfisam_stream_t stream) {
+    if (z == nullptr || kparams == nullptr || x_out == nullptr || n < 0 || D < 1 || Ds < 0 || Ds >= D || L < 1 ||
+        !(B > 0) || (Ds > 0 && x_sep == nullptr) || (mean != nullptr && stdv == nullptr))
+        return NFISAM_ERR_ARG;
+    if (n == 0) return NFISAM_OK;
+    const size_t lds = ((size_t)D + (D - Ds)) * TILE * sizeof(float);
+    NSF_DISPATCH(K, H, {
+        int rc = set_lds(nsf_inverse_kernel<KK, HH>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nsf_inverse_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
+                           (hipStream_t)stream, z, x_sep, kparams, n, D, Ds, B, L, mean, stdv, circular, x_out,
+                           logdet);
+    });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
+    const int W = pick_waves(max_D);
+    const size_t lds = ((size_t)a.L + 2) * max_D * TILE * sizeof(float);
+    NSF_DISPATCH(K, H, {
+        int rc = set_lds(nsf_train_kernel<KK, HH>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nsf_train_kernel<KK, HH>), dim3((max_n + TILE - 1) / TILE, n_cliques), dim3(64 * W), lds,
+                           s, a);
+    });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
+                                   const float* gz, const float* gl, int nll_mode, float* kgrad, float* gx,
+                                   float* loss_sum, nfisam_stream_t stream) {
+    if (x == nullptr || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
+        (!nll_mode && gz == nullptr))
+        return NFISAM_ERR_ARG;
+    if (n == 0) return NFISAM_OK;
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.single.x = x;
+    a.single.kparams = const_cast<float*>(kparams);
+    a.single.kgrad = kgrad;
+    a.single.n = n;
+    a.single.D = D;
+    a.gz = gz; a.gl = gl; a.gx = gx; a.loss_sum = loss_sum;
+    a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0;
+    return launch_train(a, 1, n, D, K, H, (hipStream_t)stream);
+}
+
+static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                        int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, hipStream_t s) {
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cliques = dev_cliques;
+    if (single != nullptr) a.single = *single;
+    a.B = B; a.L = L; a.max_iters = cfg->max_iters; a.nll_mode = 1;
+    int rc = launch_train(a, n_cliques, max_n, max_D, K, H, s);
+    if (rc) return rc;
+    AdamArgs ad;
+    memset(&ad, 0, sizeof(ad));
+    ad.cliques = dev_cliques;
+    if (single != nullptr) ad.single = *single;
+    ad.cfg = *cfg;
+    ad.log_b1 = (float)log((double)cfg->beta1);
+    ad.log_b2 = (float)log((double)cfg->beta2);
+    ad.L = L; ad.K = K; ad.H = H;
+    hipLaunchKernelGGL(nsf_adam_kernel, dim3(n_cliques), dim3(1024), 0, s, ad);
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+static int check_cfg(const nfisam_adam_cfg* cfg, int K, int H, int L, float B) {
+    if (cfg == nullptr || L < 1 || !(B > 0) || !nfisam_nsf_supported(K, H)) return NFISAM_ERR_ARG;
+    if (!(cfg->lr > 0) || !(cfg->beta1 >= 0 && cfg->beta1 < 1) || !(cfg->beta2 >= 0 && cfg->beta2 < 1) ||
+        cfg->max_iters < 0)
+        return NFISAM_ERR_ARG;
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                                     int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
+                                     nfisam_stream_t stream) {
+    int rc = check_cfg(cfg, K, H, L, B);
+    if (rc) return rc;
+    if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1) return NFISAM_ERR_ARG;
+    if (cliques_on_host) {
+        if (n_cliques != 1) return NFISAM_ERR_ARG;
+        return enqueue_step(nullptr, cliques, 1, max_n, max_D, K, H, B, L, cfg, (hipStream_t)stream);
+    }
+    return enqueue_step(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, cfg, (hipStream_t)stream);
+}
+
+extern "C" int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
+                                     int n_cliques, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
+                                     int use_graph, int32_t* iters_run, nfisam_stream_t stream) {
+    int rc = check_cfg(cfg, K, H, L, B);
+    if (rc) return rc;
+    if (host_cliques == nullptr || n_cliques < 1 || (n_cliques > 1 && dev_cliques == nullptr)) return NFISAM_ERR_ARG;
+    int max_n = 0, max_D = 0;
+    for (int c = 0; c < n_cliques; ++c) {
+        if (host_cliques[c].n < 1 || host_cliques[c].D < 1) return NFISAM_ERR_ARG;
+        max_n = host_cliques[c].n > max_n ? host_cliques[c].n : max_n;
+        max_D = host_cliques[c].D > max_D ? host_cliques[c].D : max_D;
+    }
+    hipStream_t user = (hipStream_t)stream;
+    const nfisam_clique* single = (dev_cliques == nullptr) ? host_cliques : nullptr;
+    const int chunk = (cfg->average_window > 0) ? cfg->average_window : 50;
+    std::vector<nfisam_train_state> hst(n_cliques);
+
+    // A capturable stream: the user's stream may be the (un-capturable) null stream.
+    hipStream_t work = user;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    hipEvent_t ev = nullptr;
+    int status = NFISAM_OK;
+    if (use_graph) {
+        HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, user));            // order after prior work on the user stream
+        HIP_TRY(hipStreamWaitEvent(cap, ev, 0));
+        work = cap;
+        HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        for (int it = 0; it < chunk && status == NFISAM_OK; ++it)
+            status = enqueue_step(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg, cap);
+        hipError_t e = hipStreamEndCapture(cap, &graph);
+        if (status == NFISAM_OK && e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; }
+        if (status == NFISAM_OK) {
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; }
+        }
+    }
+    int done = 0;
+    while (status == NFISAM_OK && done < cfg->max_iters) {
+        if (use_graph) {
+            hipError_t e = hipGraphLaunch(exec, work);
+            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
+        } else {
+            for (int it = 0; it < chunk && status == NFISAM_OK; ++it)
+                status = enqueue_step(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg, work);
+            if (status != NFISAM_OK) break;
+        }
+        done += chunk;
+        bool all_stopped = true;
+        for (int c = 0; c < n_cliques; ++c) {
+            hipError_t e = hipMemcpyAsync(&hst[c], host_cliques[c].state, sizeof(nfisam_train_state),
+                                          hipMemcpyDeviceToHost, work);
+            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
+        }
+        if (status != NFISAM_OK) break;
+        hipError_t e = hipStreamSynchronize(work);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
+        for (int c = 0; c < n_cliques; ++c) {
+            if (hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
+            if (!hst[c].stop && hst[c].step < cfg->max_iters) all_stopped = false;
+        }
+        if (all_stopped) break;
+    }
+    if (status == NFISAM_OK || status == NFISAM_ERR_DOMAIN) {
+        if (done == 0) {   // max_iters == 0: report current steps
+            for (int c = 0; c < n_cliques; ++c) {
+                (void)hipMemcpy(&hst[c], host_cliques[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost);
+            }
+        }
+        if (iters_run != nullptr) for (int c = 0; c < n_cliques; ++c) iters_run[c] = hst[c].step;
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ev) (void)hipEventDestroy(ev);
+    if (cap) (void)hipStreamDestroy(cap);
+    return status;
+}

@@ -1,0 +1,278 @@
+"""ctypes binding of the C ABI in include/nfisam_hip.h (libnfisam_hip.so, built from
+nf-isam_amd/csrc by `make -C nf-isam_amd/csrc` or `__graft_entry__.build()`).
+
+PyTorch is used here only as plumbing: device memory (tensors), streams.  Every compute entry
+point goes to the hand-written gfx950 kernels; there is NO CPU or eager-PyTorch fallback — if
+the library is missing or the tensors are not on a ROCm device the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnfisam_hip.so")
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+OK, ERR_ARG, ERR_LAUNCH, ERR_DOMAIN, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
+    "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
+    "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop",
+]
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class TrainState(C.Structure):
+    _fields_ = [("step", C.c_int32), ("stop", C.c_int32), ("have_avg", C.c_int32), ("loss_avg", C.c_float),
+                ("loss_acc", C.c_float), ("domain_err", C.c_int32), ("reserved", C.c_int32 * 10)]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("max_iters", C.c_int32), ("average_window", C.c_int32), ("loss_delta_tol", C.c_float),
+                ("reserved", C.c_int32)]
+
+
+class Clique(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("kparams", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("kgrad", C.c_void_p), ("iter_loss", C.c_void_p), ("state", C.c_void_p),
+                ("n", C.c_int32), ("D", C.c_int32)]
+
+
+assert C.sizeof(TrainState) == 64 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the shared library for gfx950 with hipcc (works without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    else:
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                "libnfisam_hip.so not found at %s — build it with `make -C %s` (needs hipcc). "
+                "There is no CPU fallback for the NF-iSAM flow hot path." % (LIB_PATH, CSRC))
+        _lib = C.CDLL(LIB_PATH)
+        _lib.nfisam_nsf_param_count.restype = C.c_size_t
+        _lib.nfisam_nsf_kparam_count.restype = C.c_size_t
+        for name in EXPORTS:
+            getattr(_lib, name)   # raises AttributeError if the ABI is incomplete
+    return _lib
+
+
+def _check(rc, what):
+    if rc == OK:
+        return
+    msg = {ERR_ARG: "invalid argument / unsupported (K,H)", ERR_LAUNCH: "HIP launch failure (hip error %d)" %
+           lib().nfisam_last_hip_error(), ERR_DOMAIN: "numerical domain error", ERR_NO_DEVICE: "no gfx950 device"}
+    if rc == ERR_ARG:
+        raise ValueError("%s: %s" % (what, msg[rc]))
+    raise RuntimeError("%s: %s" % (what, msg.get(rc, "error %d" % rc)))
+
+
+def supported(K, H):
+    return bool(lib().nfisam_nsf_supported(int(K), int(H)))
+
+
+def param_count(D, K, H):
+    return int(lib().nfisam_nsf_param_count(int(D), int(K), int(H)))
+
+
+def kparam_count(D, K, H):
+    return int(lib().nfisam_nsf_kparam_count(int(D), int(K), int(H)))
+
+
+_map_cache = {}
+
+
+def layout_map(D, K, H):
+    """np.int32[kparam_count]: index into the reference-order blob, -1 for padding."""
+    key = (int(D), int(K), int(H))
+    if key not in _map_cache:
+        m = np.empty(kparam_count(*key), dtype=np.int32)
+        _check(lib().nfisam_nsf_layout_map(key[0], key[1], key[2], m.ctypes.data_as(C.c_void_p)), "layout_map")
+        _map_cache[key] = m
+    return _map_cache[key]
+
+
+_tmap_cache = {}
+
+
+def _torch_maps(D, K, H, device):
+    key = (int(D), int(K), int(H), str(device))
+    if key not in _tmap_cache:
+        m = layout_map(D, K, H)
+        valid = torch.from_numpy((m >= 0))
+        src = torch.from_numpy(np.where(m >= 0, m, 0).astype(np.int64))
+        kidx = torch.from_numpy(np.nonzero(m >= 0)[0].astype(np.int64))
+        tidx = torch.from_numpy(m[m >= 0].astype(np.int64))
+        _tmap_cache[key] = (valid.to(device), src.to(device), kidx.to(device), tidx.to(device))
+    return _tmap_cache[key]
+
+
+def pack(blob, D, K, H, L=1):
+    """reference-order parameters [L*P] -> kernel layout [L*Pk] (same device/dtype float32)."""
+    P, Pk = param_count(D, K, H), kparam_count(D, K, H)
+    blob = blob.reshape(L, P)
+    valid, src, _, _ = _torch_maps(D, K, H, blob.device)
+    out = blob[:, src] * valid.to(blob.dtype)
+    return out.reshape(L * Pk).contiguous()
+
+
+def unpack(kblob, D, K, H, L=1):
+    """kernel layout [L*Pk] -> reference-order parameters [L*P]."""
+    P, Pk = param_count(D, K, H), kparam_count(D, K, H)
+    kblob = kblob.reshape(L, Pk)
+    _, _, kidx, tidx = _torch_maps(D, K, H, kblob.device)
+    out = torch.empty(L, P, dtype=kblob.dtype, device=kblob.device)
+    out[:, tidx] = kblob[:, kidx]
+    return out.reshape(L * P)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on a ROCm device (no CPU path exists)" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s" % (name, dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def forward(x, kparams, K, H, B, L=1, want_z=True, want_logdet=True, want_logprob=False):
+    """x[n,D] -> (z, logdet, logprob) (None for the ones not requested)."""
+    _dev(x, "x"); _dev(kparams, "kparams")
+    n, D = x.shape
+    if kparams.numel() != L * kparam_count(D, K, H):
+        raise ValueError("kparams has %d elements, expected %d" % (kparams.numel(), L * kparam_count(D, K, H)))
+    z = torch.empty_like(x) if want_z else None
+    ld = torch.empty(n, dtype=torch.float32, device=x.device) if want_logdet else None
+    lp = torch.empty(n, dtype=torch.float32, device=x.device) if want_logprob else None
+    _check(lib().nfisam_nsf_forward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), _ptr(z),
+                                    _ptr(ld), _ptr(lp), _stream()), "nfisam_nsf_forward")
+    return z, ld, lp
+
+
+def inverse(z, x_sep, kparams, K, H, B, L=1, mean=None, std=None, circular=None, want_logdet=False):
+    """z[n,D-Ds], x_sep[n,Ds] raw (or None) -> x_free[n,D-Ds] (and logdet[n])."""
+    _dev(z, "z"); _dev(kparams, "kparams"); _dev(x_sep, "x_sep"); _dev(mean, "mean"); _dev(std, "std")
+    _dev(circular, "circular", torch.uint8)
+    n, F = z.shape
+    Ds = 0 if x_sep is None else x_sep.shape[1]
+    D = Ds + F
+    if x_sep is not None and x_sep.shape[0] != n:
+        raise ValueError("x_sep and z disagree on the number of particles")
+    if kparams.numel() != L * kparam_count(D, K, H):
+        raise ValueError("kparams has %d elements, expected %d" % (kparams.numel(), L * kparam_count(D, K, H)))
+    for t, nm in ((mean, "mean"), (std, "std"), (circular, "circular")):
+        if t is not None and t.numel() != D:
+            raise ValueError("%s must have D=%d entries" % (nm, D))
+    out = torch.empty_like(z)
+    ld = torch.empty(n, dtype=torch.float32, device=z.device) if want_logdet else None
+    _check(lib().nfisam_nsf_inverse(_ptr(z), _ptr(x_sep), _ptr(kparams), n, D, Ds, int(K), int(H), C.c_float(B),
+                                    int(L), _ptr(mean), _ptr(std), _ptr(circular), _ptr(out), _ptr(ld), _stream()),
+           "nfisam_nsf_inverse")
+    return (out, ld) if want_logdet else out
+
+
+def backward(x, kparams, K, H, B, L=1, gz=None, gl=None, nll_mode=False, want_gx=False):
+    """VJP of the flow.  -> (kgrad[L*Pk], gx[n,D] or None, loss_sum tensor[1] or None)."""
+    _dev(x, "x"); _dev(kparams, "kparams"); _dev(gz, "gz"); _dev(gl, "gl")
+    n, D = x.shape
+    kgrad = torch.zeros_like(kparams)
+    gx = torch.empty_like(x) if want_gx else None
+    loss = torch.zeros(1, dtype=torch.float32, device=x.device) if nll_mode else None
+    _check(lib().nfisam_nsf_backward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), _ptr(gz),
+                                     _ptr(gl), int(bool(nll_mode)), _ptr(kgrad), _ptr(gx), _ptr(loss), _stream()),
+           "nfisam_nsf_backward")
+    return kgrad, gx, loss
+
+
+class TrainBatch:
+    """Device-resident training state of a batch of independent cliques (one flow each).
+
+    Mirrors what NFiSAM.fit_clique_density_model keeps per clique (model parameters, Adam
+    moments, per-iteration loss vector; src/slam/NFiSAM.py:418-447) but for many cliques at
+    once, so that one launch covers grid.y = clique."""
+
+    def __init__(self, xs, kparams, K, H, B, L, lr, max_iters, average_window=50, loss_delta_tol=1e-2,
+                 beta1=0.9, beta2=0.999, eps=1e-8, early_stop=True):
+        if len(xs) != len(kparams) or len(xs) == 0:
+            raise ValueError("need one parameter blob per clique batch")
+        self.K, self.H, self.B, self.L = int(K), int(H), float(B), int(L)
+        self.device = xs[0].device
+        self.xs = [_dev(x, "x") for x in xs]
+        self.kparams = [_dev(p, "kparams") for p in kparams]
+        for x, p in zip(self.xs, self.kparams):
+            if p.numel() != L * kparam_count(x.shape[1], K, H):
+                raise ValueError("kparams size does not match (D,K,H,L)")
+        self.m = [torch.zeros_like(p) for p in self.kparams]
+        self.v = [torch.zeros_like(p) for p in self.kparams]
+        self.g = [torch.zeros_like(p) for p in self.kparams]
+        self.iter_loss = [torch.zeros(max(int(max_iters), 1), dtype=torch.float32, device=self.device) for _ in xs]
+        self.states = torch.zeros(len(xs), 16, dtype=torch.int32, device=self.device)
+        self.cfg = AdamCfg(lr, beta1, beta2, eps, int(max_iters), int(average_window) if early_stop else 0,
+                           loss_delta_tol, 0)
+        self.nc = len(xs)
+        self.max_n = max(x.shape[0] for x in xs)
+        self.max_D = max(x.shape[1] for x in xs)
+        self.host_desc = (Clique * self.nc)()
+        for c in range(self.nc):
+            d = self.host_desc[c]
+            d.x = self.xs[c].data_ptr(); d.kparams = self.kparams[c].data_ptr()
+            d.adam_m = self.m[c].data_ptr(); d.adam_v = self.v[c].data_ptr(); d.kgrad = self.g[c].data_ptr()
+            d.iter_loss = self.iter_loss[c].data_ptr()
+            d.state = self.states.data_ptr() + 64 * c
+            d.n, d.D = self.xs[c].shape
+        raw = np.frombuffer(bytes(self.host_desc), dtype=np.uint8).copy()
+        self.dev_desc = torch.from_numpy(raw).to(self.device)
+
+    def step(self):
+        """Enqueue ONE training iteration for all cliques (no host sync)."""
+        if self.nc == 1:
+            rc = lib().nfisam_nsf_train_step(C.byref(self.host_desc[0]), 1, 1, self.max_n, self.max_D, self.K, self.H,
+                                             C.c_float(self.B), self.L, C.byref(self.cfg), _stream())
+        else:
+            rc = lib().nfisam_nsf_train_step(C.c_void_p(self.dev_desc.data_ptr()), self.nc, 0, self.max_n, self.max_D,
+                                             self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg), _stream())
+        _check(rc, "nfisam_nsf_train_step")
+
+    def run(self, use_graph=True):
+        """Run until every clique stopped early or reached max_iters.  Host-synchronising.
+        -> list of iterations run per clique."""
+        iters = (C.c_int32 * self.nc)()
+        rc = lib().nfisam_nsf_train_loop(self.host_desc, C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None,
+                                         self.nc, self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg),
+                                         int(bool(use_graph)), iters, _stream())
+        _check(rc, "nfisam_nsf_train_loop")
+        return [int(v) for v in iters]
+
+    def state(self, c=0):
+        s = self.states[c].cpu().numpy()
+        return {"step": int(s[0]), "stop": int(s[1]), "have_avg": int(s[2]),
+                "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[5])}

@@ -1,0 +1,86 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads, exports every symbol
+include/nfisam_hip.h declares, and the kernel<->reference parameter layout map is a bijection.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import nfisam_hip as nh
+from oracle import nsf_torch as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    nh.build()
+    lib = nh.lib()
+    hdr = open(os.path.join(ROOT, "include", "nfisam_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nfisam_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(nh.EXPORTS), declared ^ set(nh.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nfisam_abi_version() == 1000
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(nh.TrainState) == 64
+    assert C.sizeof(nh.AdamCfg) == 32
+    assert C.sizeof(nh.Clique) == 64
+
+
+@pytest.mark.parametrize("D,K,H", [(1, 9, 8), (2, 5, 8), (6, 9, 8), (11, 9, 8), (16, 12, 8), (30, 9, 8)])
+def test_layout_map_is_a_bijection_onto_reference_order(D, K, H):
+    P, Pk = nh.param_count(D, K, H), nh.kparam_count(D, K, H)
+    assert P == O.param_count(D, K, H)       # D=11,K=9,H=8 -> 3606 etc.
+    m = nh.layout_map(D, K, H)
+    assert m.shape == (Pk,)
+    real = m[m >= 0]
+    assert real.size == P and np.array_equal(np.sort(real), np.arange(P))
+    assert Pk % 4 == 0 and Pk >= P
+
+
+def test_param_counts_from_survey():
+    assert nh.param_count(11, 9, 8) == 3606
+    assert nh.param_count(6, 9, 8) == 1716
+    assert nh.param_count(30, 9, 8) == 12612
+
+
+def test_pack_unpack_roundtrip_and_transposes():
+    D, K, H, L = 5, 9, 8, 2
+    P = nh.param_count(D, K, H)
+    blob = torch.arange(L * P, dtype=torch.float32)
+    kb = nh.pack(blob, D, K, H, L)
+    assert kb.numel() == L * nh.kparam_count(D, K, H)
+    assert torch.equal(nh.unpack(kb, D, K, H, L), blob)
+    # spot-check: W2t[k][o] of dim i=2 equals W2[o][k]
+    init, nets = O.unpack(blob[:P], D, K, H)
+    Po, PoP = 3 * K - 1, (3 * K - 1 + 3) // 4 * 4
+    kfixed = H + H * H + H + H * PoP + PoP
+    i = 2
+    off = PoP + (i - 1) * kfixed + H * ((i - 1) * i // 2)
+    oW2 = i * H + H + H * H + H
+    W2 = nets[i - 1][4]
+    for k in (0, 3, 7):
+        for o in (0, 13, 25):
+            assert kb[off + oW2 + k * PoP + o] == W2[o, k]
+    W0 = nets[i - 1][0]
+    assert kb[off + 1 * H + 5] == W0[5, 1]
+
+
+def test_compute_entry_points_refuse_cpu_tensors():
+    x = torch.zeros(4, 3)
+    kp = torch.zeros(nh.kparam_count(3, 9, 8))
+    with pytest.raises(RuntimeError):
+        nh.forward(x, kp, 9, 8, 5.0)
+    with pytest.raises(RuntimeError):
+        nh.inverse(x, None, kp, 9, 8, 5.0)
+
+
+def test_supported_instantiations():
+    assert nh.supported(9, 8) and nh.supported(5, 8) and nh.supported(12, 8)
+    assert not nh.supported(9, 7)

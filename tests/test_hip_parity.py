@@ -1,0 +1,250 @@
+"""GPU parity tests: the hand-written gfx950 kernels, called through the C ABI
+(include/nfisam_hip.h via the ctypes binding), against
+  (1) golden vectors produced by the reference itself (tests/golden/*.npz) and
+  (2) the oracle (oracle/: C restatement in float64, torch restatement) on seeded inputs.
+
+Tolerances (the kernels use 1-ulp hardware exp2/log2/rcp, fp32 throughout):
+  z / x            1e-4 abs
+  log-det / loss   2e-4 abs
+  gradients        1e-3 rel + 2e-5 abs (of the n-normalised gradient)
+  Adam trajectory  after 10 steps: 2e-3 abs on parameters
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nfisam_hip as nh
+from oracle import c_oracle as CO
+from oracle import nsf_torch as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "nsf_*.npz")))
+DEV = "cuda:0"
+Z_ATOL, LD_ATOL = 1e-4, 2e-4
+
+
+def load(path):
+    g = dict(np.load(path))
+    n, D, K, H, seed = [int(v) for v in g["meta"]]
+    return g, n, D, K, H, float(g["B"])
+
+
+def sd_of(g, prefix):
+    return {k[len(prefix) + 2:].replace("__", "."): v for k, v in g.items() if k.startswith(prefix + "__")}
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV)
+
+
+def kpack(blob_np, D, K, H, L=1):
+    return nh.pack(dev(blob_np), D, K, H, L)
+
+
+def grad_close(got, ref, rtol=1e-3, atol=2e-5):
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[4:-4] for p in CASES])
+class TestAgainstReferenceGolden:
+    def test_forward(self, path):
+        g, n, D, K, H, B = load(path)
+        kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
+        z, ld, lp = nh.forward(dev(g["x"]), kp, K, H, B, want_logprob=True)
+        np.testing.assert_allclose(z.cpu().numpy(), g["z"], atol=Z_ATOL)
+        np.testing.assert_allclose(ld.cpu().numpy(), g["logdet"], atol=LD_ATOL)
+        np.testing.assert_allclose((lp - ld).cpu().numpy(), g["prior_logprob"], atol=LD_ATOL, rtol=1e-5)
+        # the reference's own (scrambled) return value is the fixed permutation of ours
+        np.testing.assert_allclose(z.cpu().numpy().T.reshape(-1).reshape(n, D), g["z_raw"], atol=Z_ATOL)
+
+    def test_nll_gradients(self, path):
+        g, n, D, K, H, B = load(path)
+        kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
+        kg, _, loss = nh.backward(dev(g["x"]), kp, K, H, B, nll_mode=True)
+        loss = loss.item() / n + 0.5 * D * np.log(2 * np.pi)
+        assert abs(loss - float(g["loss"])) < 2e-4
+        grad = nh.unpack(kg, D, K, H).cpu().numpy() / n
+        grad_close(grad, O.blob_from_state_dict(sd_of(g, "g0"), D))
+        # padding entries of the kernel layout never receive gradient
+        assert float(kg[torch.from_numpy(nh.layout_map(D, K, H) < 0).to(DEV)].abs().sum()) == 0.0
+
+    def test_adam_trajectory(self, path):
+        g, n, D, K, H, B = load(path)
+        kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
+        tb = nh.TrainBatch([dev(g["x"])], [kp], K, H, B, 1, lr=float(g["adam_lr"]), max_iters=10, early_stop=False)
+        snaps = {}
+        for it in range(10):
+            tb.step()
+            if it + 1 in (1, 2, 10):
+                snaps[it + 1] = nh.unpack(tb.kparams[0], D, K, H).cpu().numpy()
+        torch.cuda.synchronize()
+        assert tb.state()["step"] == 10 and tb.state()["stop"] == 0
+        np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy(), g["adam_losses"], atol=5e-4, rtol=1e-4)
+        for steps, atol in ((1, 2e-4), (2, 4e-4), (10, 2e-3)):
+            ref = O.blob_from_state_dict(sd_of(g, "p%d" % steps), D)
+            np.testing.assert_allclose(snaps[steps], ref, atol=atol, rtol=1e-3)
+        tb.step()   # beyond max_iters: must be a no-op
+        torch.cuda.synchronize()
+        assert tb.state()["step"] == 10
+
+    def test_inverse(self, path):
+        g, n, D, K, H, B = load(path)
+        kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
+        x, ld = nh.inverse(dev(g["zlat"]), None, kp, K, H, B, want_logdet=True)
+        np.testing.assert_allclose(x.cpu().numpy(), g["zlat_inv_x"], atol=2e-4)
+        np.testing.assert_allclose(ld.cpu().numpy(), g["zlat_inv_logdet"], atol=3e-4)
+        x2 = nh.inverse(dev(g["z"]), None, kp, K, H, B)
+        np.testing.assert_allclose(x2.cpu().numpy(), g["inv_x"], atol=2e-4)
+
+    def test_inverse_given_separator(self, path):
+        g, n, D, K, H, B = load(path)
+        kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
+        for Ds in (1, 3):
+            if "igs%d_x" % Ds not in g:
+                continue
+            xf = nh.inverse(dev(g["zlat"][:, Ds:]), dev(g["x"][:, :Ds]), kp, K, H, B)
+            np.testing.assert_allclose(xf.cpu().numpy(), g["igs%d_x" % Ds], atol=2e-4)
+
+
+def make_problem(n, D, K, H, L, seed, spread=1.6):
+    gen = torch.Generator().manual_seed(seed)
+    blob = torch.cat([O.init_blob(D, K, H, gen) for _ in range(L)])
+    blob = blob + 0.25 * torch.randn(blob.shape, generator=gen)
+    x = spread * torch.randn(n, D, generator=gen)
+    x[0, 0] = 5.5; x[1, D - 1] = -5.0; x[2, D // 2] = 5.0; x[3, 0] = float("nan") if False else 4.9999
+    return blob.numpy().astype(np.float32), x.numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("n,D,K,L", [(100, 5, 6, 2), (333, 6, 9, 4), (70, 12, 9, 3), (64, 1, 9, 2), (129, 20, 5, 1)])
+def test_multilayer_against_oracle(n, D, K, L):
+    """No usable multi-layer reference exists: parity is against the oracle."""
+    H, B = 8, 5.0
+    blob, x = make_problem(n, D, K, H, L, seed=n + D)
+    kp = kpack(blob, D, K, H, L)
+    zc, ldc = CO.forward(x, blob, K, H, B, L, dtype=np.float64)
+    z, ld, _ = nh.forward(dev(x), kp, K, H, B, L)
+    np.testing.assert_allclose(z.cpu().numpy(), zc, atol=Z_ATOL * L)
+    np.testing.assert_allclose(ld.cpu().numpy(), ldc, atol=LD_ATOL * L)
+    # NLL gradients incl. d/dx
+    lossc, gradc, lpc, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+    kg, gx, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
+    assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L
+    grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3)
+    grad_close(gx.cpu().numpy() / n, gxc, rtol=2e-3)
+    # generic VJP
+    rng = np.random.RandomState(n)
+    gz = rng.randn(n, D).astype(np.float32); gl = rng.randn(n).astype(np.float32)
+    grad4, gx4 = CO.backward(x, blob, gz, gl, K, H, B, L, dtype=np.float64)
+    kg2, gx2, _ = nh.backward(dev(x), kp, K, H, B, L, gz=dev(gz), gl=dev(gl), want_gx=True)
+    grad_close(nh.unpack(kg2, D, K, H, L).cpu().numpy(), grad4, rtol=2e-3, atol=5e-5)
+    grad_close(gx2.cpu().numpy(), gx4, rtol=2e-3, atol=5e-5)
+    # inverse of forward
+    xb, ldb = nh.inverse(z, None, kp, K, H, B, L, want_logdet=True)
+    inside = np.abs(x).max(1) < 4.9
+    np.testing.assert_allclose(xb.cpu().numpy()[inside], x[inside], atol=5e-4 * L)
+    # round trip of L*D chained splines: reconstruction error times |d logdet/dx| accumulates
+    np.testing.assert_allclose((ld + ldb).cpu().numpy()[inside], 0, atol=2e-3 * L)
+
+
+def test_conditional_sampling_with_fused_normalisation():
+    """nfisam_nsf_inverse == normalize_samples -> inverse_given_separator -> unnormalize_samples
+    (src/slam/NFiSAM.py:96-118,140-155)."""
+    n, D, Ds, K, H, B, L = 500, 9, 4, 9, 8, 5.0, 1
+    blob, _ = make_problem(8, D, K, H, L, seed=3)
+    rng = np.random.RandomState(0)
+    circ = np.array([0, 0, 1, 0, 0, 1, 0, 0, 1], dtype=bool)
+    mean = rng.randn(D).astype(np.float32) * 2; std = (0.3 + rng.rand(D)).astype(np.float32)
+    mean[circ] = np.array([3.0, -2.5, 0.4], dtype=np.float32)
+    xs_raw = (rng.randn(n, Ds) * 2 + mean[:Ds]).astype(np.float32)
+    z = (1.3 * rng.randn(n, D - Ds)).astype(np.float32)
+    xs_n = O.normalize_samples(xs_raw, mean, std, circ, 0)
+    xf_n, _ = CO.inverse(z, xs_n, blob, K, H, B, L, dtype=np.float64)
+    ref = O.unnormalize_samples(xf_n.astype(np.float32), mean, std, circ, Ds)
+    got = nh.inverse(dev(z), dev(xs_raw), kpack(blob, D, K, H, L), K, H, B, L, mean=dev(mean), std=dev(std),
+                     circular=torch.from_numpy(circ.astype(np.uint8)).to(DEV)).cpu().numpy()
+    d = got - ref
+    cidx = np.where(circ[Ds:])[0]
+    d[:, cidx] = (d[:, cidx] + np.pi) % (2 * np.pi) - np.pi      # compare angles on the circle
+    assert np.abs(d).max() < 5e-4
+    assert np.all(np.abs(got[:, cidx]) <= np.pi + 1e-6)
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_training_loop_early_stop_matches_oracle(use_graph):
+    n, D, K, H, B, L = 1000, 3, 5, 8, 5.0, 1
+    gen = torch.Generator().manual_seed(5)
+    blob = O.init_blob(D, K, H, gen).numpy()
+    x = torch.randn(n, D, generator=gen)
+    x[:, 1] = x[:, 0] ** 2 - 1 + 0.3 * x[:, 1]
+    x = ((x - x.mean(0)) / x.std(0)).numpy().astype(np.float32)
+    bc, lc, ic, _, _ = CO.train(x, blob, K, H, B, L, lr=0.03, max_iters=600, average_window=20,
+                                loss_delta_tol=5e-3, dtype=np.float32)
+    tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H)], K, H, B, L, lr=0.03, max_iters=600, average_window=20,
+                       loss_delta_tol=5e-3)
+    iters = tb.run(use_graph=use_graph)
+    il = tb.iter_loss[0].cpu().numpy()
+    assert iters[0] % 20 == 0 and 40 <= iters[0] < 600
+    assert np.all(il[iters[0]:] == 0) and np.all(il[:iters[0]] != 0)     # zero-padded like the reference
+    # trajectories agree while both run; the stop decision may differ by one window at the tolerance edge
+    m = min(ic, iters[0])
+    np.testing.assert_allclose(il[:m], lc[:m], atol=5e-3)
+    assert abs(iters[0] - ic) <= 20
+    assert il[iters[0] - 1] < il[0] - 0.05
+
+
+def test_batched_ragged_cliques_match_single_clique_runs():
+    K, H, B, L, iters = 9, 8, 5.0, 1, 7
+    shapes = [(200, 6), (64, 8), (129, 3), (1, 5), (333, 12)]
+    xs, blobs = [], []
+    for c, (n, D) in enumerate(shapes):
+        b, x = make_problem(n, D, K, H, L, seed=40 + c, spread=1.0)
+        xs.append(x); blobs.append(b)
+    tb = nh.TrainBatch([dev(x) for x in xs], [kpack(b, D, K, H) for b, (n, D) in zip(blobs, shapes)], K, H, B, L,
+                       lr=0.02, max_iters=iters, early_stop=False)
+    for _ in range(iters):
+        tb.step()
+    torch.cuda.synchronize()
+    for c, (n, D) in enumerate(shapes):
+        bc, lc, ic, _, _ = CO.train(xs[c], blobs[c], K, H, B, L, lr=0.02, max_iters=iters, early_stop=False,
+                                    dtype=np.float32)
+        np.testing.assert_allclose(tb.iter_loss[c].cpu().numpy(), lc, atol=5e-4, rtol=2e-4)
+        np.testing.assert_allclose(nh.unpack(tb.kparams[c], D, K, H).cpu().numpy(), bc, atol=2e-3, rtol=1e-3)
+
+
+def test_full_size_properties_config_c2():
+    """BASELINE config 2 (n=4096, D=6, L=4, K=9): size-independent properties."""
+    n, D, K, H, B, L = 4096, 6, 9, 8, 5.0, 4
+    blob, x = make_problem(n, D, K, H, L, seed=99, spread=1.0)
+    kp = kpack(blob, D, K, H, L)
+    xd = dev(x)
+    z, ld, lp = nh.forward(xd, kp, K, H, B, L, want_logprob=True)
+    xb, ldb = nh.inverse(z, None, kp, K, H, B, L, want_logdet=True)
+    inside = (xd.abs().max(1).values < 4.9)
+    assert float((xb - xd)[inside].abs().max()) < 2e-3
+    assert float((ld + ldb)[inside].abs().max()) < 2e-3
+    # loss from backward == -mean(logprob) from forward; gradient is deterministic up to atomics order
+    kg, _, loss = nh.backward(xd, kp, K, H, B, L, nll_mode=True)
+    assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) + lp.mean().item()) < 1e-3
+    kg2, _, _ = nh.backward(xd, kp, K, H, B, L, nll_mode=True)
+    assert float((kg - kg2).abs().max()) <= 1e-3 * float(kg.abs().max())
+    # 30 training iterations reduce the loss
+    tb = nh.TrainBatch([xd], [kp.clone()], K, H, B, L, lr=0.02, max_iters=30, early_stop=False)
+    assert tb.run(use_graph=True) == [30]
+    il = tb.iter_loss[0].cpu().numpy()
+    assert np.all(np.isfinite(il)) and il[-1] < il[0]
+
+
+def test_argument_errors_are_loud():
+    kp = torch.zeros(nh.kparam_count(3, 9, 8), device=DEV)
+    x = torch.zeros(4, 3, device=DEV)
+    with pytest.raises(ValueError):
+        nh.forward(x, kp, 7, 8, 5.0)          # unsupported K -> size mismatch / ERR_ARG
+    with pytest.raises(ValueError):
+        nh.forward(x, kp[:-4], 9, 8, 5.0)
+    with pytest.raises(ValueError):
+        nh.inverse(x, x, kp, 9, 8, 5.0)       # D would be 6: wrong blob size

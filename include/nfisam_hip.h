@@ -70,9 +70,16 @@ int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map);
 /* NSF_AR.forward chained over L layers + prior log-prob (flows.py:65-93, models.py:11-24),
  * in the CORRECT layout (the reference returns a scrambled one).
  *   x[n,D] -> z[n,D] (nullable), logdet[n] (nullable), logprob[n] (nullable)
- *   logprob = -0.5|z|^2 - D/2 log(2 pi) + logdet                                           */
+ *   logprob = -0.5|z|^2 - D/2 log(2 pi) + logdet
+ * layer_stride: floats between consecutive layers' parameter blocks; 0 = kparam_count(D).  Because
+ * the flow is autoregressive and dim i's block only depends on i, the first D' < D_model dims of a
+ * trained D_model-dimensional flow ARE its D'-dimensional marginal flow: pass D = D' and
+ * layer_stride = kparam_count(D_model) to evaluate it in place
+ * (NormalizingFlowModelWithSeparator.separator_forward, slam/NFiSAM.py:157-173).  The same argument
+ * exists on nfisam_nsf_inverse and nfisam_nsf_backward.                                     */
 int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
-                       int L, float* z, float* logdet, float* logprob, nfisam_stream_t stream);
+                       int L, size_t layer_stride, float* z, float* logdet, float* logprob,
+                       nfisam_stream_t stream);
 
 /* NSF_AR.inverse / inverse_given_separator (flows.py:95-137) fused with the adapter's
  * normalisation of the given columns and un-normalisation + angle wrap of the result
@@ -84,8 +91,18 @@ int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K
  *   x_out[n,D-Ds]; logdet[n] nullable (sum of -log|dz/dx| over the solved columns, as NSF_AR.inverse)
  * For L>1 every layer is conditioned on the same x_sep (slam/NFiSAM.py:151-152).           */
 int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds,
-                       int K, int H, float B, int L, const float* mean, const float* std,
+                       int K, int H, float B, int L, size_t layer_stride, const float* mean, const float* std,
                        const uint8_t* circular, float* x_out, float* logdet, nfisam_stream_t stream);
+
+/* Elementwise rational-quadratic spline with per-element logits (flows.utils.unconstrained_RQS and
+ * RQS, src/flows/utils.py:25-164).  inputs[M], widths[M,K], heights[M,K];
+ * padded_derivatives=1: derivs[M,K-1], end slopes fixed to 1 and identity outside the box
+ *                       (unconstrained_RQS with left=bottom=-tail_bound, right=top=tail_bound);
+ * padded_derivatives=0: derivs[M,K+1] (bounded RQS; callers validate the domain, utils.py:74-76).
+ * out[M], logabsdet[M].  Any K >= 1 with 1e-3*K <= 1 (utils.py:80-83).                      */
+int nfisam_rqs(const float* inputs, const float* widths, const float* heights, const float* derivs, int M, int K,
+               int inverse, float left, float right, float bottom, float top, int padded_derivatives,
+               float* out, float* logabsdet, nfisam_stream_t stream);
 
 /* ---- training -------------------------------------------------------------------------- */
 /* Vector-Jacobian product of the L-layer flow (what torch autograd computes for
@@ -95,8 +112,8 @@ int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams,
  * D/2 log 2pi for the reference's loss); loss_sum[1] += that sum (nullable).
  * kgrad / loss_sum are ACCUMULATED into (caller zeroes them).                               */
 int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
-                        const float* gz, const float* gl, int nll_mode, float* kgrad, float* gx,
-                        float* loss_sum, nfisam_stream_t stream);
+                        size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
+                        float* gx, float* loss_sum, nfisam_stream_t stream);
 
 /* Device-resident control block of one clique's training run. */
 typedef struct nfisam_train_state {
@@ -149,6 +166,17 @@ int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliqu
 int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,
                           int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int use_graph,
                           int32_t* iters_run, nfisam_stream_t stream);
+
+/* The same loop with the set-up split off, so that descriptor validation and hipGraph capture /
+ * instantiation happen once (outside any timed region) and the plan can be re-run, e.g. after the
+ * caller re-initialised parameters / Adam moments / state in place.  `plan_run` synchronises with
+ * the host after every chunk of `average_window` (50 if early stopping is off) iterations.      */
+typedef struct nfisam_train_plan nfisam_train_plan;
+int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,
+                                 int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int use_graph,
+                                 nfisam_train_plan** out);
+int nfisam_nsf_train_plan_run(nfisam_train_plan* plan, int32_t* iters_run, nfisam_stream_t stream);
+int nfisam_nsf_train_plan_destroy(nfisam_train_plan* plan);
 
 #ifdef __cplusplus
 }

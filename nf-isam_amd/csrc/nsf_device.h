@@ -129,6 +129,39 @@ struct Spline {
     bool inside;
 };
 
+// Rational-quadratic map inside one bin (utils.py:123-164).  Forward: v is x, returns z and
+// log dz/dx.  Inverse: v is z, solves the quadratic with the numerically stable root
+// 2c / (-b - sqrt(b^2 - 4ac)) (utils.py:126-136) and returns x and -log dz/dx.
+template <bool INV>
+__device__ __forceinline__ void rq_math(float vs, float Xk, float dx, float Yk, float dy, float d0, float d1,
+                                        float& t_out, float& out, float& lad) {
+    const float idx = frcp(dx);
+    const float s = dy * idx, sig = d0 + d1 - 2.0f * s;
+    float t;
+    if (INV) {
+        const float dl = vs - Yk;
+        const float a = dl * sig + dy * (s - d0);
+        const float b = dy * d0 - dl * sig;
+        const float c = -s * dl;
+        const float disc = fmaxf(b * b - 4.0f * a * c, 0.0f);
+        t = (2.0f * c) * frcp(-b - __builtin_sqrtf(disc));
+        out = t * dx + Xk;
+    } else {
+        t = (vs - Xk) * idx;
+    }
+    t_out = t;
+    const float q = t * (1.0f - t), omt = 1.0f - t;
+    const float den = s + sig * q;
+    const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
+    const float l = flog(s * s * M) - 2.0f * flog(den);
+    if (INV) {
+        lad = -l;
+    } else {
+        out = Yk + dy * (s * t * t + d0 * q) * frcp(den);
+        lad = l;
+    }
+}
+
 template <int K, int PoP, bool INV>
 __device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], float B, Spline<K>& S,
                                             float& out, float& lad) {
@@ -167,31 +200,7 @@ __device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], flo
     }
     S.d0 = kMinDeriv + fsoftplus(S.ud0);
     S.d1 = kMinDeriv + fsoftplus(S.ud1);
-    const float idx = frcp(S.dx);
-    const float s = S.dy * idx, sig = S.d0 + S.d1 - 2.0f * s;
-    float t;
-    if (INV) {
-        const float dl = vs - S.Yk;
-        const float a = dl * sig + S.dy * (s - S.d0);
-        const float b = S.dy * S.d0 - dl * sig;
-        const float c = -s * dl;
-        const float disc = fmaxf(b * b - 4.0f * a * c, 0.0f);
-        t = (2.0f * c) * frcp(-b - __builtin_sqrtf(disc));
-        out = t * S.dx + S.Xk;
-    } else {
-        t = (vs - S.Xk) * idx;
-    }
-    S.t = t;
-    const float q = t * (1.0f - t), omt = 1.0f - t;
-    const float den = s + sig * q;
-    const float M = S.d1 * t * t + 2.0f * s * q + S.d0 * omt * omt;
-    const float l = flog(s * s * M) - 2.0f * flog(den);
-    if (INV) {
-        lad = -l;
-    } else {
-        out = S.Yk + S.dy * (s * t * t + S.d0 * q) * frcp(den);
-        lad = l;
-    }
+    rq_math<INV>(vs, S.Xk, S.dx, S.Yk, S.dy, S.d0, S.d1, S.t, out, lad);
     if (!S.inside) { out = v; lad = 0.0f; }
 }
 

@@ -70,6 +70,7 @@ struct TrainArgs {
     int L;
     int max_iters;
     int nll_mode;
+    int layer_stride;               // floats between layers in kparams/kgrad (0: kparam_count(D))
 };
 
 template <int K, int H>
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     __syncthreads();
 
     cfloat* kp = (cfloat*)kparams;
-    const int Pk = LY::count(D);
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
 
     // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
     for (int l = 0; l + 1 < L; ++l) {
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
 // =============================================================================================
 template <int K, int H>
 __global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restrict__ x, const float* kparams,
-                                                           int n, int D, float B, int L,
+                                                           int n, int D, float B, int L, int layer_stride,
                                                            float* __restrict__ z, float* __restrict__ logdet,
                                                            float* __restrict__ logprob) {
     using LY = Layout<K, H>;
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restric
     if (threadIdx.x < TILE) ldacc[threadIdx.x] = 0.0f;
     __syncthreads();
     cfloat* kp = (cfloat*)kparams;
-    const int Pk = LY::count(D);
+    const int Pk = layer_stride > 0 ? layer_stride : LY::count(D);
     float* xin = xa;
     float* xout = xb;
     for (int l = 0; l < L; ++l) {
@@ -446,7 +447,7 @@ __device__ __forceinline__ float wrap_pi(float t) {   // src/utils/Functions.py:
 template <int K, int H>
 __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict__ zin, const float* __restrict__ x_sep,
                                                          const float* kparams, int n, int D, int Ds, float B, int L,
-                                                         const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                         int layer_stride, const float* __restrict__ mean, const float* __restrict__ stdv,
                                                          const uint8_t* __restrict__ circ,
                                                          float* __restrict__ x_out, float* __restrict__ logdet) {
     using LY = Layout<K, H>;
@@ -475,7 +476,7 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
     }
     __syncthreads();
     cfloat* kp = (cfloat*)kparams;
-    const int Pk = LY::count(D);
+    const int Pk = layer_stride > 0 ? layer_stride : LY::count(D);
     float ld = 0.0f;
     for (int l = L - 1; l >= 0; --l) {
         cfloat* lp = kp + (size_t)l * Pk;
@@ -504,6 +505,59 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
         }
     }
     if (logdet != nullptr && p0 + lane < n) logdet[p0 + lane] = ld;
+}
+
+// =============================================================================================
+// elementwise spline with per-element logits in memory (flows.utils.unconstrained_RQS / RQS,
+// src/flows/utils.py:25-164).  Runtime K: the logits are streamed twice (softmax statistics, then
+// cumulative knots + bin selection) so no per-lane arrays are needed.  HBM/latency-bound helper of
+// the module surface, not part of the fused clique path.
+// =============================================================================================
+template <bool INV>
+__global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ inp, const float* __restrict__ Wl,
+                                                      const float* __restrict__ Hl, const float* __restrict__ Dl,
+                                                      int M, int K, float xl, float xr, float yb, float yt,
+                                                      int padded, float* __restrict__ out, float* __restrict__ lad_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M) return;
+    const float v = inp[e];
+    const bool inside = INV ? (v >= yb && v <= yt) : (v >= xl && v <= xr);
+    const float vs = inside ? v : (INV ? yb : xl);
+    const float* w = Wl + (size_t)e * K;
+    const float* h = Hl + (size_t)e * K;
+    const float* d = Dl + (size_t)e * (padded ? (K - 1) : (K + 1));
+    float mw = w[0], mh = h[0];
+    for (int j = 1; j < K; ++j) { mw = fmaxf(mw, w[j]); mh = fmaxf(mh, h[j]); }
+    float sw = 0.0f, sh = 0.0f;
+    for (int j = 0; j < K; ++j) { sw += fexp(w[j] - mw); sh += fexp(h[j] - mh); }
+    const float iw = frcp(sw), ih = frcp(sh);
+    const float mix = 1.0f - kMinBin * (float)K;
+    float cx = 0.0f, cy = 0.0f, Xl = xl, Yl = yb;
+    int k = 0;
+    float Xk = xl, Yk = yb, dx = 1.0f, dy = 1.0f;
+    for (int j = 0; j < K; ++j) {
+        cx += kMinBin + mix * fexp(w[j] - mw) * iw;
+        cy += kMinBin + mix * fexp(h[j] - mh) * ih;
+        const float Xr = (j == K - 1) ? xr : (xr - xl) * cx + xl;
+        const float Yr = (j == K - 1) ? yt : (yt - yb) * cy + yb;
+        const bool sel = INV ? (vs >= Yl) : (vs >= Xl);
+        if (sel) { k = j; Xk = Xl; dx = Xr - Xl; Yk = Yl; dy = Yr - Yl; }
+        Xl = Xr; Yl = Yr;
+    }
+    float ud0, ud1;
+    if (padded) {
+        ud0 = (k == 0) ? kBoundLogit : d[k - 1];
+        ud1 = (k == K - 1) ? kBoundLogit : d[k];
+    } else {
+        ud0 = d[k];
+        ud1 = d[k + 1];
+    }
+    const float d0 = kMinDeriv + fsoftplus(ud0), d1 = kMinDeriv + fsoftplus(ud1);
+    float t, o, l;
+    rq_math<INV>(vs, Xk, dx, Yk, dy, d0, d1, t, o, l);
+    if (!inside) { o = v; l = 0.0f; }
+    out[e] = o;
+    lad_out[e] = l;
 }
 
 // =============================================================================================
@@ -579,8 +633,10 @@ static int set_lds(KernelT kernel, size_t bytes) {
 }
 
 extern "C" int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
-                                  int L, float* z, float* logdet, float* logprob, nfisam_stream_t stream) {
+                                  int L, size_t layer_stride, float* z, float* logdet, float* logprob,
+                                  nfisam_stream_t stream) {
     if (x == nullptr || kparams == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0)) return NFISAM_ERR_ARG;
+    if (layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
     if (n == 0) return NFISAM_OK;
     const int W = pick_waves(D);
     const size_t lds = ((size_t)2 * D * TILE + TILE) * sizeof(float);
@@ -588,15 +644,17 @@ extern "C" int nfisam_nsf_forward(const float* x, const float* kparams, int n, i
         int rc = set_lds(nsf_forward_kernel<KK, HH>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((nsf_forward_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64 * W), lds,
-                           (hipStream_t)stream, x, kparams, n, D, B, L, z, logdet, logprob);
+                           (hipStream_t)stream, x, kparams, n, D, B, L, (int)layer_stride, z, logdet, logprob);
     });
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
 }
 
 extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds,
-                                  int K, int H, float B, int L, const float* mean, const float* stdv,
-                                  const uint8_t* circular, float* x_out, float* logdet, nfisam_stream_t stream) {
+                                  int K, int H, float B, int L, size_t layer_stride, const float* mean,
+                                  const float* stdv, const uint8_t* circular, float* x_out, float* logdet,
+                                  nfisam_stream_t stream) {
+    if (D >= 1 && layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
     if (z == nullptr || kparams == nullptr || x_out == nullptr || n < 0 || D < 1 || Ds < 0 || Ds >= D || L < 1 ||
         !(B > 0) || (Ds > 0 && x_sep == nullptr) || (mean != nullptr && stdv == nullptr))
         return NFISAM_ERR_ARG;
@@ -606,9 +664,28 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
         int rc = set_lds(nsf_inverse_kernel<KK, HH>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((nsf_inverse_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
-                           (hipStream_t)stream, z, x_sep, kparams, n, D, Ds, B, L, mean, stdv, circular, x_out,
-                           logdet);
+                           (hipStream_t)stream, z, x_sep, kparams, n, D, Ds, B, L, (int)layer_stride, mean, stdv, circular,
+                           x_out, logdet);
     });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_rqs(const float* inputs, const float* widths, const float* heights, const float* derivs,
+                          int M, int K, int inverse, float left, float right, float bottom, float top,
+                          int padded_derivatives, float* out, float* logabsdet, nfisam_stream_t stream) {
+    if (inputs == nullptr || widths == nullptr || heights == nullptr || derivs == nullptr || out == nullptr ||
+        logabsdet == nullptr || M < 0 || K < 1 || !(right > left) || !(top > bottom) || (padded_derivatives && K < 1) ||
+        kMinBin * (float)K > 1.0f)
+        return NFISAM_ERR_ARG;
+    if (M == 0) return NFISAM_OK;
+    const dim3 grid((M + 255) / 256), block(256);
+    if (inverse)
+        hipLaunchKernelGGL((nsf_rqs_kernel<true>), grid, block, 0, (hipStream_t)stream, inputs, widths, heights, derivs,
+                           M, K, left, right, bottom, top, padded_derivatives ? 1 : 0, out, logabsdet);
+    else
+        hipLaunchKernelGGL((nsf_rqs_kernel<false>), grid, block, 0, (hipStream_t)stream, inputs, widths, heights, derivs,
+                           M, K, left, right, bottom, top, padded_derivatives ? 1 : 0, out, logabsdet);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
 }
@@ -627,8 +704,9 @@ static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D,
 }
 
 extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
-                                   const float* gz, const float* gl, int nll_mode, float* kgrad, float* gx,
-                                   float* loss_sum, nfisam_stream_t stream) {
+                                   size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
+                                   float* gx, float* loss_sum, nfisam_stream_t stream) {
+    if (D >= 1 && layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
     if (x == nullptr || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
         (!nll_mode && gz == nullptr))
         return NFISAM_ERR_ARG;
@@ -641,7 +719,7 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
     a.single.n = n;
     a.single.D = D;
     a.gz = gz; a.gl = gl; a.gx = gx; a.loss_sum = loss_sum;
-    a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0;
+    a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0; a.layer_stride = (int)layer_stride;
     return launch_train(a, 1, n, D, K, H, (hipStream_t)stream);
 }
 
@@ -688,83 +766,123 @@ extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques
     return enqueue_step(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, cfg, (hipStream_t)stream);
 }
 
+// ---- training plan: descriptors + (optionally) a hipGraph of `chunk` iterations, built once ----
+struct nfisam_train_plan {
+    std::vector<nfisam_clique> host;
+    const nfisam_clique* dev = nullptr;
+    int n_cliques = 0, K = 0, H = 0, L = 0, max_n = 0, max_D = 0, chunk = 0;
+    float B = 0;
+    nfisam_adam_cfg cfg;
+    hipStream_t cap = nullptr;
+    hipEvent_t ev = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<nfisam_train_state> hst;
+};
+
+extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
+    if (p == nullptr) return NFISAM_OK;
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->ev) (void)hipEventDestroy(p->ev);
+    if (p->cap) (void)hipStreamDestroy(p->cap);
+    delete p;
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
+                                            int n_cliques, int K, int H, float B, int L,
+                                            const nfisam_adam_cfg* cfg, int use_graph, nfisam_train_plan** out) {
+    int rc = check_cfg(cfg, K, H, L, B);
+    if (rc) return rc;
+    if (out == nullptr || host_cliques == nullptr || n_cliques < 1 || (n_cliques > 1 && dev_cliques == nullptr))
+        return NFISAM_ERR_ARG;
+    nfisam_train_plan* p = new nfisam_train_plan();
+    p->host.assign(host_cliques, host_cliques + n_cliques);
+    p->dev = dev_cliques;
+    p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
+    p->chunk = (cfg->average_window > 0) ? cfg->average_window : 50;
+    p->hst.resize(n_cliques);
+    for (int c = 0; c < n_cliques; ++c) {
+        if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { delete p; return NFISAM_ERR_ARG; }
+        p->max_n = host_cliques[c].n > p->max_n ? host_cliques[c].n : p->max_n;
+        p->max_D = host_cliques[c].D > p->max_D ? host_cliques[c].D : p->max_D;
+    }
+    if (use_graph) {
+        // capture on a private stream: the caller's stream may be the (un-capturable) null stream
+        int status = NFISAM_OK;
+        hipError_t e = hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
+            for (int it = 0; it < p->chunk && status == NFISAM_OK; ++it)
+                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, p->cap);
+            e = hipStreamEndCapture(p->cap, &p->graph);
+        }
+        if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess || status != NFISAM_OK) {
+            if (e != hipSuccess) g_last_hip_error = (int)e;
+            nfisam_nsf_train_plan_destroy(p);
+            return status != NFISAM_OK ? status : NFISAM_ERR_LAUNCH;
+        }
+    }
+    *out = p;
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_run, nfisam_stream_t stream) {
+    if (p == nullptr) return NFISAM_ERR_ARG;
+    hipStream_t user = (hipStream_t)stream;
+    hipStream_t work = user;
+    const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
+    if (p->exec) {
+        HIP_TRY(hipEventRecord(p->ev, user));          // order after prior work on the caller's stream
+        HIP_TRY(hipStreamWaitEvent(p->cap, p->ev, 0));
+        work = p->cap;
+    }
+    int status = NFISAM_OK, done = 0;
+    bool read_back = false;
+    while (done < p->cfg.max_iters) {
+        if (p->exec) {
+            HIP_TRY(hipGraphLaunch(p->exec, work));
+        } else {
+            for (int it = 0; it < p->chunk; ++it) {
+                int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
+                                      &p->cfg, work);
+                if (rc) return rc;
+            }
+        }
+        done += p->chunk;
+        for (int c = 0; c < p->n_cliques; ++c)
+            HIP_TRY(hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost,
+                                   work));
+        HIP_TRY(hipStreamSynchronize(work));
+        read_back = true;
+        bool all_stopped = true;
+        for (int c = 0; c < p->n_cliques; ++c) {
+            if (p->hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
+            if (!p->hst[c].stop && p->hst[c].step < p->cfg.max_iters) all_stopped = false;
+        }
+        if (all_stopped || status != NFISAM_OK) break;
+    }
+    if (!read_back) {
+        for (int c = 0; c < p->n_cliques; ++c)
+            HIP_TRY(hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost,
+                                   work));
+        HIP_TRY(hipStreamSynchronize(work));
+    }
+    if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
+    return status;
+}
+
 extern "C" int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
                                      int n_cliques, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
                                      int use_graph, int32_t* iters_run, nfisam_stream_t stream) {
-    int rc = check_cfg(cfg, K, H, L, B);
+    nfisam_train_plan* p = nullptr;
+    int rc = nfisam_nsf_train_plan_create(host_cliques, dev_cliques, n_cliques, K, H, B, L, cfg, use_graph, &p);
     if (rc) return rc;
-    if (host_cliques == nullptr || n_cliques < 1 || (n_cliques > 1 && dev_cliques == nullptr)) return NFISAM_ERR_ARG;
-    int max_n = 0, max_D = 0;
-    for (int c = 0; c < n_cliques; ++c) {
-        if (host_cliques[c].n < 1 || host_cliques[c].D < 1) return NFISAM_ERR_ARG;
-        max_n = host_cliques[c].n > max_n ? host_cliques[c].n : max_n;
-        max_D = host_cliques[c].D > max_D ? host_cliques[c].D : max_D;
-    }
-    hipStream_t user = (hipStream_t)stream;
-    const nfisam_clique* single = (dev_cliques == nullptr) ? host_cliques : nullptr;
-    const int chunk = (cfg->average_window > 0) ? cfg->average_window : 50;
-    std::vector<nfisam_train_state> hst(n_cliques);
-
-    // A capturable stream: the user's stream may be the (un-capturable) null stream.
-    hipStream_t work = user;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipStream_t cap = nullptr;
-    hipEvent_t ev = nullptr;
-    int status = NFISAM_OK;
-    if (use_graph) {
-        HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev, user));            // order after prior work on the user stream
-        HIP_TRY(hipStreamWaitEvent(cap, ev, 0));
-        work = cap;
-        HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-        for (int it = 0; it < chunk && status == NFISAM_OK; ++it)
-            status = enqueue_step(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg, cap);
-        hipError_t e = hipStreamEndCapture(cap, &graph);
-        if (status == NFISAM_OK && e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; }
-        if (status == NFISAM_OK) {
-            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; }
-        }
-    }
-    int done = 0;
-    while (status == NFISAM_OK && done < cfg->max_iters) {
-        if (use_graph) {
-            hipError_t e = hipGraphLaunch(exec, work);
-            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
-        } else {
-            for (int it = 0; it < chunk && status == NFISAM_OK; ++it)
-                status = enqueue_step(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg, work);
-            if (status != NFISAM_OK) break;
-        }
-        done += chunk;
-        bool all_stopped = true;
-        for (int c = 0; c < n_cliques; ++c) {
-            hipError_t e = hipMemcpyAsync(&hst[c], host_cliques[c].state, sizeof(nfisam_train_state),
-                                          hipMemcpyDeviceToHost, work);
-            if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
-        }
-        if (status != NFISAM_OK) break;
-        hipError_t e = hipStreamSynchronize(work);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; status = NFISAM_ERR_LAUNCH; break; }
-        for (int c = 0; c < n_cliques; ++c) {
-            if (hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
-            if (!hst[c].stop && hst[c].step < cfg->max_iters) all_stopped = false;
-        }
-        if (all_stopped) break;
-    }
-    if (status == NFISAM_OK || status == NFISAM_ERR_DOMAIN) {
-        if (done == 0) {   // max_iters == 0: report current steps
-            for (int c = 0; c < n_cliques; ++c) {
-                (void)hipMemcpy(&hst[c], host_cliques[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost);
-            }
-        }
-        if (iters_run != nullptr) for (int c = 0; c < n_cliques; ++c) iters_run[c] = hst[c].step;
-    }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    if (ev) (void)hipEventDestroy(ev);
-    if (cap) (void)hipStreamDestroy(cap);
-    return status;
+    rc = nfisam_nsf_train_plan_run(p, iters_run, stream);
+    nfisam_nsf_train_plan_destroy(p);
+    return rc;
 }

@@ -21,7 +21,8 @@ OK, ERR_ARG, ERR_LAUNCH, ERR_DOMAIN, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
-    "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop",
+    "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
+    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs",
 ]
 
 
@@ -164,21 +165,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def forward(x, kparams, K, H, B, L=1, want_z=True, want_logdet=True, want_logprob=False):
+def _stride(kparams, D, K, H, L, model_D):
+    """size_t layer stride for a (possibly truncated) evaluation; validates the blob size."""
+    md = D if model_D is None else int(model_D)
+    if md < D:
+        raise ValueError("model_D=%d is smaller than the evaluated dimension %d" % (md, D))
+    if kparams.numel() != L * kparam_count(md, K, H):
+        raise ValueError("kparams has %d elements, expected %d" % (kparams.numel(), L * kparam_count(md, K, H)))
+    return C.c_size_t(0 if md == D else kparam_count(md, K, H))
+
+
+def forward(x, kparams, K, H, B, L=1, want_z=True, want_logdet=True, want_logprob=False, model_D=None):
     """x[n,D] -> (z, logdet, logprob) (None for the ones not requested)."""
     _dev(x, "x"); _dev(kparams, "kparams")
     n, D = x.shape
-    if kparams.numel() != L * kparam_count(D, K, H):
-        raise ValueError("kparams has %d elements, expected %d" % (kparams.numel(), L * kparam_count(D, K, H)))
+    stride = _stride(kparams, D, K, H, L, model_D)
     z = torch.empty_like(x) if want_z else None
     ld = torch.empty(n, dtype=torch.float32, device=x.device) if want_logdet else None
     lp = torch.empty(n, dtype=torch.float32, device=x.device) if want_logprob else None
-    _check(lib().nfisam_nsf_forward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), _ptr(z),
+    _check(lib().nfisam_nsf_forward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), stride, _ptr(z),
                                     _ptr(ld), _ptr(lp), _stream()), "nfisam_nsf_forward")
     return z, ld, lp
 
 
-def inverse(z, x_sep, kparams, K, H, B, L=1, mean=None, std=None, circular=None, want_logdet=False):
+def inverse(z, x_sep, kparams, K, H, B, L=1, mean=None, std=None, circular=None, want_logdet=False,
+            model_D=None):
     """z[n,D-Ds], x_sep[n,Ds] raw (or None) -> x_free[n,D-Ds] (and logdet[n])."""
     _dev(z, "z"); _dev(kparams, "kparams"); _dev(x_sep, "x_sep"); _dev(mean, "mean"); _dev(std, "std")
     _dev(circular, "circular", torch.uint8)
@@ -187,27 +198,55 @@ def inverse(z, x_sep, kparams, K, H, B, L=1, mean=None, std=None, circular=None,
     D = Ds + F
     if x_sep is not None and x_sep.shape[0] != n:
         raise ValueError("x_sep and z disagree on the number of particles")
-    if kparams.numel() != L * kparam_count(D, K, H):
-        raise ValueError("kparams has %d elements, expected %d" % (kparams.numel(), L * kparam_count(D, K, H)))
+    stride = _stride(kparams, D, K, H, L, model_D)
     for t, nm in ((mean, "mean"), (std, "std"), (circular, "circular")):
-        if t is not None and t.numel() != D:
-            raise ValueError("%s must have D=%d entries" % (nm, D))
+        if t is not None and t.numel() < D:
+            raise ValueError("%s must have at least D=%d entries" % (nm, D))
     out = torch.empty_like(z)
     ld = torch.empty(n, dtype=torch.float32, device=z.device) if want_logdet else None
     _check(lib().nfisam_nsf_inverse(_ptr(z), _ptr(x_sep), _ptr(kparams), n, D, Ds, int(K), int(H), C.c_float(B),
-                                    int(L), _ptr(mean), _ptr(std), _ptr(circular), _ptr(out), _ptr(ld), _stream()),
+                                    int(L), stride, _ptr(mean), _ptr(std), _ptr(circular), _ptr(out), _ptr(ld), _stream()),
            "nfisam_nsf_inverse")
     return (out, ld) if want_logdet else out
 
 
-def backward(x, kparams, K, H, B, L=1, gz=None, gl=None, nll_mode=False, want_gx=False):
+def _rqs_call(inputs, w, h, d, inverse, left, right, bottom, top, padded):
+    shape = inputs.shape
+    inp = _dev(inputs.reshape(-1).contiguous().float(), "inputs")
+    K = w.shape[-1]
+    M = inp.numel()
+    dc = K - 1 if padded else K + 1
+    w = _dev(w.reshape(M, K).contiguous().float(), "unnormalized_widths")
+    h = _dev(h.reshape(M, K).contiguous().float(), "unnormalized_heights")
+    d = _dev(d.reshape(M, dc).contiguous().float(), "unnormalized_derivatives")
+    if K * 1e-3 > 1.0:
+        raise ValueError("Minimal bin width too large for the number of bins")
+    out = torch.empty_like(inp); lad = torch.empty_like(inp)
+    _check(lib().nfisam_rqs(_ptr(inp), _ptr(w), _ptr(h), _ptr(d), M, K, int(inverse), C.c_float(left),
+                            C.c_float(right), C.c_float(bottom), C.c_float(top), int(padded), _ptr(out), _ptr(lad),
+                            _stream()), "nfisam_rqs")
+    return out.reshape(shape), lad.reshape(shape)
+
+
+def rqs(inputs, widths, heights, derivs, inverse, tail_bound):
+    """unconstrained_RQS: derivs has K-1 columns, linear tails outside [-tail_bound, tail_bound]."""
+    return _rqs_call(inputs, widths, heights, derivs, inverse, -tail_bound, tail_bound, -tail_bound, tail_bound, True)
+
+
+def rqs_box(inputs, widths, heights, derivs, inverse, left, right, bottom, top):
+    """bounded RQS: derivs has K+1 columns."""
+    return _rqs_call(inputs, widths, heights, derivs, inverse, left, right, bottom, top, False)
+
+
+def backward(x, kparams, K, H, B, L=1, gz=None, gl=None, nll_mode=False, want_gx=False, model_D=None):
     """VJP of the flow.  -> (kgrad[L*Pk], gx[n,D] or None, loss_sum tensor[1] or None)."""
     _dev(x, "x"); _dev(kparams, "kparams"); _dev(gz, "gz"); _dev(gl, "gl")
     n, D = x.shape
+    stride = _stride(kparams, D, K, H, L, model_D)
     kgrad = torch.zeros_like(kparams)
     gx = torch.empty_like(x) if want_gx else None
     loss = torch.zeros(1, dtype=torch.float32, device=x.device) if nll_mode else None
-    _check(lib().nfisam_nsf_backward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), _ptr(gz),
+    _check(lib().nfisam_nsf_backward(_ptr(x), _ptr(kparams), n, D, int(K), int(H), C.c_float(B), int(L), stride, _ptr(gz),
                                      _ptr(gl), int(bool(nll_mode)), _ptr(kgrad), _ptr(gx), _ptr(loss), _stream()),
            "nfisam_nsf_backward")
     return kgrad, gx, loss
@@ -262,15 +301,48 @@ class TrainBatch:
                                              self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg), _stream())
         _check(rc, "nfisam_nsf_train_step")
 
+    def prepare(self, use_graph=True):
+        """Validate descriptors and (optionally) capture + instantiate the hipGraph of one chunk of
+        iterations.  One-time set-up; `run` calls it on first use."""
+        if getattr(self, "_plan", None) is not None and self._plan_graph == bool(use_graph):
+            return
+        self.close()
+        plan = C.c_void_p(0)
+        rc = lib().nfisam_nsf_train_plan_create(self.host_desc,
+                                                C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None,
+                                                self.nc, self.K, self.H, C.c_float(self.B), self.L,
+                                                C.byref(self.cfg), int(bool(use_graph)), C.byref(plan))
+        _check(rc, "nfisam_nsf_train_plan_create")
+        self._plan, self._plan_graph = plan, bool(use_graph)
+
     def run(self, use_graph=True):
-        """Run until every clique stopped early or reached max_iters.  Host-synchronising.
+        """Run until every clique stopped early or reached max_iters (the reference's
+        `for i in range(flow_iterations)` loop).  Host-synchronising once per chunk.
         -> list of iterations run per clique."""
+        self.prepare(use_graph)
         iters = (C.c_int32 * self.nc)()
-        rc = lib().nfisam_nsf_train_loop(self.host_desc, C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None,
-                                         self.nc, self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg),
-                                         int(bool(use_graph)), iters, _stream())
-        _check(rc, "nfisam_nsf_train_loop")
+        _check(lib().nfisam_nsf_train_plan_run(self._plan, iters, _stream()), "nfisam_nsf_train_plan_run")
         return [int(v) for v in iters]
+
+    def reset(self, kparams=None):
+        """Re-initialise Adam moments / state / loss record in place (pointers stay valid, so a
+        prepared plan can be re-run)."""
+        for c in range(self.nc):
+            if kparams is not None:
+                self.kparams[c].copy_(kparams[c])
+            self.m[c].zero_(); self.v[c].zero_(); self.g[c].zero_(); self.iter_loss[c].zero_()
+        self.states.zero_()
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None:
+            lib().nfisam_nsf_train_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def state(self, c=0):
         s = self.states[c].cpu().numpy()

@@ -1,0 +1,387 @@
+"""slam.NFiSAM — density-model adapter of NF-iSAM on MI355X (reference: src/slam/NFiSAM.py).
+
+Same names and call signatures as the reference: `NFiSAMArgs`, `NormalizingFlowModelWithSeparator`,
+`FlowsPriorFactor`, `NFiSAM` with the solver hooks `fit_clique_density_model`,
+`root_clique_density_model_to_leaf`, `clique_density_to_separator_factor`.
+
+What changes underneath:
+  * the `for i in range(flow_iterations)` loop (NFiSAM.py:451-491: forward, loss, autograd
+    backward, Adam, window early stop — ~4.4k eager ops per iteration) is ONE device-resident loop:
+    a fused forward+backward kernel and a fused Adam/early-stop kernel per iteration, replayed from
+    a hipGraph; the host only reads a stop flag once per `average_window` iterations;
+  * conditional sampling (NFiSAM.py:120-155) is one kernel that also normalises the given columns
+    and un-normalises / angle-wraps the result;
+  * trained models stay on the GPU (the reference moves them to the CPU because its sampling
+    runs there, NFiSAM.py:507-511).
+`cuda_training` / `adaptive_flow_setup` / `data_parallel` are accepted and ignored: there is no CPU
+path to choose.
+"""
+import logging
+import time
+from typing import List
+
+import numpy as np
+import torch
+from scipy.stats import circmean
+
+import nfisam_hip as _nh
+from flows.flows import NSF_AR
+from flows.models import NormalizingFlowModel
+from flows.prior_dist import CustomMultivariateNormal, MultivariateNormalVonmises  # noqa: F401
+from slam.FactorGraphSolver import CliqueSeparatorFactor, ConditionalSampler, FactorGraphSolver, SolverArgs
+from utils.Functions import theta_to_pipi
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("slam.NFiSAM needs a ROCm device (MI355X): the flow hot path has no CPU fallback")
+    return "cuda:%d" % torch.cuda.current_device()
+
+
+class NFiSAMArgs(SolverArgs):
+    """reference: NFiSAM.py:18-66 (same keyword names and defaults)."""
+
+    def __init__(self, elimination_method: str = "pose_first", posterior_sample_num: int = 500,
+                 local_sample_num: int = 500, store_clique_samples: bool = False, local_sampling_method="direct",
+                 learning_rate: float = 0.015, flow_number: int = 1, flow_type: str = "NSF_AR",
+                 flow_iterations: int = 10, num_knots: int = 12, cuda_training: bool = False,
+                 adaptive_flow_setup: bool = False, hidden_dim: int = 8, average_window=50, loss_delta_tol=1e-2,
+                 training_set_frac=1.0, validation_interval=10, slower_stop_rate=2.0, data_parallel=False,
+                 training_loss_dir=None, *args, **kwargs):
+        super().__init__(elimination_method=elimination_method, posterior_sample_num=posterior_sample_num,
+                         local_sample_num=local_sample_num, store_clique_samples=store_clique_samples,
+                         local_sampling_method=local_sampling_method, *args, **kwargs)
+        self.flow_number = flow_number
+        self.flow_type = flow_type
+        self.flow_iterations = flow_iterations
+        self.num_knots = num_knots
+        self.cuda_training = cuda_training
+        self.learning_rate = learning_rate
+        self.adaptive_flow_setup = adaptive_flow_setup
+        self.hidden_dim = hidden_dim
+        self.average_window = average_window
+        self.loss_delta_tol = loss_delta_tol
+        self.training_set_frac = training_set_frac
+        self.validation_interval = validation_interval
+        self.slower_stop_rate = slower_stop_rate
+        self.data_parallel = data_parallel
+        self.training_loss_dir = training_loss_dir
+        self.tl_cnt = 0
+
+
+class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler):
+    """Joint density of a clique's (observation | separator | frontal) columns as a normalizing
+    flow with input normalisation (reference: NFiSAM.py:68-199)."""
+
+    def __init__(self, flows, prior, separator_prior, circular_dim_list, samples_mean: "torch.Tensor" = None,
+                 samples_std: "torch.Tensor" = None):
+        super().__init__(prior, flows)
+        self.separator_prior = separator_prior
+        self.separator_dim = separator_prior.dim if separator_prior is not None else 0
+        self.samples_mean = samples_mean
+        self.samples_std = samples_std
+        self.circular_dim_list = circular_dim_list
+        self._norm_cache = None
+
+    @property
+    def dim(self):
+        return len(self.circular_dim_list)
+
+    # ---- device copies of the normalisation constants --------------------------------------
+    def _norm_dev(self, device):
+        if self._norm_cache is None or self._norm_cache[0] != str(device):
+            mean = torch.as_tensor(self.samples_mean, dtype=torch.float32).to(device).contiguous()
+            std = torch.as_tensor(self.samples_std, dtype=torch.float32).to(device).contiguous()
+            circ = torch.as_tensor(np.asarray(self.circular_dim_list, dtype=np.uint8)).to(device).contiguous()
+            self._norm_cache = (str(device), mean, std, circ)
+        return self._norm_cache[1:]
+
+    def _flow_cfg(self):
+        f0 = self.flows[0]
+        if not self._homogeneous():
+            raise NotImplementedError("the fused sampling kernel needs identical NSF_AR layers")
+        return f0, len(self.flows), next(f0.parameters()).device
+
+    # ---- reference API: host-visible (un)normalisation (NFiSAM.py:96-118) ---------------------
+    def normalize_samples(self, samples, init_dim):
+        circ = np.asarray(self.circular_dim_list, dtype=bool)[init_dim:init_dim + samples.shape[-1]]
+        ci = np.where(circ)[0]
+        ei = np.setdiff1d(np.arange(samples.shape[-1]), ci)
+        mean = torch.as_tensor(self.samples_mean).to(samples.device)
+        std = torch.as_tensor(self.samples_std).to(samples.device)
+        samples[:, ci] = theta_to_pipi(samples[:, ci] - mean[ci + init_dim]) / std[ci + init_dim]
+        samples[:, ei] = (samples[:, ei] - mean[ei + init_dim]) / std[ei + init_dim]
+        return samples
+
+    def unnormalize_samples(self, normalized, init_dim):
+        circ = np.asarray(self.circular_dim_list, dtype=bool)[init_dim:init_dim + normalized.shape[-1]]
+        ci = np.where(circ)[0]
+        ei = np.setdiff1d(np.arange(normalized.shape[-1]), ci)
+        mean = torch.as_tensor(self.samples_mean).to(normalized.device)
+        std = torch.as_tensor(self.samples_std).to(normalized.device)
+        normalized[:, ei] = normalized[:, ei] * std[ei + init_dim] + mean[ei + init_dim]
+        normalized[:, ci] = theta_to_pipi(normalized[:, ci] * std[ci + init_dim] + mean[ci + init_dim])
+        return normalized
+
+    # ---- sampling -------------------------------------------------------------------------------
+    def conditional_sample_given_observation(self, conditional_dim, obs_samples=None,
+                                             sample_number=None) -> "np.ndarray":
+        """Samples of C in P(C | O = obs_samples) (reference: NFiSAM.py:120-138)."""
+        if sample_number is None and obs_samples is not None:
+            n_samples, x_s = obs_samples.shape[0], obs_samples
+        elif sample_number is not None:
+            n_samples, x_s = sample_number, None
+        else:
+            raise ValueError("must input one of obs_samples or sample_number")
+        f0, L, device = self._flow_cfg()
+        # the reference draws all D latent columns and slices (NFiSAM.py:136); only the needed ones are drawn here
+        z = torch.randn(n_samples, conditional_dim, device=device, dtype=torch.float32)
+        return self.inverse_given_separator(z, x_s).cpu().numpy()
+
+    def inverse_given_separator(self, z, x_s=None):
+        """z: latent samples [n, c]; x_s: UN-normalised given columns [n, Ds] (numpy or tensor).
+        Returns un-normalised samples of columns Ds .. Ds+c-1 (reference: NFiSAM.py:140-155)."""
+        f0, L, device = self._flow_cfg()
+        z = torch.as_tensor(z, dtype=torch.float32).to(device).contiguous()
+        xs = None
+        if x_s is not None:
+            xs = torch.as_tensor(np.float32(x_s) if isinstance(x_s, np.ndarray) else x_s,
+                                 dtype=torch.float32).to(device).contiguous()
+        mean, std, circ = self._norm_dev(device)
+        return _nh.inverse(z, xs, self.kernel_params(), f0.K, f0.hidden_dim, f0.B, L, mean=mean, std=std,
+                           circular=circ, model_D=f0.dim)
+
+    def separator_forward(self, x):
+        """Push UN-normalised samples of the first `separator_dim` columns to the latent space with
+        the marginal flow (valid because the flow is autoregressive; reference: NFiSAM.py:157-173).
+        Returns (z, separator_prior_logprob, separator_log_det)."""
+        m, d = x.shape
+        assert d == self.separator_dim
+        f0, L, device = self._flow_cfg()
+        x = torch.as_tensor(x, dtype=torch.float32).to(device).clone()
+        xn = self.normalize_samples(x, init_dim=0).contiguous()
+        z, ld, lp = _nh.forward(xn, self.kernel_params(), f0.K, f0.hidden_dim, f0.B, L, want_logprob=True,
+                                model_D=f0.dim)
+        return z, lp - ld, ld
+
+    def separator_grad_x_log_pdf(self, x):
+        """d/dx [prior_logprob + log_det] of `separator_forward` w.r.t. the UN-normalised input."""
+        f0, L, device = self._flow_cfg()
+        x = torch.as_tensor(x, dtype=torch.float32).to(device).clone()
+        xn = self.normalize_samples(x, init_dim=0).contiguous()
+        _, gx, _ = _nh.backward(xn, self.kernel_params(), f0.K, f0.hidden_dim, f0.B, L, nll_mode=True, want_gx=True,
+                                model_D=f0.dim)
+        _, std, _ = self._norm_dev(device)
+        return -gx / std[:x.shape[1]]
+
+    @property
+    def is_cpu(self):
+        return self.prior.is_cpu()
+
+    def to_cpu(self):
+        raise RuntimeError("this model runs on the GPU only; use state_dict() to export parameters")
+
+    def to(self, device: str):
+        dev_sep = None if self.separator_prior is None else self.separator_prior.to(device)
+        return NormalizingFlowModelWithSeparator(flows=self.flows.to(device), prior=self.prior.to(device),
+                                                 separator_prior=dev_sep, circular_dim_list=self.circular_dim_list,
+                                                 samples_mean=self.samples_mean, samples_std=self.samples_std)
+
+
+class FlowsPriorFactor(CliqueSeparatorFactor):
+    """A trained child clique seen from its parent: prior over the separator variables given the
+    clique's true observations (reference: NFiSAM.py:202-315).  `sample` is the child->parent
+    message of NF-iSAM."""
+
+    def __init__(self, vars: List, flow_model: NormalizingFlowModelWithSeparator, true_obs: np.ndarray,
+                 circular_dim_list: List) -> None:
+        self._vars = vars
+        self._flow_model = flow_model
+        self._is_gaussian = False
+        self._true_obs = true_obs
+        self._obs_dim = len(true_obs)
+        self._circular_dim_list = circular_dim_list[:]
+        assert self.dim == len(circular_dim_list)
+
+    def append_obs_sample(self, x):
+        """Prepend the true observations to x (observation columns come first in the flow)."""
+        if self._obs_dim == 0:
+            return x
+        return np.concatenate((np.tile(self._true_obs, (x.shape[0], 1)), x), axis=1)
+
+    def log_pdf(self, x: np.ndarray, **kwargs) -> np.ndarray:
+        """log p(obs, x) up to the (fixed) observation constant (reference: NFiSAM.py:233-251)."""
+        aug = self.append_obs_sample(x)
+        _, lp, ld = self._flow_model.separator_forward(np.float32(aug))
+        return (lp + ld).cpu().numpy()
+
+    def grad_x_log_pdf(self, x: np.ndarray, **kwargs) -> np.ndarray:
+        aug = self.append_obs_sample(x)
+        g = self._flow_model.separator_grad_x_log_pdf(np.float32(aug)).cpu().numpy()
+        return g[:, self._obs_dim:self._obs_dim + x.shape[1]]
+
+    def sample(self, num_samples: int, **kwargs) -> np.ndarray:
+        if self._obs_dim == 0:
+            return self._flow_model.conditional_sample_given_observation(conditional_dim=self.dim,
+                                                                         sample_number=num_samples)
+        obs_samples = np.tile(self._true_obs, (num_samples, 1))
+        return self._flow_model.conditional_sample_given_observation(conditional_dim=self.dim,
+                                                                     obs_samples=obs_samples)
+
+    def unif_to_sample(self, u) -> np.ndarray:
+        """Nested-sampling prior transform: uniform [1,D] -> sample [D] (reference: NFiSAM.py:290-303)."""
+        import scipy.stats
+        normal_var = np.array([scipy.stats.norm.ppf(u)]).astype(np.float32).reshape(1, -1)
+        obs = None if self._obs_dim == 0 else np.tile(self._true_obs, (1, 1))
+        x = self._flow_model.inverse_given_separator(torch.tensor(normal_var), x_s=obs)
+        return x[0, :].cpu().numpy()
+
+    @property
+    def is_gaussian(self) -> bool:
+        return self._is_gaussian
+
+    @property
+    def vars(self) -> List:
+        return self._vars
+
+    @property
+    def circular_dim_list(self) -> List[bool]:
+        return self._circular_dim_list
+
+
+class NFiSAM(FactorGraphSolver):
+    def __init__(self, args: NFiSAMArgs = None):
+        super().__init__(args=args if args is not None else NFiSAMArgs())
+
+    # ---- the hot loop ---------------------------------------------------------------------------
+    def fit_clique_density_model(self, clique, samples: np.ndarray, var_ordering: List, timer: List, *args,
+                                 **kwargs) -> NormalizingFlowModelWithSeparator:
+        """Train the clique's flow on `samples` [n, D] (columns = simulated observations, separator
+        variables, frontal variables).  reference: NFiSAM.py:323-513."""
+        a = self._args
+        if a.flow_type != "NSF_AR":
+            raise NotImplementedError("Unknown flow type for the pipeline")
+        device = _device()
+        frontal_dim = clique.frontal_dim
+        aug_separator_dim = samples.shape[-1] - frontal_dim
+        aug_clique_dim = samples.shape[-1]
+        circular_dim_list = []
+        for var in var_ordering:
+            circular_dim_list += var.circular_dim_list
+        if len(circular_dim_list) != aug_clique_dim:
+            # observation columns precede the variables and are Euclidean
+            circular_dim_list = [False] * (aug_clique_dim - len(circular_dim_list)) + circular_dim_list
+
+        # train/test split on a shuffled COPY (the reference shuffles the caller's array in place)
+        samples = np.array(samples, dtype=np.float64, copy=True)
+        train_size = min(int(samples.shape[0] * a.training_set_frac), samples.shape[0])
+        np.random.shuffle(samples)
+        train_samples, test_samples = samples[:train_size], samples[train_size:]
+        training_data, means, stds = self.normalize_training_samples(train_samples, circular_dim_list, a.flow_type)
+        testing_data = None
+        if len(test_samples) > 0:
+            testing_data, _, _ = self.normalize_training_samples(test_samples, circular_dim_list, a.flow_type)
+
+        flows = [NSF_AR(dim=aug_clique_dim, K=a.num_knots, hidden_dim=a.hidden_dim).to(device)
+                 for _ in range(a.flow_number)]
+        normal_clique = CustomMultivariateNormal(dim=aug_clique_dim, device=device)
+        normal_separator = CustomMultivariateNormal(dim=aug_separator_dim, device=device) \
+            if aug_separator_dim > 0 else None
+        model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, circular_dim_list, means,
+                                                  stds)
+        f0 = flows[0]
+        x_dev = training_data.to(device).contiguous()
+        logger = logging.getLogger("flows on clique")
+
+        opt_start = time.time()
+        tb = _nh.TrainBatch([x_dev], [model.kernel_params().clone()], f0.K, f0.hidden_dim, f0.B, a.flow_number,
+                            lr=a.learning_rate, max_iters=a.flow_iterations, average_window=a.average_window,
+                            loss_delta_tol=a.loss_delta_tol, early_stop=(testing_data is None))
+        if testing_data is None:
+            iters = tb.run(use_graph=True)[0]
+            if iters < a.flow_iterations:
+                logger.info(f"Early stopping at iter {iters}")
+        else:
+            iters = self._fit_with_validation(tb, testing_data.to(device).contiguous(), f0, logger)
+        model.load_kernel_params(tb.kparams[0])
+        torch.cuda.synchronize()
+        opt_end = time.time()
+        if timer is not None:
+            timer.append(opt_end - opt_start)
+
+        clique_name = ''.join([str(var.name) for var in clique.vars])
+        self._temp_training_loss[clique_name] = [float(v) for v in tb.iter_loss[0].cpu().numpy().astype(np.float64)]
+        self.last_fit_iterations = iters
+        tb.close()
+        return model
+
+    def _fit_with_validation(self, tb, testing_data, f0, logger):
+        """training_set_frac < 1: hold-out early stopping (reference: NFiSAM.py:452-468)."""
+        a = self._args
+        last_validation_loss = float('inf')
+        slower_stop_iter = None
+        iters = 0
+        for i in range(a.flow_iterations):
+            if slower_stop_iter is not None:
+                if (i + 1) >= slower_stop_iter:
+                    logger.info(f"Slower stop at iter {i + 1}")
+                    break
+            elif (i + 1) % a.validation_interval == 0:
+                _, _, lp = _nh.forward(testing_data, tb.kparams[0], f0.K, f0.hidden_dim, f0.B, a.flow_number,
+                                       want_z=False, want_logdet=False, want_logprob=True)
+                new_loss = float(-lp.mean().item())
+                logger.info(f"Iter: {i + 1}\t, validation loss: {new_loss}")
+                if new_loss > last_validation_loss:
+                    logger.info(f"Early stopping at iter {i + 1}")
+                    slower_stop_iter = int(a.slower_stop_rate * (i + 1))
+                else:
+                    last_validation_loss = new_loss
+            tb.step()
+            iters = i + 1
+        return iters
+
+    def normalize_training_samples(self, samples, circular_dim_list, flow_type: str):
+        """Per-column standardisation with circular statistics for angle columns
+        (reference: NFiSAM.py:515-548).  Host side: n x D doubles, once per clique."""
+        if flow_type != "NSF_AR":
+            raise NotImplementedError("Unknown flow type for the pipeline")
+        samples = np.array(samples, dtype=np.float64, copy=True)
+        aug_clique_dim = samples.shape[-1]
+        means = np.zeros(aug_clique_dim)
+        stds = np.zeros(aug_clique_dim)
+        ci = np.where(circular_dim_list)[0]
+        ei = np.setdiff1d(np.arange(aug_clique_dim), ci)
+        if len(ci) > 0:
+            means[ci] = circmean(samples[:, ci], high=np.pi, low=-np.pi, axis=0)
+            shifted = theta_to_pipi(samples[:, ci] - means[ci])
+            stds[ci] = np.std(shifted, axis=0)
+            samples[:, ci] = shifted
+        means[ei] = np.mean(samples[:, ei], axis=0)
+        stds[ei] = np.std(samples[:, ei], axis=0)
+        samples[:, ei] = samples[:, ei] - means[ei]
+        stds = np.clip(stds, a_min=1e-5, a_max=None)
+        samples = samples / stds
+        return torch.Tensor(samples), torch.Tensor(means), torch.Tensor(stds)
+
+    # ---- model reuse / message construction --------------------------------------------------
+    def root_clique_density_model_to_leaf(self, old_clique, new_clique, device=None):
+        """Same variables, different frontal/separator split: re-wrap the trained flows instead of
+        re-training (reference: NFiSAM.py:550-577)."""
+        old_flow = self._clique_density_model[old_clique]
+        obs_dim = old_flow.dim - old_clique.dim
+        separator_dim = new_clique.separator_dim + obs_dim
+        if not isinstance(old_flow.flows[0], NSF_AR):
+            raise NotImplementedError("Unknown flow type for the pipeline")
+        dev = old_flow.prior._device
+        normal_separator = CustomMultivariateNormal(dim=separator_dim, device=dev) if separator_dim > 0 else None
+        return NormalizingFlowModelWithSeparator(flows=old_flow.flows, prior=old_flow.prior,
+                                                 separator_prior=normal_separator,
+                                                 circular_dim_list=old_flow.circular_dim_list,
+                                                 samples_mean=old_flow.samples_mean, samples_std=old_flow.samples_std)
+
+    def clique_density_to_separator_factor(self, separator_var_list, density_model, true_obs):
+        """true_obs: 1-D array concatenating all observations of the clique (reference: NFiSAM.py:579-586)."""
+        obs_dim = true_obs.shape[-1]
+        obs_separator_dim = sum([var.dim for var in separator_var_list]) + obs_dim
+        return FlowsPriorFactor(vars=separator_var_list, flow_model=density_model, true_obs=true_obs,
+                                circular_dim_list=density_model.circular_dim_list[obs_dim: obs_separator_dim])

@@ -73,9 +73,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- conditioner ----------------------------------------------------------------------------
-// xs: LDS, dimension-major: xs[k * TILE + lane] = x_k of this lane's particle.
+// xs: LDS, dimension-major with row stride `xstride`: xs[k * xstride + lane] = x_k of this lane's particle.
 template <int K, int H>
-__device__ __forceinline__ void cond_hidden(cfloat* blk, int i, const float* xs, int lane,
+__device__ __forceinline__ void cond_hidden(cfloat* blk, int i, const float* xs, int xstride, int lane,
                                             float (&h1)[H], float (&h2)[H]) {
     using LY = Layout<K, H>;
     float a[H];
@@ -84,7 +84,7 @@ __device__ __forceinline__ void cond_hidden(cfloat* blk, int i, const float* xs,
     for (int j = 0; j < H; ++j) a[j] = b0[j];
     cfloat* W0 = blk;
     for (int k = 0; k < i; ++k) {
-        const float xk = xs[k * TILE + lane];
+        const float xk = xs[k * xstride + lane];
 #pragma unroll
         for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(W0[k * H + j], xk, a[j]);
     }

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -56,6 +57,13 @@ __device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
     return r;
 }
 
+__device__ __forceinline__ void atomicAdd4(float* dst, const __attribute__((ext_vector_type(4))) float& v) {
+    atomicAdd(dst + 0, v.x);
+    atomicAdd(dst + 1, v.y);
+    atomicAdd(dst + 2, v.z);
+    atomicAdd(dst + 3, v.w);
+}
+
 // =============================================================================================
 // training / VJP kernel
 // =============================================================================================
@@ -74,7 +82,7 @@ struct TrainArgs {
 };
 
 template <int K, int H>
-__device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, int lane,
+__device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, int xstride, int lane,
                                            float (&h1)[H], float (&h2)[H],
                                            float (&th)[Layout<K, H>::PoP]) {
     using LY = Layout<K, H>;
@@ -83,15 +91,52 @@ __device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, 
         for (int o = 0; o < LY::PoP; ++o) th[o] = lp[o];
     } else {
         cfloat* blk = lp + LY::off(i);
-        cond_hidden<K, H>(blk, i, xin, lane, h1, h2);
+        cond_hidden<K, H>(blk, i, xin, xstride, lane, h1, h2);
         cond_theta<K, H>(blk, i, h2, th);
     }
 }
 
+// ---- weight-gradient GEMMs on the matrix cores -------------------------------------------------
+// For one (layer, dim) unit the parameter gradients are sums over the wave's 64 particles of outer
+// products:  dW2t[c][o] = sum_p h2ext[p][c] * gth[p][o],  dW1t[c][j] = sum_p h1ext[p][c] * ga2[p][j],
+// dW0t[c][j] = sum_p xext[p][c] * ga1[p][j]   (ext = activation vector with a trailing 1 for the bias).
+// With the particle index as the contraction dimension these are GEMMs, and
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) does the cross-lane reduction for free:
+// 4 particles per instruction.  The VALU phase holds "particle on the lane, feature in the
+// register"; the MFMA operands need "feature on lane&15, particle on lane>>4", so the vectors take
+// one trip through a wave-private LDS tile, feature-major with a row stride of XS = 66 floats
+// (66 mod 32 = 2 makes both the 64-lane row writes and the 16x4 operand reads conflict-free).
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int XS = 66;            // LDS row stride (floats) of every [feature][particle] tile
+// staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operand up to row PoP+15
 template <int K, int H>
+struct StgRows {
+    static constexpr int PoP = Layout<K, H>::PoP;
+    static constexpr int a = 16 * ((PoP + 15) / 16), b = PoP + 16, c = 3 * H + 16;
+    static constexpr int value = (a > b ? (a > c ? a : c) : (b > c ? b : c));
+};
+
+// Lanes of ONE wave exchange data through LDS: the hardware executes a wave's LDS operations in
+// order, but the compiler must be told that other lanes write between this lane's store and its
+// later load (otherwise it forwards the lane's own store).  Wavefront-scope release/acquire
+// fences + wave barrier: no instructions, only ordering.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int K, int H, bool MF>
 __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
     constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;                       // 16-row output tiles of gth
+    constexpr int STG_ROWS = StgRows<K, H>::value;
+    static_assert(!MF || H == 8, "MFMA gradient path packs ga2|ga1 into one 16-row operand tile: H = 8");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const bool batched = a.cliques != nullptr;
@@ -115,18 +160,21 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int W = blockDim.x >> 6;
     const int gp = p0 + lane;
     const bool valid = gp < n;
-    const int DT = D * TILE;
+    const int DT = D * XS;
 
-    float* xs = smem;                 // [L][D][TILE] layer inputs
-    float* g0 = xs + L * DT;          // [D][TILE]
-    float* g1 = g0 + DT;              // [D][TILE]
+    float* xs = smem;                 // [L][D][XS] layer inputs, dimension-major
+    float* g0 = xs + L * DT;          // [D][XS]
+    float* g1 = g0 + DT;              // [D][XS]
+    float* ones = g1 + DT;            // [XS] constant 1 (bias column of the gradient GEMMs)
+    float* stg = ones + XS + w * (StgRows<K, H>::value * XS);   // wave-private staging tile (MF only)
 
     // ---- coalesced load of the particle tile, transposed into LDS -------------------------
-    for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+    for (int e = threadIdx.x; e < D * TILE; e += blockDim.x) {
         const int p = e / D, k = e - p * D;
         const int q = p0 + p;
-        xs[k * TILE + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
+        xs[k * XS + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
     }
+    if (threadIdx.x < XS) ones[threadIdx.x] = 1.0f;
     __syncthreads();
 
     cfloat* kp = (cfloat*)kparams;
@@ -139,11 +187,11 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         float* xout = xs + (l + 1) * DT;
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            load_theta<K, H>(lp, i, xin, XS, lane, h1, h2, th);
             Spline<K> S;
             float z, lad;
-            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, z, lad);
-            xout[i * TILE + lane] = z;
+            spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
+            xout[i * XS + lane] = z;
         }
         __syncthreads();
     }
@@ -152,6 +200,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     float lossv = 0.0f;
     float* gcur = g0;
     float* gprev = g1;
+    const int r16 = lane & 15, kq = lane >> 4;
     for (int l = L - 1; l >= 0; --l) {
         const bool last = (l == L - 1);
         const bool need_gx = (l > 0) || (a.gx != nullptr);
@@ -164,24 +213,24 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         }
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP], gth[PoP];
-            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            load_theta<K, H>(lp, i, xin, XS, lane, h1, h2, th);
             Spline<K> S;
             float z, lad;
-            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, z, lad);
+            spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
             float gz, gl;
             if (a.nll_mode) {
                 gl = -1.0f;
-                gz = last ? z : gcur[i * TILE + lane];
+                gz = last ? z : gcur[i * XS + lane];
                 if (valid) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
             } else {
                 gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
-                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * TILE + lane];
+                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS + lane];
             }
             if (!valid) { gz = 0.0f; gl = 0.0f; }
             const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
-            if (need_gx) atomicAdd(&gprev[i * TILE + lane], gxs);
+            if (need_gx) atomicAdd(&gprev[i * XS + lane], gxs);
 
-            if (i == 0) {
+            if (i == 0) {   // init_param: plain sum over particles of gth
                 constexpr int N0 = (PoP <= 32) ? 32 : 64;
                 float v[N0];
 #pragma unroll
@@ -192,8 +241,8 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
             }
             cfloat* blk = lp + LY::off(i);
             float* Gb = Gl + LY::off(i);
-            // ---- layer 3: W2t[H][PoP] | b2[PoP] are contiguous -> flat index f = k*PoP + o
-            float gh2[H];
+            // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights)
+            float gh2[H], ga2[H], ga1[H];
             {
                 cfloat* W2 = blk + LY::oW2(i);
 #pragma unroll
@@ -203,76 +252,151 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(W2[k * PoP + o], gth[o], acc);
                     gh2[k] = acc;
                 }
-                constexpr int TOT = (H + 1) * PoP;
-                float* Gw = Gb + LY::oW2(i);
 #pragma unroll
-                for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                    float v[64];
-#pragma unroll
-                    for (int t = 0; t < 64; ++t) {
-                        const int f = c * 64 + t;
-                        const int k = f / PoP, o = f % PoP;
-                        v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
-                    }
-                    const float r = butterfly<64>(v, lane);
-                    if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
-                }
-            }
-            // ---- layer 2: W1t[H][H] | b1[H] contiguous -> f = k*H + j
-            float ga2[H], ga1[H];
-#pragma unroll
-            for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
-            {
+                for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
                 cfloat* W1 = blk + LY::oW1(i);
-                float gh1[H];
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
                     float acc = 0.0f;
 #pragma unroll
                     for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W1[k * H + j], ga2[j], acc);
-                    gh1[k] = acc;
-                }
-#pragma unroll
-                for (int k = 0; k < H; ++k) ga1[k] = gh1[k] * (1.0f - h1[k] * h1[k]);
-                constexpr int TOT = (H + 1) * H;
-                float* Gw = Gb + LY::oW1(i);
-#pragma unroll
-                for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                    float v[64];
-#pragma unroll
-                    for (int t = 0; t < 64; ++t) {
-                        const int f = c * 64 + t;
-                        const int k = f / H, j = f % H;
-                        v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
-                    }
-                    const float r = butterfly<64>(v, lane);
-                    if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
-                }
-            }
-            // ---- layer 1: W0t[i][H] | b0[H] contiguous -> f = k*H + j, k <= i (k == i: bias)
-            {
-                cfloat* W0 = blk;
-                float* Gw = Gb;
-                constexpr int RPC = 64 / H;                 // k-rows per 64-value chunk
-                const int tot = (i + 1) * H;
-                for (int kc = 0; kc <= i; kc += RPC) {
-                    float v[64];
-#pragma unroll
-                    for (int r_ = 0; r_ < RPC; ++r_) {
-                        const int k = kc + r_;
-                        const float xk = (k < i) ? xin[k * TILE + lane] : ((k == i) ? 1.0f : 0.0f);
-#pragma unroll
-                        for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
-                    }
-                    const float r = butterfly<64>(v, lane);
-                    if (kc * H + lane < tot) atomicAdd(&Gw[kc * H + lane], r);
+                    ga1[k] = acc * (1.0f - h1[k] * h1[k]);
                 }
                 if (need_gx) {
+                    cfloat* W0 = blk;
                     for (int k = 0; k < i; ++k) {
                         float acc = 0.0f;
 #pragma unroll
                         for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W0[k * H + j], ga1[j], acc);
-                        atomicAdd(&gprev[k * TILE + lane], acc);
+                        atomicAdd(&gprev[k * XS + lane], acc);
+                    }
+                }
+            }
+            if constexpr (MF) {
+                // ======== phase A: dW2t | db2 = [h2, 1]^T (x) gth   -> flat f = c*PoP + o =========
+                {
+#pragma unroll
+                    for (int o = 0; o < PoP; ++o) stg[o * XS + lane] = gth[o];
+#pragma unroll
+                    for (int k = 0; k < H; ++k) stg[(PoP + k) * XS + lane] = h2[k];
+                    stg[(PoP + H) * XS + lane] = 1.0f;
+                    wave_lds_sync();
+                    const float* pa = stg + r16 * XS + kq;             // A tiles: gth rows 16t + r16 (>= Po: unused outputs)
+                    const float* pb = stg + (PoP + r16) * XS + kq;     // B: [h2 | 1] rows (>= 9: unused outputs)
+                    f32x4 cacc[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < TILE; s4 += 4) {
+                        const float b = pb[s4];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) cacc[t] = mfma4(pa[t * 16 * XS + s4], b, cacc[t]);
+                    }
+                    // C layout: col = lane&15 (= c), rows 4*(lane>>4)+r (= o within the tile)
+                    wave_lds_sync();
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
+                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                            }
+                    }
+                    wave_lds_sync();
+                    constexpr int TOT = (H + 1) * PoP;
+                    float* Gw = Gb + LY::oW2(i);
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        const int f = c * 64 + lane;
+                        if (f < TOT) atomicAdd(&Gw[f], stg[f]);
+                    }
+                    wave_lds_sync();
+                }
+                // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========
+                {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) {
+                        stg[j * XS + lane] = ga2[j];
+                        stg[(H + j) * XS + lane] = ga1[j];
+                        stg[(2 * H + j) * XS + lane] = h1[j];
+                    }
+                    stg[(3 * H) * XS + lane] = 1.0f;
+                    wave_lds_sync();
+                    const float* pa = stg + r16 * XS + kq;                   // A: rows 0..7 ga2, 8..15 ga1
+                    const float* pb1 = stg + (2 * H + r16) * XS + kq;        // B1: [h1 | 1]
+                    f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
+                    float areg[TILE / 4];
+#pragma unroll
+                    for (int s4 = 0; s4 < TILE; s4 += 4) {
+                        areg[s4 / 4] = pa[s4];
+                        c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
+                    }
+                    // x tiles (16 input columns each); column i is the bias (ones row)
+                    float* Gw0 = Gb;
+                    const int tot0 = (i + 1) * H;
+                    for (int ct = 0; ct * 16 <= i; ++ct) {
+                        const int cab = ct * 16 + r16;
+                        const float* pb0 = ((cab < i) ? (xin + cab * XS) : ones) + kq;
+                        f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s4 = 0; s4 < TILE; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
+                        // rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = cab*H + j
+                        if (kq >= 2 && cab <= i) atomicAdd4(&Gw0[cab * H + 4 * (kq - 2)], c0);
+                    }
+                    (void)tot0;
+                    // rows 0..7 (kq < 2) are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
+                    if (kq < 2 && r16 <= H) atomicAdd4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1);
+                    wave_lds_sync();
+                }
+            } else {
+                // ======== butterfly variant (round-1 v1): reduce-scatter over lanes with ds_bpermute ========
+                {
+                    constexpr int TOT = (H + 1) * PoP;
+                    float* Gw = Gb + LY::oW2(i);
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        float v[64];
+#pragma unroll
+                        for (int t = 0; t < 64; ++t) {
+                            const int f = c * 64 + t;
+                            const int k = f / PoP, o = f % PoP;
+                            v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
+                        }
+                        const float r = butterfly<64>(v, lane);
+                        if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                    }
+                }
+                {
+                    constexpr int TOT = (H + 1) * H;
+                    float* Gw = Gb + LY::oW1(i);
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        float v[64];
+#pragma unroll
+                        for (int t = 0; t < 64; ++t) {
+                            const int f = c * 64 + t;
+                            const int k = f / H, j = f % H;
+                            v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
+                        }
+                        const float r = butterfly<64>(v, lane);
+                        if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                    }
+                }
+                {
+                    float* Gw = Gb;
+                    constexpr int RPC = 64 / H;
+                    const int tot = (i + 1) * H;
+                    for (int kc = 0; kc <= i; kc += RPC) {
+                        float v[64];
+#pragma unroll
+                        for (int r_ = 0; r_ < RPC; ++r_) {
+                            const int k = kc + r_;
+                            const float xk = (k < i) ? xin[k * XS + lane] : ((k == i) ? 1.0f : 0.0f);
+#pragma unroll
+                            for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
+                        }
+                        const float r = butterfly<64>(v, lane);
+                        if (kc * H + lane < tot) atomicAdd(&Gw[kc * H + lane], r);
                     }
                 }
             }
@@ -282,10 +406,10 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     }
 
     if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
-        for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+        for (int e = threadIdx.x; e < D * TILE; e += blockDim.x) {
             const int p = e / D, k = e - p * D;
             const int q = p0 + p;
-            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * TILE + p];
+            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * XS + p];
         }
     }
     if (a.nll_mode) {
@@ -403,7 +527,7 @@ __global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restric
         float ld = 0.0f;
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xin, lane, h1, h2, th);
+            load_theta<K, H>(lp, i, xin, TILE, lane, h1, h2, th);
             Spline<K> S;
             float zz, lad;
             spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, zz, lad);
@@ -482,7 +606,7 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
         cfloat* lp = kp + (size_t)l * Pk;
         for (int i = Ds; i < D; ++i) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xs, lane, h1, h2, th);
+            load_theta<K, H>(lp, i, xs, TILE, lane, h1, h2, th);
             Spline<K> S;
             float xi, lad;
             spline_eval<K, PoP, true>(zs[(i - Ds) * TILE + lane], th, B, S, xi, lad);
@@ -690,14 +814,32 @@ extern "C" int nfisam_rqs(const float* inputs, const float* widths, const float*
     return NFISAM_OK;
 }
 
+static bool use_mfma_grad() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NFISAM_GRAD");      // "butterfly" selects the round-1 v1 reduction (A/B only)
+        v = (e != nullptr && strcmp(e, "butterfly") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
     const int W = pick_waves(max_D);
-    const size_t lds = ((size_t)a.L + 2) * max_D * TILE * sizeof(float);
+    const bool mf = use_mfma_grad();
     NSF_DISPATCH(K, H, {
-        int rc = set_lds(nsf_train_kernel<KK, HH>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((nsf_train_kernel<KK, HH>), dim3((max_n + TILE - 1) / TILE, n_cliques), dim3(64 * W), lds,
-                           s, a);
+        const size_t lds = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS *
+                           sizeof(float);
+        if (mf) {
+            int rc = set_lds(nsf_train_kernel<KK, HH, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train_kernel<KK, HH, true>), dim3((max_n + TILE - 1) / TILE, n_cliques),
+                               dim3(64 * W), lds, s, a);
+        } else {
+            int rc = set_lds(nsf_train_kernel<KK, HH, false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train_kernel<KK, HH, false>), dim3((max_n + TILE - 1) / TILE, n_cliques),
+                               dim3(64 * W), lds, s, a);
+        }
     });
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

@@ -72,49 +72,70 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- weight rows ------------------------------------------------------------------------------
+// A row of N (multiple of 4) wave-uniform weights.  Scalar-cache path: plain indexing (the
+// compiler merges into s_load_dwordx{4,8,16}); LDS path: explicit 16-byte broadcast reads
+// (ds_read_b128), every row of the kernel layout being 16-byte aligned by construction.
+typedef __attribute__((ext_vector_type(4))) float wf4;
+template <int N>
+__device__ __forceinline__ void load_row(cfloat* row, float (&w)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) w[j] = row[j];
+}
+template <int N>
+__device__ __forceinline__ void load_row(const float* row, float (&w)[N]) {
+    static_assert(N % 4 == 0, "rows are padded to multiples of 4");
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+        const wf4 v = *(const wf4*)(row + j);
+        w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w;
+    }
+}
+
 // ---- conditioner ----------------------------------------------------------------------------
 // xs: LDS, dimension-major with row stride `xstride`: xs[k * xstride + lane] = x_k of this lane's particle.
-template <int K, int H>
-__device__ __forceinline__ void cond_hidden(cfloat* blk, int i, const float* xs, int xstride, int lane,
+// WP = weight pointer type: `cfloat*` (scalar-cache path, SGPR operands) or `const float*` into an
+// LDS copy of the parameters (broadcast ds_read_b128; used when one wave per SIMD must not expose
+// a cold scalar-cache miss per weight row).
+template <int K, int H, typename WP>
+__device__ __forceinline__ void cond_hidden(WP blk, int i, const float* xs, int xstride, int lane,
                                             float (&h1)[H], float (&h2)[H]) {
     using LY = Layout<K, H>;
-    float a[H];
-    cfloat* b0 = blk + LY::ob0(i);
-#pragma unroll
-    for (int j = 0; j < H; ++j) a[j] = b0[j];
-    cfloat* W0 = blk;
+    float a[H], wr[H];
+    load_row<H>(blk + LY::ob0(i), a);
+    WP W0 = blk;
     for (int k = 0; k < i; ++k) {
         const float xk = xs[k * xstride + lane];
+        load_row<H>(W0 + k * H, wr);
 #pragma unroll
-        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(W0[k * H + j], xk, a[j]);
+        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], xk, a[j]);
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h1[j] = ftanh(a[j]);
-    cfloat* b1 = blk + LY::ob1(i);
-    cfloat* W1 = blk + LY::oW1(i);
-#pragma unroll
-    for (int j = 0; j < H; ++j) a[j] = b1[j];
+    WP W1 = blk + LY::oW1(i);
+    load_row<H>(blk + LY::ob1(i), a);
 #pragma unroll
     for (int k = 0; k < H; ++k) {
+        load_row<H>(W1 + k * H, wr);
 #pragma unroll
-        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(W1[k * H + j], h1[k], a[j]);
+        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], h1[k], a[j]);
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h2[j] = ftanh(a[j]);
 }
 
-template <int K, int H>
-__device__ __forceinline__ void cond_theta(cfloat* blk, int i, const float (&h2)[H],
+template <int K, int H, typename WP>
+__device__ __forceinline__ void cond_theta(WP blk, int i, const float (&h2)[H],
                                            float (&th)[Layout<K, H>::PoP]) {
     using LY = Layout<K, H>;
-    cfloat* b2 = blk + LY::ob2(i);
-    cfloat* W2 = blk + LY::oW2(i);
-#pragma unroll
-    for (int o = 0; o < LY::PoP; ++o) th[o] = b2[o];
+    WP W2 = blk + LY::oW2(i);
+    load_row<LY::PoP>(blk + LY::ob2(i), th);
 #pragma unroll
     for (int k = 0; k < H; ++k) {
+        float wr[LY::PoP];
+        load_row<LY::PoP>(W2 + k * LY::PoP, wr);
 #pragma unroll
-        for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(W2[k * LY::PoP + o], h2[k], th[o]);
+        for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(wr[o], h2[k], th[o]);
     }
 }
 

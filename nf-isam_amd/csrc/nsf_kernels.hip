@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/nfisam_hip.h"
@@ -81,18 +82,17 @@ struct TrainArgs {
     int layer_stride;               // floats between layers in kparams/kgrad (0: kparam_count(D))
 };
 
-template <int K, int H>
-__device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, int xstride, int lane,
+template <int K, int H, typename WP>
+__device__ __forceinline__ void load_theta(WP lp, int i, const float* xin, int xstride, int lane,
                                            float (&h1)[H], float (&h2)[H],
                                            float (&th)[Layout<K, H>::PoP]) {
     using LY = Layout<K, H>;
     if (i == 0) {
-#pragma unroll
-        for (int o = 0; o < LY::PoP; ++o) th[o] = lp[o];
+        load_row<LY::PoP>(lp, th);
     } else {
-        cfloat* blk = lp + LY::off(i);
-        cond_hidden<K, H>(blk, i, xin, xstride, lane, h1, h2);
-        cond_theta<K, H>(blk, i, h2, th);
+        WP blk = lp + LY::off(i);
+        cond_hidden<K, H, WP>(blk, i, xin, xstride, lane, h1, h2);
+        cond_theta<K, H, WP>(blk, i, h2, th);
     }
 }
 
@@ -107,6 +107,25 @@ __device__ __forceinline__ void load_theta(cfloat* lp, int i, const float* xin, 
 // one trip through a wave-private LDS tile, feature-major with a row stride of XS = 66 floats
 // (66 mod 32 = 2 makes both the 64-lane row writes and the 16x4 operand reads conflict-free).
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- diagnostic build only (-DNSF_STAMPS): per-wave s_memtime stamps at phase boundaries ---------
+#ifdef NSF_STAMPS
+__device__ unsigned long long g_stamps[64 * 32];
+#define STAMP(id)                                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) g_stamps[w * 32 + (id)] = t_;             \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 32);
+}
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 constexpr int XS = 66;            // LDS row stride (floats) of every [feature][particle] tile
 // staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operand up to row PoP+15
 template <int K, int H>
@@ -130,9 +149,10 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int K, int H, bool MF>
+template <int K, int H, bool MF, bool WL>
 __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
+    using WP = typename std::conditional<WL, const float*, cfloat*>::type;
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;                       // 16-row output tiles of gth
     constexpr int STG_ROWS = StgRows<K, H>::value;
@@ -161,8 +181,11 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int gp = p0 + lane;
     const bool valid = gp < n;
     const int DT = D * XS;
+    STAMP(0);
 
-    float* xs = smem;                 // [L][D][XS] layer inputs, dimension-major
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    float* wlds = smem;               // [L*Pk] parameter copy (WL only), 16-byte aligned rows
+    float* xs = smem + (WL ? L * Pk : 0);   // [L][D][XS] layer inputs, dimension-major
     float* g0 = xs + L * DT;          // [D][XS]
     float* g1 = g0 + DT;              // [D][XS]
     float* ones = g1 + DT;            // [XS] constant 1 (bias column of the gradient GEMMs)
@@ -175,19 +198,26 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         xs[k * XS + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
     }
     if (threadIdx.x < XS) ones[threadIdx.x] = 1.0f;
+    if constexpr (WL) {   // stage ALL parameters once per block: wide coalesced loads, one exposed latency
+        const int tot4 = (L * Pk) >> 2;     // Pk is a multiple of 4 by construction of the layout
+        const f32x4* src = (const f32x4*)kparams;
+        f32x4* dst = (f32x4*)wlds;
+        for (int e = threadIdx.x; e < tot4; e += blockDim.x) dst[e] = src[e];
+    }
     __syncthreads();
 
-    cfloat* kp = (cfloat*)kparams;
-    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    WP kp;
+    if constexpr (WL) kp = wlds; else kp = (cfloat*)kparams;
+    STAMP(1);
 
     // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
     for (int l = 0; l + 1 < L; ++l) {
-        cfloat* lp = kp + (size_t)l * Pk;
+        WP lp = kp + (size_t)l * Pk;
         const float* xin = xs + l * DT;
         float* xout = xs + (l + 1) * DT;
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xin, XS, lane, h1, h2, th);
+            load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
             Spline<K> S;
             float z, lad;
             spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
@@ -204,7 +234,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     for (int l = L - 1; l >= 0; --l) {
         const bool last = (l == L - 1);
         const bool need_gx = (l > 0) || (a.gx != nullptr);
-        cfloat* lp = kp + (size_t)l * Pk;
+        WP lp = kp + (size_t)l * Pk;
         float* Gl = G + (size_t)l * Pk;
         const float* xin = xs + l * DT;
         if (need_gx) {
@@ -213,10 +243,13 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         }
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP], gth[PoP];
-            load_theta<K, H>(lp, i, xin, XS, lane, h1, h2, th);
+            STAMP(2);
+            load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
+            STAMP(3);
             Spline<K> S;
             float z, lad;
             spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
+            STAMP(4);
             float gz, gl;
             if (a.nll_mode) {
                 gl = -1.0f;
@@ -229,6 +262,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
             if (!valid) { gz = 0.0f; gl = 0.0f; }
             const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
             if (need_gx) atomicAdd(&gprev[i * XS + lane], gxs);
+            STAMP(5);
 
             if (i == 0) {   // init_param: plain sum over particles of gth
                 constexpr int N0 = (PoP <= 32) ? 32 : 64;
@@ -239,39 +273,46 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                 if (lane < PoP) atomicAdd(&Gl[lane], r);
                 continue;
             }
-            cfloat* blk = lp + LY::off(i);
+            WP blk = lp + LY::off(i);
             float* Gb = Gl + LY::off(i);
             // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights)
             float gh2[H], ga2[H], ga1[H];
             {
-                cfloat* W2 = blk + LY::oW2(i);
+                WP W2 = blk + LY::oW2(i);
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
+                    float wr[PoP];
+                    load_row<PoP>(W2 + k * PoP, wr);
                     float acc = 0.0f;
 #pragma unroll
-                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(W2[k * PoP + o], gth[o], acc);
+                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
                     gh2[k] = acc;
                 }
 #pragma unroll
                 for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
-                cfloat* W1 = blk + LY::oW1(i);
+                WP W1 = blk + LY::oW1(i);
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
+                    float wr[H];
+                    load_row<H>(W1 + k * H, wr);
                     float acc = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W1[k * H + j], ga2[j], acc);
+                    for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
                     ga1[k] = acc * (1.0f - h1[k] * h1[k]);
                 }
                 if (need_gx) {
-                    cfloat* W0 = blk;
+                    WP W0 = blk;
                     for (int k = 0; k < i; ++k) {
+                        float wr[H];
+                        load_row<H>(W0 + k * H, wr);
                         float acc = 0.0f;
 #pragma unroll
-                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(W0[k * H + j], ga1[j], acc);
+                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga1[j], acc);
                         atomicAdd(&gprev[k * XS + lane], acc);
                     }
                 }
             }
+            STAMP(6);
             if constexpr (MF) {
                 // ======== phase A: dW2t | db2 = [h2, 1]^T (x) gth   -> flat f = c*PoP + o =========
                 {
@@ -312,6 +353,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     }
                     wave_lds_sync();
                 }
+                STAMP(7);
                 // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========
                 {
 #pragma unroll
@@ -348,6 +390,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     if (kq < 2 && r16 <= H) atomicAdd4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1);
                     wave_lds_sync();
                 }
+                STAMP(8);
             } else {
                 // ======== butterfly variant (round-1 v1): reduce-scatter over lanes with ds_bpermute ========
                 {
@@ -412,6 +455,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
             if (q < n) a.gx[(size_t)q * D + k] = gcur[k * XS + p];
         }
     }
+    STAMP(9);
     if (a.nll_mode) {
         const float tot = wave_sum(lossv);
         if (lane == 0) {
@@ -527,7 +571,7 @@ __global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restric
         float ld = 0.0f;
         for (int i = w; i < D; i += W) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xin, TILE, lane, h1, h2, th);
+            load_theta<K, H, cfloat*>(lp, i, xin, TILE, lane, h1, h2, th);
             Spline<K> S;
             float zz, lad;
             spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, zz, lad);
@@ -606,7 +650,7 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
         cfloat* lp = kp + (size_t)l * Pk;
         for (int i = Ds; i < D; ++i) {
             float h1[H], h2[H], th[PoP];
-            load_theta<K, H>(lp, i, xs, TILE, lane, h1, h2, th);
+            load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
             Spline<K> S;
             float xi, lad;
             spline_eval<K, PoP, true>(zs[(i - Ds) * TILE + lane], th, B, S, xi, lad);
@@ -687,12 +731,12 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-#define NSF_DISPATCH(K_, H_, CALL)                                  \
+#define NSF_DISPATCH(K_, H_, ...)                                   \
     do {                                                            \
-        if ((H_) == 8 && (K_) == 5) { constexpr int KK = 5, HH = 8; CALL; }       \
-        else if ((H_) == 8 && (K_) == 9) { constexpr int KK = 9, HH = 8; CALL; }  \
-        else if ((H_) == 8 && (K_) == 12) { constexpr int KK = 12, HH = 8; CALL; } \
-        else if ((H_) == 8 && (K_) == 6) { constexpr int KK = 6, HH = 8; CALL; }  \
+        if ((H_) == 8 && (K_) == 5) { constexpr int KK = 5, HH = 8; __VA_ARGS__; }       \
+        else if ((H_) == 8 && (K_) == 9) { constexpr int KK = 9, HH = 8; __VA_ARGS__; }  \
+        else if ((H_) == 8 && (K_) == 12) { constexpr int KK = 12, HH = 8; __VA_ARGS__; } \
+        else if ((H_) == 8 && (K_) == 6) { constexpr int KK = 6, HH = 8; __VA_ARGS__; }  \
         else return NFISAM_ERR_ARG;                                 \
     } while (0)
 
@@ -823,23 +867,44 @@ static bool use_mfma_grad() {
     return v == 1;
 }
 
+static int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: automatic
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("NFISAM_WEIGHTS");
+        v = (e == nullptr) ? -1 : (strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "scalar") == 0 ? 0 : -1));
+    }
+    return v;
+}
+
+template <int KK, int HH, bool MF, bool WL>
+static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, int W, size_t lds, hipStream_t s) {
+    int rc = set_lds(nsf_train_kernel<KK, HH, MF, WL>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL>), dim3((max_n + TILE - 1) / TILE, n_cliques), dim3(64 * W),
+                       lds, s, a);
+    return NFISAM_OK;
+}
+
 static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
     const int W = pick_waves(max_D);
     const bool mf = use_mfma_grad();
     NSF_DISPATCH(K, H, {
-        const size_t lds = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS *
-                           sizeof(float);
-        if (mf) {
-            int rc = set_lds(nsf_train_kernel<KK, HH, true>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train_kernel<KK, HH, true>), dim3((max_n + TILE - 1) / TILE, n_cliques),
-                               dim3(64 * W), lds, s, a);
-        } else {
-            int rc = set_lds(nsf_train_kernel<KK, HH, false>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train_kernel<KK, HH, false>), dim3((max_n + TILE - 1) / TILE, n_cliques),
-                               dim3(64 * W), lds, s, a);
-        }
+        const size_t base = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS *
+                            sizeof(float);
+        const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
+        const size_t wbytes = (size_t)a.L * stride * sizeof(float);
+        // LDS copy of the parameters: pays when few waves share a SIMD (nothing hides a cold scalar-cache
+        // miss per weight row); it must fit next to the tiles.  Large batches keep the scalar path.
+        const int wm = weights_mode();
+        const long blocks = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+        const bool fits = base + wbytes <= 150 * 1024;
+        const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096));
+        int rc;
+        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, base + wbytes, s);
+        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, base, s);
+        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, base + wbytes, s);
+        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, base, s);
+        if (rc) return rc;
     });
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

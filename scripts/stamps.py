@@ -1,0 +1,28 @@
+"""Diagnostic (GPU): per-phase cycle stamps of one train-kernel block (needs `make -C nf-isam_amd/csrc stamps`)."""
+import os, sys, ctypes as C
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
+import nfisam_hip as nh
+nh.LIB_PATH = os.path.join(os.path.dirname(nh.LIB_PATH), "libnfisam_hip_stamps.so")
+import bench as BM
+dev = torch.device("cuda:0")
+n, D, L, K, H, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 9, 8, 5.0
+rng = np.random.RandomState(0)
+x = torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev)
+kp = nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, 0)).to(dev), D, K, H, L)
+for _ in range(3):
+    nh.backward(x, kp, K, H, B, L, nll_mode=True)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (64 * 32))()
+assert nh.lib().nfisam_debug_read_stamps(buf) == 0
+st = np.array(buf[:]).reshape(64, 32)
+names = ["start", "x+w loaded", "unit start", "theta(MLP fwd)", "spline fwd", "spline bwd", "MLP bwd (VALU)", "phase A (W2 mfma+flush)",
+         "phase B (W1,W0 mfma+flush)", "end of layers"]
+W = min(D, 8)
+for w in range(W):
+    t = st[w]
+    print("wave %d (dim %d):" % (w, w), " ".join("%s=%d" % (names[i].split()[0], t[i] - t[0]) for i in range(10) if t[i] > 0))
+    if w > 0:
+        seg = [(names[i], int(t[i] - t[i - 1])) for i in range(3, 9)]
+        print("    last-unit segments (cycles):", seg, " total kernel:", int(t[9] - t[0]))

@@ -178,6 +178,11 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
+    // With L == 1 the dims of a tile never exchange data: blockIdx.z picks a group of W dims so that
+    // every wave runs exactly one unit (grid.z = ceil(D / W)).  L > 1 needs all dims in one block.
+    const int dim_lo = blockIdx.z * W;
+    const int dim_step = (gridDim.z > 1) ? D : W;       // one pass over [dim_lo + w] when grouped
+    if (dim_lo >= D) return;
     const int gp = p0 + lane;
     const bool valid = gp < n;
     const int DT = D * XS;
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         WP lp = kp + (size_t)l * Pk;
         const float* xin = xs + l * DT;
         float* xout = xs + (l + 1) * DT;
-        for (int i = w; i < D; i += W) {
+        for (int i = dim_lo + w; i < D; i += dim_step) {
             float h1[H], h2[H], th[PoP];
             load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
             Spline<K> S;
@@ -241,7 +246,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
             for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
             __syncthreads();
         }
-        for (int i = w; i < D; i += W) {
+        for (int i = dim_lo + w; i < D; i += dim_step) {
             float h1[H], h2[H], th[PoP], gth[PoP];
             STAMP(2);
             load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
@@ -477,9 +482,12 @@ struct AdamArgs {
     int L, K, H;
 };
 
-__global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
+__global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
+    // grid = (ADAM_BLOCKS, n_cliques).  Every block reads step/stop at its start; the block that
+    // finishes LAST (ticket) does the per-iteration bookkeeping, so no block can observe a step or
+    // stop value written during the same launch.
     const bool batched = a.cliques != nullptr;
-    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
     float* theta = batched ? cp->kparams : a.single.kparams;
     float* m = batched ? cp->adam_m : a.single.adam_m;
     float* v = batched ? cp->adam_v : a.single.adam_v;
@@ -489,8 +497,11 @@ __global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
     const int n = batched ? cp->n : a.single.n;
     const int D = batched ? cp->D : a.single.D;
 
-    __shared__ int s_step, s_stop;
-    if (threadIdx.x == 0) { s_step = st->step; s_stop = st->stop; }
+    __shared__ int s_step, s_stop, s_last;
+    if (threadIdx.x == 0) {
+        s_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (s_stop != 0 || s_step >= a.cfg.max_iters) return;
     const int t = s_step + 1;
@@ -505,7 +516,7 @@ __global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
     const float step_size = a.cfg.lr / bc1;
     const float inv_bc2s = 1.0f / sqrtf(bc2);
     const float inv_n = 1.0f / (float)n;
-    for (int j = threadIdx.x; j < P; j += blockDim.x) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
         const float g = G[j] * inv_n;
         const float mj = b1 * m[j] + (1.0f - b1) * g;
         const float vj = b2 * v[j] + (1.0f - b2) * g * g;
@@ -515,24 +526,35 @@ __global__ void __launch_bounds__(1024) nsf_adam_kernel(AdamArgs a) {
         theta[j] -= step_size * mj / denom;
         G[j] = 0.0f;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float loss = st->loss_acc * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
+        const int ticket = __hip_atomic_fetch_add(&st->reserved[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        st->reserved[0] = 0;
+        // loss_acc was written by the previous kernel's atomics: read it at agent scope
+        const float acc = __hip_atomic_load(&st->loss_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float loss = acc * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
         iter_loss[t - 1] = loss;
         st->loss_acc = 0.0f;
-        st->step = t;
-        if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; st->stop = 1; }
+        int stop = 0;
+        if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; stop = 1; }
         const int wnd = a.cfg.average_window;
         if (wnd > 0 && (t % wnd) == 0) {
-            float s = 0.0f;
-            for (int j = t - wnd; j < t; ++j) s += iter_loss[j];
+            float s = loss;
+            for (int j = t - wnd; j < t - 1; ++j) s += iter_loss[j];
             const float nw = s / (float)wnd;
             if (st->have_avg != 0 && st->loss_avg != 0.0f) {
                 const float delta = fabsf(1.0f - nw / st->loss_avg);
-                if (delta < a.cfg.loss_delta_tol) st->stop = 1;
+                if (delta < a.cfg.loss_delta_tol) stop = 1;
             }
             st->loss_avg = nw;
             st->have_avg = 1;
         }
+        if (stop) st->stop = 1;
+        st->step = t;
     }
 }
 
@@ -877,17 +899,22 @@ static int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: automati
 }
 
 template <int KK, int HH, bool MF, bool WL>
-static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, int W, size_t lds, hipStream_t s) {
+static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, int W, int groups, size_t lds,
+                                hipStream_t s) {
     int rc = set_lds(nsf_train_kernel<KK, HH, MF, WL>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL>), dim3((max_n + TILE - 1) / TILE, n_cliques), dim3(64 * W),
-                       lds, s, a);
+    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL>), dim3((max_n + TILE - 1) / TILE, n_cliques, groups),
+                       dim3(64 * W), lds, s, a);
     return NFISAM_OK;
 }
 
 static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
     const int W = pick_waves(max_D);
     const bool mf = use_mfma_grad();
+    // L == 1 and no dL/dx requested: dims are independent -> spread them over grid.z
+    // (only when the launch is small: with thousands of waves in flight the extra blocks just re-load tiles)
+    const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+    const int groups = (a.L == 1 && a.gx == nullptr && tiles * W <= 2048) ? (max_D + W - 1) / W : 1;
     NSF_DISPATCH(K, H, {
         const size_t base = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS *
                             sizeof(float);
@@ -896,14 +923,14 @@ static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D,
         // LDS copy of the parameters: pays when few waves share a SIMD (nothing hides a cold scalar-cache
         // miss per weight row); it must fit next to the tiles.  Large batches keep the scalar path.
         const int wm = weights_mode();
-        const long blocks = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+        const long blocks = (long)((max_n + TILE - 1) / TILE) * n_cliques * groups;
         const bool fits = base + wbytes <= 150 * 1024;
         const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096));
         int rc;
-        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, base + wbytes, s);
-        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, base, s);
-        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, base + wbytes, s);
-        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, base, s);
+        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, groups, base + wbytes, s);
+        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, groups, base, s);
+        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, groups, base + wbytes, s);
+        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, groups, base, s);
         if (rc) return rc;
     });
     HIP_TRY(hipGetLastError());
@@ -947,7 +974,12 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H;
-    hipLaunchKernelGGL(nsf_adam_kernel, dim3(n_cliques), dim3(1024), 0, s, ad);
+    // enough blocks to cover the parameters with ~4 per thread, capped (the work is tiny)
+    const size_t Pmax = (size_t)L * kcount(max_D, K, H);
+    int ablocks = (int)((Pmax + 1023) / 1024);
+    if (ablocks < 1) ablocks = 1;
+    if (ablocks > 32) ablocks = 32;
+    hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
 }

@@ -1,0 +1,83 @@
+"""sampler.SimulationBasedSampler — ancestral simulation of a clique's training batch
+(reference: src/sampler/SimulationBasedSampler.py:10-133).
+
+Given the factors inside a clique, draw n joint samples of its variables by forward simulation
+(priors first — including the children's trained flows wrapped as `FlowsPriorFactor` — then
+binary factors from an already-sampled end to the other), and for every factor whose two ends are
+both sampled already (a "loop-closing" factor) draw a *simulated measurement* column instead.
+The batch is laid out [simulated observations | clique variables in pattern order], the true
+measurement values are returned separately: conditioning the trained flow on them gives the
+posterior.
+"""
+from typing import List
+
+import numpy as np
+
+from factors.utils import unpack_prior_binary_nh_da_factors
+
+
+class SimulationBasedSampler:
+    def __init__(self, factors: List, vars: List):
+        self.factors = factors
+        self.vars = vars
+
+    def sample(self, num_samples: int):
+        priors, binaries, null_hypo, assoc = unpack_prior_binary_nh_da_factors(self.factors)
+        if null_hypo or assoc:
+            raise NotImplementedError("null-hypothesis / ambiguous-association factors: next row (SURVEY.md §8 f-2)")
+        drawn = {}
+        for f in priors:                              # assumes priors do not overlap
+            s = f.sample(num_samples)
+            col = 0
+            for v in f.vars:
+                drawn[v] = s[:, col:col + v.dim]
+                col += v.dim
+        obs_cols, obs_vars, true_obs = [], [], []
+
+        def observe(f):
+            true_obs.append(np.asarray(f.observation, dtype=np.float64).ravel())
+            obs_cols.append(f.sample(var1=drawn[f.var1], var2=drawn[f.var2]))
+            obs_vars.append(f.observation_var)
+
+        queue = list(binaries)
+        deferred = []          # factors that could only be simulated "small -> large" (landmark -> pose)
+        stalled = 0
+        while queue:
+            f = queue.pop(0)
+            have1, have2 = f.var1 in drawn, f.var2 in drawn
+            if have1 and have2:
+                observe(f)
+                stalled = 0
+            elif have1 or have2:
+                src, dst = (f.var1, f.var2) if have1 else (f.var2, f.var1)
+                if src.dim < dst.dim:
+                    # never simulate a pose from a landmark; retry later, give up if nothing else is left
+                    if not queue:
+                        deferred.append(f)
+                    else:
+                        queue.append(f)
+                        stalled += 1
+                        if stalled > len(queue):
+                            deferred.extend(queue)
+                            queue = []
+                    continue
+                drawn[dst] = f.sample(var1=drawn[f.var1], var2=None) if have1 else f.sample(var1=None,
+                                                                                          var2=drawn[f.var2])
+                stalled = 0
+            else:
+                queue.append(f)
+                stalled += 1
+                if stalled > len(queue):
+                    raise ValueError("Some factors connect variables that cannot be simulated: " +
+                                     " ".join(str(q) for q in queue))
+        for f in deferred:
+            if f.var1 in drawn and f.var2 in drawn:
+                observe(f)
+            else:
+                missing = [str(v.name) for v in f.vars if v not in drawn]
+                raise ValueError("Some variables have not been sampled: " + " ".join(missing) +
+                                 ". Consider using a different variable elimination ordering.")
+        cols = obs_cols + [drawn[v] for v in self.vars]
+        local_samples = np.hstack(cols) if cols else np.empty((num_samples, 0))
+        unused_obs = np.concatenate(true_obs) if true_obs else np.array([])
+        return local_samples, obs_vars + list(self.vars), unused_obs

@@ -1,15 +1,29 @@
-"""slam.FactorGraphSolver — the solver-side interface of the hot path (reference:
-src/slam/FactorGraphSolver.py:27-107,360-400): argument object, the `ConditionalSampler` /
-`CliqueSeparatorFactor` contracts and the three hooks a density back end implements.
+"""slam.FactorGraphSolver — the incremental-update loop that drives the flow hot path
+(reference: src/slam/FactorGraphSolver.py:27-550,760-933).
 
-Scope note: the Bayes-tree bookkeeping of the reference's FactorGraphSolver
-(graph update, elimination, tree traversal) is host-side Python that *calls* the hot path; it is a
-"next" row and not rebuilt here.  This module carries exactly the part the density back end
-(slam.NFiSAM) plugs into, so a reference solver can use the back end unchanged."""
+One incremental update = `update_physical_and_working_graphs()` + `incremental_inference()`:
+re-eliminate the part of the Bayes tree touched by the new factors, then, leaves first, for every
+clique without a model: simulate its training batch (children enter through their separator
+factors), **train its flow** (`fit_clique_density_model`, the hot path), turn it into a separator
+factor for the parent; finally sample the posterior root -> leaves with the conditional samplers.
+
+Same method names / argument lists / per-clique call order as the reference.  Plotting,
+nested-sampling local samplers and the ccolamd ordering are not rebuilt (out of scope / dead code).
+The density back end plugs in through three hooks (`fit_clique_density_model`,
+`root_clique_density_model_to_leaf`, `clique_density_to_separator_factor`).
+"""
 import json
-from typing import List
+import os
+import time
+from typing import Dict, List
 
 import numpy as np
+
+from factors.Factors import Factor, ImplicitPriorFactor
+from sampler.SimulationBasedSampler import SimulationBasedSampler
+from slam.BayesTree import BayesTree, BayesTreeNode
+from slam.FactorGraph import FactorGraph
+from slam.Variables import Variable, VariableType
 
 
 class SolverArgs:
@@ -34,41 +48,324 @@ class ConditionalSampler:
         raise NotImplementedError("Implementation depends on density estimation method.")
 
 
-class CliqueSeparatorFactor:
+class CliqueSeparatorFactor(ImplicitPriorFactor):
     """Prior over a clique's separator variables induced by its trained density model."""
 
     def sample(self, num_samples: int, **kwargs):
         raise NotImplementedError("implementation depends on density models")
 
-    @property
-    def vars(self) -> List:
-        raise NotImplementedError
-
-    @property
-    def dim(self) -> int:
-        return sum(v.dim for v in self.vars)
-
 
 class FactorGraphSolver:
-    """Holds the per-clique dictionaries the density back end reads/writes
-    (reference: FactorGraphSolver.py:79-104) and declares the hooks (…:360-400)."""
-
     def __init__(self, args: SolverArgs):
         self._args = args
-        self._samples = {}
+        self._physical_graph = FactorGraph()
+        self._working_graph = FactorGraph()
+        self._physical_bayes_tree = None
+        self._working_bayes_tree = None
+        self._implicit_factors = {}          # clique -> separator factor
+        self._samples = {}                   # variable -> posterior samples
+        self._new_nodes = []
+        self._new_factors = []
         self._clique_samples = {}
-        self._clique_true_obs = {}
-        self._clique_density_model = {}
+        self._clique_true_obs = {}           # clique -> true observations appended to its flow input
+        self._clique_density_model = {}      # clique -> trained model
         self._clique_variable_pattern = {}
-        self._implicit_factors = {}
+        self._elimination_ordering = []
+        self._reverse_ordering_map = {}
         self._temp_training_loss = {}
 
+    def set_args(self, args: SolverArgs):
+        raise NotImplementedError("Implementation depends on probabilistic modeling approaches.")
+
+    # ---- read-only views ------------------------------------------------------------------------
+    @property
+    def elimination_method(self) -> str:
+        return self._args.elimination_method
+
+    @property
+    def elimination_ordering(self) -> List[Variable]:
+        return self._elimination_ordering
+
+    @property
+    def physical_vars(self) -> List[Variable]:
+        return self._physical_graph.vars
+
+    @property
+    def new_vars(self) -> List[Variable]:
+        return self._new_nodes
+
+    @property
+    def working_vars(self) -> List[Variable]:
+        return self._working_graph.vars
+
+    @property
+    def physical_factors(self) -> List[Factor]:
+        return self._physical_graph.factors
+
+    @property
+    def new_factors(self) -> List[Factor]:
+        return self._new_factors
+
+    @property
+    def working_factors(self) -> List[Factor]:
+        return self._working_graph.factors
+
+    @property
+    def working_factor_graph(self) -> FactorGraph:
+        return self._working_graph
+
+    @property
+    def physical_factor_graph(self) -> FactorGraph:
+        return self._physical_graph
+
+    @property
+    def working_bayes_tree(self) -> BayesTree:
+        return self._working_bayes_tree
+
+    @property
+    def physical_bayes_tree(self) -> BayesTree:
+        return self._physical_bayes_tree
+
+    def results(self) -> Dict[Variable, np.ndarray]:
+        return self._samples
+
+    # ---- orderings ------------------------------------------------------------------------------
+    def generate_natural_ordering(self) -> None:
+        self._elimination_ordering = self._physical_graph.vars + self._new_nodes
+
+    def generate_pose_first_ordering(self) -> None:
+        """Order of insertion, landmarks eliminated last."""
+        self._elimination_ordering = FactorGraph.generate_pose_first_ordering(
+            self._physical_graph.vars + self._new_nodes)
+
+    def generate_ordering(self) -> None:
+        m = self._args.elimination_method
+        if m == "natural":
+            self.generate_natural_ordering()
+        elif m == "pose_first":
+            self.generate_pose_first_ordering()
+        else:
+            raise NotImplementedError("elimination_method=%r (the reference's ccolamd path is dead code)" % m)
+        self._reverse_ordering_map = {v: k for k, v in enumerate(self._elimination_ordering[::-1])}
+
+    # ---- staging --------------------------------------------------------------------------------
+    def add_node(self, var: Variable = None, name: str = None, dim: int = None) -> "FactorGraphSolver":
+        self._new_nodes.append(var if var else Variable(name, dim))
+        return self
+
+    def add_factor(self, factor: Factor) -> "FactorGraphSolver":
+        self._new_factors.append(factor)
+        return self
+
+    # ---- graph / tree update ------------------------------------------------------------------
+    def update_physical_and_working_graphs(self, timer: List[float] = None, device: str = "cpu") -> "FactorGraphSolver":
+        start = time.time()
+        old_nodes = set(self.physical_vars)
+        touched = set().union(*[set(f.vars) for f in self._new_factors]) if self._new_factors else set()
+        if self._physical_bayes_tree:
+            affected_nodes, sub_trees = self._physical_bayes_tree.get_affected_vars_and_partial_bayes_trees(
+                vars=old_nodes & touched)
+            self._working_graph = self._physical_graph.get_sub_factor_graph_with_prior(
+                variables=affected_nodes, sub_trees=sub_trees, clique_prior_dict=self._implicit_factors)
+        else:
+            sub_trees = []
+        for node in self._new_nodes:
+            self._working_graph.add_node(node)
+        for factor in self._new_factors:
+            self._working_graph.add_factor(factor)
+
+        old_ordering = self._elimination_ordering
+        self.generate_ordering()
+        working = set(self.working_vars)
+        self._working_bayes_tree = self._working_graph.get_bayes_tree(
+            ordering=[v for v in self._elimination_ordering if v in working])
+
+        for node in self._new_nodes:
+            self._physical_graph.add_node(node)
+        for factor in self._new_factors:
+            self._physical_graph.add_factor(factor)
+        self._physical_bayes_tree = self._working_bayes_tree.__copy__()
+        self._physical_bayes_tree.append_child_bayes_trees(sub_trees)
+
+        # Old cliques that vanished: if one reappears with the same variables in the same relative
+        # order (last update's root is now a leaf), its trained flow is re-used instead of re-trained.
+        live = self._physical_bayes_tree.clique_nodes
+        to_delete = []
+        for old_clique in list(self._clique_density_model.keys()):
+            if old_clique in live:
+                continue
+            for new_clique in self._working_bayes_tree.clique_ordering():
+                if old_clique.vars == new_clique.vars and \
+                        [v for v in old_ordering if v in old_clique.vars] == \
+                        [v for v in self._elimination_ordering if v in new_clique.vars]:
+                    self._clique_true_obs[new_clique] = self._clique_true_obs[old_clique]
+                    if old_clique in self._clique_variable_pattern:
+                        self._clique_variable_pattern[new_clique] = self._clique_variable_pattern[old_clique]
+                    if old_clique in self._clique_samples:
+                        self._clique_samples[new_clique] = self._clique_samples[old_clique]
+                    self._clique_density_model[new_clique] = \
+                        self.root_clique_density_model_to_leaf(old_clique, new_clique, device)
+                    new_separator_factor = None
+                    if new_clique.separator:
+                        separator_var_list = sorted(new_clique.separator, key=lambda x: self._reverse_ordering_map[x])
+                        new_separator_factor = self.clique_density_to_separator_factor(
+                            separator_var_list, self._clique_density_model[new_clique],
+                            self._clique_true_obs[old_clique])
+                        self._implicit_factors[new_clique] = new_separator_factor
+                    self._working_graph = self._working_graph.eliminate_clique_variables(
+                        clique=new_clique, new_factor=new_separator_factor)
+                    break
+            to_delete.append(old_clique)
+        for old_clique in to_delete:
+            # (an old clique equal to a re-used new clique shares its key: keep the new entries)
+            if old_clique in self._working_bayes_tree.clique_nodes:
+                continue
+            self._clique_density_model.pop(old_clique, None)
+            self._clique_true_obs.pop(old_clique, None)
+            self._clique_variable_pattern.pop(old_clique, None)
+            self._clique_samples.pop(old_clique, None)
+
+        self._new_nodes = []
+        self._new_factors = []
+        if timer is not None:
+            timer.append(time.time() - start)
+        return self
+
+    # ---- hooks of the density back end ----------------------------------------------------------
     def fit_clique_density_model(self, clique, samples, var_ordering, timer, *args, **kwargs) -> ConditionalSampler:
         raise NotImplementedError("Implementation depends on probabilistic modeling.")
 
-    def root_clique_density_model_to_leaf(self, old_clique, new_clique, device) -> ConditionalSampler:
+    def root_clique_density_model_to_leaf(self, old_clique: BayesTreeNode, new_clique: BayesTreeNode,
+                                          device) -> ConditionalSampler:
         raise NotImplementedError("Implementation depends on probabilistic modeling")
 
-    def clique_density_to_separator_factor(self, separator_var_list, density_model,
+    def clique_density_to_separator_factor(self, separator_var_list: List[Variable], density_model,
                                            true_obs: np.ndarray) -> CliqueSeparatorFactor:
         raise NotImplementedError("Implementation depends on probabilistic modeling")
+
+    def adaptive_posterior(self, timer: List[float] = None, *args, **kwargs):
+        raise NotImplementedError("implementation depends on density models.")
+
+    # ---- inference ------------------------------------------------------------------------------
+    def incremental_inference(self, timer: List[float] = None, clique_dim_timer: List[List[float]] = None, *args,
+                              **kwargs):
+        self.fit_tree_density_models(timer=timer, clique_dim_timer=clique_dim_timer, *args, **kwargs)
+        if self._args.adaptive_posterior_sampling is None:
+            self._samples = self.sample_posterior(timer=timer, *args, **kwargs)
+        else:
+            self._samples = self.adaptive_posterior(timer=timer, *args, **kwargs)
+        return self._samples
+
+    def fit_tree_density_models(self, timer: List[float] = None, clique_dim_timer: List[List[float]] = None, *args,
+                                **kwargs):
+        """Leaves first: local sampling and flow training on every clique of the working tree that
+        has no model yet (reference :409-477)."""
+        self._temp_training_loss = {}
+        clique_ordering = self._working_bayes_tree.clique_ordering()
+        t_begin = time.time()
+        while clique_ordering:
+            clique = clique_ordering.pop()
+            if clique in self._clique_density_model:
+                if clique_dim_timer is not None:
+                    clique_dim_timer.append([clique.dim, time.time() - t_begin])
+                continue
+            t0 = time.time()
+            local_samples, sample_var_ordering, true_obs = self.clique_training_sampler(
+                clique, num_samples=self._args.local_sample_num, method=self._args.local_sampling_method)
+            if timer is not None:
+                timer.append(time.time() - t0)
+            self._clique_true_obs[clique] = true_obs
+            if self._args.store_clique_samples:
+                self._clique_samples[clique] = local_samples
+            model = self.fit_clique_density_model(clique=clique, samples=local_samples,
+                                                  var_ordering=sample_var_ordering, timer=timer)
+            self._clique_density_model[clique] = model
+            new_separator_factor = None
+            if clique.separator:
+                separator_list = sorted(clique.separator, key=lambda x: self._reverse_ordering_map[x])
+                new_separator_factor = self.clique_density_to_separator_factor(separator_list, model, true_obs)
+                self._implicit_factors[clique] = new_separator_factor
+            self._working_graph = self._working_graph.eliminate_clique_variables(clique=clique,
+                                                                                 new_factor=new_separator_factor)
+            if clique_dim_timer is not None:
+                clique_dim_timer.append([clique.dim, time.time() - t_begin])
+
+    def clique_training_sampler(self, clique: BayesTreeNode, num_samples: int, method: str):
+        """-> (training samples [n, D], variable ordering incl. observation variables, true observations)."""
+        graph = self._working_graph.get_clique_factor_graph(clique)
+        variable_pattern = self._working_bayes_tree.clique_variable_pattern(clique)
+        if method == "direct":
+            sampler = SimulationBasedSampler(factors=graph.factors, vars=variable_pattern)
+            return sampler.sample(num_samples)
+        raise ValueError("Unknown sampling method (nested-sampling local samplers are not rebuilt).")
+
+    def sample_posterior(self, timer: List[float] = None, *args, **kwargs) -> Dict[Variable, np.ndarray]:
+        """Root -> leaves: every clique samples its frontal variables conditioned on its true
+        observations and the already-sampled separator variables (reference :497-550)."""
+        num_samples = self._args.posterior_sample_num
+        start = time.time()
+        stack = [self._physical_bayes_tree.root]
+        samples = {}
+        while stack:
+            clique = stack.pop()
+            frontal_list = sorted(clique.frontal, key=lambda x: self._reverse_ordering_map[x])
+            separator_list = sorted(clique.separator, key=lambda x: self._reverse_ordering_map[x])
+            model = self._clique_density_model[clique]
+            obs = self._clique_true_obs[clique]
+            given = [np.tile(obs, (num_samples, 1))] if len(obs) != 0 else []
+            given += [samples[v] for v in separator_list]
+            if given:
+                frontal_samples = model.conditional_sample_given_observation(
+                    conditional_dim=clique.frontal_dim, obs_samples=np.hstack(given))
+            else:
+                frontal_samples = model.conditional_sample_given_observation(
+                    conditional_dim=clique.frontal_dim, sample_number=num_samples)
+            col = 0
+            for v in frontal_list:
+                samples[v] = frontal_samples[:, col:col + v.dim]
+                col += v.dim
+            stack.extend(clique.children)
+        if timer is not None:
+            timer.append(time.time() - start)
+        return samples
+
+
+def run_incrementally(case_dir: str, solver: FactorGraphSolver, nodes_factors_by_step, truth=None, traj_plot=False,
+                      plot_args=None, check_root_transform=False) -> str:
+    """Feed the solver step by step and write the reference's per-step result files
+    (reference :760-933; figures are not produced).  Returns the run directory."""
+    run_count = 1
+    while os.path.exists(f"{case_dir}/run{run_count}"):
+        run_count += 1
+    run_dir = f"{case_dir}/run{run_count}"
+    os.makedirs(run_dir)
+    with open(f"{run_dir}/parameters", "w+") as f:
+        f.write(solver._args.jsonStr())
+    step_timer, step_list, posterior_sampling_timer, fitting_timer = [], [], [], []
+    for i, (step_nodes, step_factors) in enumerate(nodes_factors_by_step):
+        for node in step_nodes:
+            solver.add_node(node)
+        for factor in step_factors:
+            solver.add_factor(factor)
+        step_list.append(i)
+        prefix = f"{run_dir}/step{i}"
+        detailed_timer, clique_dim_timer = [], []
+        start = time.time()
+        solver.update_physical_and_working_graphs(timer=detailed_timer)
+        cur_sample = solver.incremental_inference(timer=detailed_timer, clique_dim_timer=clique_dim_timer)
+        step_timer.append(time.time() - start)
+        with open(f"{prefix}_ordering", "w+") as f:
+            f.write(" ".join([str(v.name) for v in solver.elimination_ordering]))
+        with open(f"{prefix}_split_timing", "w+") as f:
+            f.write(" ".join([str(t) for t in detailed_timer]))
+        with open(f"{prefix}_step_training_loss", "w+") as f:
+            f.write(json.dumps(solver._temp_training_loss))
+        posterior_sampling_timer.append(detailed_timer[-1])
+        fitting_timer.append(sum(detailed_timer[1:-1]))
+        np.savetxt(fname=prefix, X=np.hstack([cur_sample[v] for v in solver.elimination_ordering]))
+        np.savetxt(fname=prefix + "_dim_time", X=np.array(clique_dim_timer))
+        for name, vals in (("step_timing", step_timer), ("step_list", step_list),
+                           ("posterior_sampling_timer", posterior_sampling_timer), ("fitting_timer", fitting_timer)):
+            with open(f"{run_dir}/{name}", "w+") as f:
+                f.write(" ".join(str(t) for t in vals))
+    return run_dir

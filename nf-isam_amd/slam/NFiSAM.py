@@ -28,7 +28,9 @@ import nfisam_hip as _nh
 from flows.flows import NSF_AR
 from flows.models import NormalizingFlowModel
 from flows.prior_dist import CustomMultivariateNormal, MultivariateNormalVonmises  # noqa: F401
-from slam.FactorGraphSolver import CliqueSeparatorFactor, ConditionalSampler, FactorGraphSolver, SolverArgs
+from slam.FactorGraphSolver import CliqueSeparatorFactor, ConditionalSampler, FactorGraphSolver, SolverArgs, \
+    run_incrementally
+from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
 from utils.Functions import theta_to_pipi
 
 
@@ -195,6 +197,7 @@ class FlowsPriorFactor(CliqueSeparatorFactor):
 
     def __init__(self, vars: List, flow_model: NormalizingFlowModelWithSeparator, true_obs: np.ndarray,
                  circular_dim_list: List) -> None:
+        super().__init__()
         self._vars = vars
         self._flow_model = flow_model
         self._is_gaussian = False
@@ -385,3 +388,28 @@ class NFiSAM(FactorGraphSolver):
         obs_separator_dim = sum([var.dim for var in separator_var_list]) + obs_dim
         return FlowsPriorFactor(vars=separator_var_list, flow_model=density_model, true_obs=true_obs,
                                 circular_dim_list=density_model.circular_dim_list[obs_dim: obs_separator_dim])
+
+
+def NFiSAM_empirial_study(knots, iters, training_samples, learning_rates, hidden_dims, case_dir, data_file,
+                          data_format, incremental_step=1, prior_cov_scale=0.1, traj_plot=False, plot_args=None,
+                          check_root_transform=False, **kwargs):
+    """Grid driver of the example scripts (reference: NFiSAM.py:589-609): parse the graph, group it
+    into incremental updates and run one solver per hyper-parameter combination.  Returns the run
+    directories (the reference returns None)."""
+    import os
+    nodes, truth, factors = graph_file_parser(data_file=os.path.join(case_dir, data_file), data_format=data_format,
+                                              prior_cov_scale=prior_cov_scale)
+    nodes_factors_by_step = group_nodes_factors_incrementally(nodes=nodes, factors=factors,
+                                                              incremental_step=incremental_step)
+    run_dirs = []
+    for knt in knots:
+        for it in iters:
+            for training_sample in training_samples:
+                for lr in learning_rates:
+                    for hidden_dim in hidden_dims:
+                        args = NFiSAMArgs(num_knots=knt, flow_iterations=it, local_sample_num=training_sample,
+                                          learning_rate=lr, hidden_dim=hidden_dim, **kwargs)
+                        solver = NFiSAM(args)
+                        run_dirs.append(run_incrementally(case_dir, solver, nodes_factors_by_step, truth, traj_plot,
+                                                          plot_args, check_root_transform))
+    return run_dirs

@@ -1,0 +1,249 @@
+"""CPU tests of the host bookkeeping around the hot path: `.fg` parsing,
+incremental grouping, symbolic elimination -> Bayes tree, affected-subtree extraction, the clique
+training-batch simulator's column layout and the solver loop's per-clique call order (with a stand-in
+density back end: the real one needs a GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from factors.Factors import Factor, SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor, \
+    UnarySE2ApproximateGaussianPriorFactor
+from geometry.TwoDimension import SE2Pose, se2_compose, se2_exp, se2_inverse, se2_log
+from sampler.SimulationBasedSampler import SimulationBasedSampler
+from slam.BayesTree import BayesTree, BayesTreeNode
+from slam.FactorGraph import FactorGraph
+from slam.FactorGraphSimulator import factor_graph_to_string, read_factor_graph_from_file
+from slam.FactorGraphSolver import CliqueSeparatorFactor, ConditionalSampler, FactorGraphSolver, SolverArgs
+from slam.RunBatch import group_nodes_factors_incrementally
+from slam.Variables import R2Variable, SE2Variable, VariableType
+from utils.Statistics import MMDb
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def small_graph(tmp_path_factory):
+    g = np.load(os.path.join(GOLDEN, "small_range_case1.npz"))
+    p = tmp_path_factory.mktemp("fg") / "factor_graph.fg"
+    p.write_text(str(g["factor_graph_fg"]))
+    return read_factor_graph_from_file(str(p)), str(p)
+
+
+def test_se2_algebra():
+    rng = np.random.RandomState(0)
+    v = rng.randn(50, 3) * np.array([2.0, 2.0, 1.0])
+    v[0] = [1.0, 2.0, 0.0]                               # zero rotation branch
+    p = se2_exp(v)
+    np.testing.assert_allclose(se2_log(p), v, atol=1e-10)
+    ident = se2_compose(p, se2_inverse(p))
+    np.testing.assert_allclose(ident, 0, atol=1e-10)
+    a, b = SE2Pose(1, 2, 0.5), SE2Pose(-3, 0.5, 2.9)
+    np.testing.assert_allclose((a * b).matrix, a.matrix @ b.matrix, atol=1e-12)
+    np.testing.assert_allclose((a / b).matrix, a.matrix @ np.linalg.inv(b.matrix), atol=1e-12)
+    np.testing.assert_allclose(SE2Pose.by_exp_map(a.log_map()).array, a.array, atol=1e-12)
+
+
+def test_fg_roundtrip_and_grouping(small_graph):
+    (nodes, truth, factors), path = small_graph
+    assert [v.name for v in nodes] == ["X0", "X1", "X2", "X3", "X4", "X5", "L1", "L2"]
+    assert len(factors) == 14 and isinstance(factors[0], UnarySE2ApproximateGaussianPriorFactor)
+    np.testing.assert_allclose(truth[nodes[2]], [30.0, 30.0, 0.0])
+    text = factor_graph_to_string(nodes, factors, truth)
+    again = [Factor.construct_from_text(l, nodes) for l in text.splitlines() if l.startswith("Factor")]
+    assert [str(f) for f in again] == [str(f) for f in factors]
+    steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=1)
+    assert [[v.name for v in s[0]] for s in steps] == [["X0", "L1", "L2"], ["X1"], ["X2"], ["X3"], ["X4"], ["X5"]]
+    assert [len(s[1]) for s in steps] == [3, 2, 2, 2, 2, 3]
+    assert sum(len(s[1]) for s in steps) == len(factors)
+    two = group_nodes_factors_incrementally(nodes, factors, incremental_step=2)
+    assert [[v.name for v in s[0]] for s in two] == [["X0", "L1", "L2", "X1"], ["X2", "X3"], ["X4", "X5"]]
+    with pytest.raises(NotImplementedError):
+        Factor.construct_from_text("Factor R2RangeGaussianLikelihoodFactor X0 L1 1 1", nodes)
+
+
+def test_factor_sampling_statistics():
+    np.random.seed(0)
+    X0, X1, L = SE2Variable("X0"), SE2Variable("X1"), R2Variable("L1", VariableType.Landmark)
+    cov = np.diag([0.04, 0.0016, 0.0004])
+    prior = UnarySE2ApproximateGaussianPriorFactor(X0, SE2Pose(1.0, 2.0, 1.5), cov)
+    s0 = prior.sample(20000)
+    eps = se2_log(se2_compose(se2_inverse(np.array([1.0, 2.0, 1.5])), s0))
+    np.testing.assert_allclose(np.cov(eps.T), cov, atol=3e-3)
+    odo = SE2RelativeGaussianLikelihoodFactor(X0, X1, SE2Pose(30, 0, -1.2), covariance=cov)
+    s1 = odo.sample(var1=s0, var2=None)
+    rel = se2_compose(se2_inverse(s0), s1)
+    np.testing.assert_allclose(np.median(rel, 0), [30, 0, -1.2], atol=0.02)
+    back = odo.sample(var1=None, var2=s1)          # inverse direction is consistent in distribution
+    np.testing.assert_allclose(back.mean(0)[:2], s0.mean(0)[:2], atol=0.05)
+    obs = odo.sample(var1=s0, var2=s1)
+    assert obs.shape == (20000, 3) and odo.observation_var.circular_dim_list == [False, False, True]
+    rng_f = SE2R2RangeGaussianLikelihoodFactor(X0, L, 42.4, sigma=2.0)
+    lm = rng_f.sample(var1=s0, var2=None)
+    d = np.linalg.norm(lm - s0[:, :2], axis=1)
+    assert abs(d.mean() - 42.4) < 0.1 and abs(d.std() - 2.0) < 0.1
+    ang = np.arctan2((lm - s0[:, :2])[:, 1], (lm - s0[:, :2])[:, 0])
+    assert abs(np.mean(np.cos(ang))) < 0.03               # uniform bearing: ring
+    o = rng_f.sample(var1=s0, var2=lm)
+    assert o.shape == (20000, 1) and abs((o[:, 0] - d).std() - 2.0) < 0.1
+
+
+def test_bayes_tree_from_chain_and_affected_subtrees(small_graph):
+    (nodes, truth, factors), _ = small_graph
+    g = FactorGraph()
+    for v in nodes:
+        g.add_node(v)
+    for f in factors:
+        g.add_factor(f)
+    order = FactorGraph.generate_pose_first_ordering(nodes)
+    assert [v.name for v in order] == ["X0", "X1", "X2", "X3", "X4", "X5", "L1", "L2"]
+    tree = g.get_bayes_tree(ordering=order)
+    cliques = tree.clique_ordering()
+    names = lambda vs: sorted(v.name for v in vs)   # noqa: E731
+    # pose_first gives a chain: root {L1,L2,X4,X5}, then X3 | L1 L2 X4, ...
+    assert names(cliques[0].frontal) == ["L1", "L2", "X4", "X5"] and not cliques[0].separator
+    for k, c in enumerate(cliques[1:]):
+        assert names(c.frontal) == ["X%d" % (3 - k)] and names(c.separator) == ["L1", "L2", "X%d" % (4 - k)]
+        assert len(c.children) <= 1
+    pat = tree.clique_variable_pattern(cliques[1])
+    assert [v.name for v in pat] == ["L2", "L1", "X4", "X3"]          # [separator | frontal], reverse elimination order
+    # running intersection + every variable is frontal exactly once
+    assert sorted(v.name for c in cliques for v in c.frontal) == sorted(v.name for v in nodes)
+    cp = tree.__copy__()
+    assert cp.clique_nodes == tree.clique_nodes and cp.root is not tree.root
+    X1 = nodes[1]
+    affected, subs = tree.get_affected_vars_and_partial_bayes_trees({X1})
+    assert names(affected) == ["L1", "L2", "X1", "X2", "X3", "X4", "X5"]
+    assert len(subs) == 1 and names(subs[0].root.frontal) == ["X0"]
+    # hash / equality semantics: same frontal + separator => same clique key
+    a = BayesTreeNode(frontal={nodes[0]}, separator={nodes[6]})
+    b = BayesTreeNode(frontal={nodes[0]}, separator={nodes[6]})
+    assert a == b and hash(a) == hash(b) and a != BayesTreeNode(frontal={nodes[0]})
+
+
+def test_natural_ordering_gives_a_branching_tree():
+    """x0 - x1 - x2 with two landmarks seen from the ends: sibling subtrees exist (sharding unit)."""
+    X = [SE2Variable("X%d" % i) for i in range(3)]
+    L = [R2Variable("L%d" % i, VariableType.Landmark) for i in range(2)]
+    cov = np.eye(3) * 0.01
+    g = FactorGraph()
+    for v in X + L:
+        g.add_node(v)
+    g.add_factor(UnarySE2ApproximateGaussianPriorFactor(X[0], SE2Pose(), cov))
+    g.add_factor(SE2RelativeGaussianLikelihoodFactor(X[0], X[1], SE2Pose(1, 0, 0), covariance=cov))
+    g.add_factor(SE2RelativeGaussianLikelihoodFactor(X[1], X[2], SE2Pose(1, 0, 0), covariance=cov))
+    g.add_factor(SE2R2RangeGaussianLikelihoodFactor(X[0], L[0], 1.0, 0.1))
+    g.add_factor(SE2R2RangeGaussianLikelihoodFactor(X[2], L[1], 1.0, 0.1))
+    tree = g.get_bayes_tree(ordering=[L[0], L[1], X[0], X[2], X[1]])
+    root = tree.root
+    assert len(tree.clique_ordering()) >= 3 and any(len(c.children) >= 2 for c in tree.clique_ordering()) or \
+        len(root.children) >= 1
+
+
+def test_simulation_sampler_layout(small_graph):
+    (nodes, truth, factors), _ = small_graph
+    np.random.seed(1)
+    name = {v.name: v for v in nodes}
+    # the last clique of the real run: X4, X5, L1, L2 with two loop-closing range factors at X5
+    prior = UnarySE2ApproximateGaussianPriorFactor(name["X4"], SE2Pose(90, 30, 0), np.eye(3) * 1e-2)
+    fs = [prior] + [f for f in factors if set(v.name for v in f.vars) <= {"X4", "X5", "L1", "L2"} and len(f.vars) == 2]
+    pattern = [name["L2"], name["L1"], name["X5"], name["X4"]]
+    samples, order, obs = SimulationBasedSampler(fs, pattern).sample(500)
+    assert [v.name for v in order][-4:] == ["L2", "L1", "X5", "X4"]
+    n_obs = len(order) - 4
+    assert samples.shape == (500, n_obs + 2 + 2 + 3 + 3) and obs.shape == (n_obs,)
+    assert n_obs >= 1 and all(str(v.name).startswith("O") for v in order[:n_obs])
+    assert set(np.round(obs, 3)) <= {round(float(f.observation[0]), 3) for f in fs[1:] if len(f.observation) == 1}
+
+
+class _StubModel(ConditionalSampler):
+    def __init__(self, mean):
+        self.mean = mean
+
+    def conditional_sample_given_observation(self, conditional_dim, obs_samples=None, sample_number=None):
+        n = sample_number if obs_samples is None else obs_samples.shape[0]
+        o = 0 if obs_samples is None else obs_samples.shape[1]
+        return self.mean[o:o + conditional_dim] + 0.01 * np.random.randn(n, conditional_dim)
+
+
+class _StubFactor(CliqueSeparatorFactor):
+    def __init__(self, vars, model, obs):
+        self._v, self.m, self.obs = vars, model, obs
+
+    @property
+    def vars(self):
+        return self._v
+
+    def sample(self, n, **kw):
+        d = sum(v.dim for v in self._v)
+        if len(self.obs):
+            return self.m.conditional_sample_given_observation(d, obs_samples=np.tile(self.obs, (n, 1)))
+        return self.m.conditional_sample_given_observation(d, sample_number=n)
+
+
+class _StubSolver(FactorGraphSolver):
+    def __init__(self, args):
+        super().__init__(args)
+        self.log = []
+
+    def fit_clique_density_model(self, clique, samples, var_ordering, timer, *a, **k):
+        self.log.append(("fit", sorted(v.name for v in clique.frontal), samples.shape[1]))
+        return _StubModel(samples.mean(0))
+
+    def root_clique_density_model_to_leaf(self, old, new, device):
+        self.log.append(("reuse", sorted(v.name for v in new.frontal)))
+        return self._clique_density_model[old]
+
+    def clique_density_to_separator_factor(self, sep, model, obs):
+        return _StubFactor(sep, model, obs)
+
+
+def test_solver_loop_structure_matches_reference_run(small_graph):
+    """D = 7 -> 11 -> ... -> 12 and one trained clique per update with root-model reuse, as measured
+    on the reference (SURVEY.md §8 'Sizes at the BASELINE configs', §0.4)."""
+    (nodes, truth, factors), _ = small_graph
+    np.random.seed(0)
+    s = _StubSolver(SolverArgs(elimination_method="pose_first", local_sample_num=64, posterior_sample_num=16))
+    dims = []
+    for vs, fs in group_nodes_factors_incrementally(nodes, factors, 1):
+        for v in vs:
+            s.add_node(v)
+        for f in fs:
+            s.add_factor(f)
+        s.update_physical_and_working_graphs()
+        res = s.incremental_inference()
+        assert set(res) == set(s.physical_vars) and all(x.shape[0] == 16 for x in res.values())
+        dims.append([e[2] for e in s.log if e[0] == "fit"][-1])
+    assert dims == [7, 11, 11, 11, 11, 12]
+    assert sum(1 for e in s.log if e[0] == "fit") == 6
+    assert [e[1] for e in s.log if e[0] == "reuse"] == [["X0"], ["X1"], ["X2"], ["X3"]]
+    assert [v.name for v in s.elimination_ordering] == ["X0", "X1", "X2", "X3", "X4", "X5", "L1", "L2"]
+    for v in nodes[:6]:   # stub models return batch means: poses land near the truth
+        assert np.linalg.norm(res[v].mean(0)[:2] - truth[v][:2]) < 3.0
+
+
+def test_mmd_metric():
+    rng = np.random.RandomState(0)
+    a, b = rng.randn(500, 2), rng.randn(500, 2)
+    assert MMDb(a, b) < 0.1 and MMDb(a, b + 3.0) > 0.5
+    assert abs(MMDb(a, a)) < 1e-7
+
+
+def test_reference_nf_vs_nested_sampling_discrepancy_is_what_the_survey_measured():
+    """Calibration of the posterior parity tolerance: MMDb(reference NF-iSAM run, nested sampling)."""
+    g = np.load(os.path.join(GOLDEN, "small_range_case1.npz"))
+    vals = []
+    for i in range(4):
+        o_run, o_dyn = str(g["run1_step%d_ordering" % i]).split(), str(g["dyn1_step%d_ordering" % i]).split()
+        cols = lambda order, arr: np.hstack([arr[:, _off(order, v):_off(order, v) + 2] for v in sorted(order)])  # noqa: E731
+        vals.append(MMDb(cols(o_run, g["run1_step%d" % i]), cols(o_dyn, g["dyn1_step%d" % i])))
+    assert all(0.01 < v < 0.35 for v in vals), vals
+
+
+def _off(order, name):
+    off = 0
+    for v in order:
+        if v == name:
+            return off
+        off += 3 if v.startswith("X") else 2
+    raise KeyError(name)

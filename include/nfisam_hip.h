@@ -104,6 +104,33 @@ int nfisam_rqs(const float* inputs, const float* widths, const float* heights, c
                int inverse, float left, float right, float bottom, float top, int padded_derivatives,
                float* out, float* logabsdet, nfisam_stream_t stream);
 
+/* ---- posterior traversal ------------------------------------------------------------------ */
+/* One clique of the tree walk, parents before children.  Column indices refer to the sample matrix. */
+typedef struct nfisam_post_clique {
+    const float* kparams;        /* the clique's trained flow, kernel layout, D_model dims, L layers   */
+    const float* mean;           /* [D_model] normalisation constants (slam/NFiSAM.py:515-548)        */
+    const float* std;
+    const uint8_t* circular;     /* [D_model] 1 = angle column                                        */
+    int32_t D_model;             /* n_obs + all clique variable dims                                  */
+    int32_t n_obs;               /* leading true-observation columns                                  */
+    int32_t n_sep;               /* separator columns (already sampled by ancestors)                  */
+    int32_t n_frontal;           /* columns sampled by this clique                                    */
+    int32_t obs_off;             /* offset of the clique's true observations in `obs`                 */
+    int32_t sep_off;             /* offset in `cols` of the n_sep source column indices               */
+    int32_t front_off;           /* offset in `cols` of the n_frontal destination column indices      */
+    int32_t reserved;
+} nfisam_post_clique;
+
+/* FactorGraphSolver.sample_posterior (src/slam/FactorGraphSolver.py:497-550) for a whole tree in ONE
+ * launch: for every clique in `table` order (root first) sample its frontal columns conditioned on its
+ * true observations and on the separator columns sampled earlier, exactly as n_cliques successive
+ * conditional_sample_given_observation calls would (slam/NFiSAM.py:120-155), but without leaving
+ * the device.  Zt[total_dim][n]: standard-normal draws, St[total_dim][n]: output samples, both
+ * COLUMN-major; cols/obs: device arrays indexed by the table; max_D: largest D_model.        */
+int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs,
+                              int max_D, int K, int H, float B, int L, int n, const float* Zt, float* St,
+                              nfisam_stream_t stream);
+
 /* ---- training -------------------------------------------------------------------------- */
 /* Vector-Jacobian product of the L-layer flow (what torch autograd computes for
  * `loss.backward()` in slam/NFiSAM.py:474): kgrad[L*kparam_count] += d<gz,z>/dtheta + d<gl,logdet>/dtheta,

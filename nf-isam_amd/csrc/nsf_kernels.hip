@@ -698,6 +698,64 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
 }
 
 // =============================================================================================
+// posterior traversal of a whole Bayes tree in ONE launch (SURVEY.md §8 f-1;
+// reference: FactorGraphSolver.sample_posterior, src/slam/FactorGraphSolver.py:497-550, which
+// makes one host-synchronised conditional-sampling call per clique).
+// Sample j of a child clique is conditioned on sample j of its parent only, so a wave of 64
+// samples can walk all cliques root -> leaves on its own: no inter-block synchronisation, samples
+// never leave the device.  St / Zt are COLUMN-major [total_dim][n] (one variable column = one
+// coalesced run over particles); St receives the un-normalised posterior samples.
+// =============================================================================================
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_post_clique* __restrict__ table,
+                                                                int n_cliques, const int32_t* __restrict__ cols,
+                                                                const float* __restrict__ obs, float B, int L, int n,
+                                                                const float* __restrict__ Zt, float* __restrict__ St) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x * TILE + lane;
+    const bool valid = p < n;
+    const size_t pp = valid ? (size_t)p : 0;
+    float* xs = smem;                       // [Dmax][TILE]
+    for (int c = 0; c < n_cliques; ++c) {
+        const nfisam_post_clique q = table[c];
+        const int n_obs = q.n_obs, Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const float* mean = q.mean;
+        const float* stdv = q.std;
+        const uint8_t* circ = q.circular;
+        // given columns: true observations (same for every sample) then the separator samples
+        for (int k = 0; k < Ds; ++k) {
+            float v = (k < n_obs) ? obs[q.obs_off + k] : St[(size_t)cols[q.sep_off + (k - n_obs)] * n + pp];
+            const float d = v - mean[k];
+            xs[k * TILE + lane] = (circ[k] ? wrap_pi(d) : d) / stdv[k];
+        }
+        cfloat* kp = (cfloat*)q.kparams;
+        const int Pk = LY::count(q.D_model);
+        for (int l = L - 1; l >= 0; --l) {
+            cfloat* lp = kp + (size_t)l * Pk;
+            for (int i = Ds; i < D; ++i) {
+                float h1[H], h2[H], th[PoP];
+                load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
+                // layer L-1 consumes the latent draw; lower layers consume the previous layer's output
+                const float zin = (l == L - 1) ? Zt[(size_t)cols[q.front_off + (i - Ds)] * n + pp] : xs[i * TILE + lane];
+                Spline<K> S;
+                float xi, lad;
+                spline_eval<K, PoP, true>(zin, th, B, S, xi, lad);
+                xs[i * TILE + lane] = xi;
+            }
+        }
+        for (int i = Ds; i < D; ++i) {
+            float v = xs[i * TILE + lane] * stdv[i] + mean[i];
+            if (circ[i]) v = wrap_pi(v);
+            if (valid) St[(size_t)cols[q.front_off + (i - Ds)] * n + p] = v;
+        }
+        // the next clique may read the columns just written by THIS lane only: program order suffices
+    }
+}
+
+// =============================================================================================
 // elementwise spline with per-element logits in memory (flows.utils.unconstrained_RQS / RQS,
 // src/flows/utils.py:25-164).  Runtime K: the logits are streamed twice (softmax statistics, then
 // cumulative knots + bin selection) so no per-lane arrays are needed.  HBM/latency-bound helper of
@@ -856,6 +914,24 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
         hipLaunchKernelGGL((nsf_inverse_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
                            (hipStream_t)stream, z, x_sep, kparams, n, D, Ds, B, L, (int)layer_stride, mean, stdv, circular,
                            x_out, logdet);
+    });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols,
+                                         const float* obs, int max_D, int K, int H, float B, int L, int n,
+                                         const float* Zt, float* St, nfisam_stream_t stream) {
+    if (table == nullptr || cols == nullptr || Zt == nullptr || St == nullptr || n_cliques < 0 || n < 0 || max_D < 1 ||
+        L < 1 || !(B > 0))
+        return NFISAM_ERR_ARG;
+    if (n == 0 || n_cliques == 0) return NFISAM_OK;
+    const size_t lds = (size_t)max_D * TILE * sizeof(float);
+    NSF_DISPATCH(K, H, {
+        int rc = set_lds(nsf_posterior_walk_kernel<KK, HH>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nsf_posterior_walk_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
+                           (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, Zt, St);
     });
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

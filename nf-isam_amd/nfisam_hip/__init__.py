@@ -22,7 +22,7 @@ EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
-    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs",
+    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk",
 ]
 
 
@@ -47,7 +47,13 @@ class Clique(C.Structure):
                 ("n", C.c_int32), ("D", C.c_int32)]
 
 
-assert C.sizeof(TrainState) == 64 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64
+class PostClique(C.Structure):
+    _fields_ = [("kparams", C.c_void_p), ("mean", C.c_void_p), ("std", C.c_void_p), ("circular", C.c_void_p),
+                ("D_model", C.c_int32), ("n_obs", C.c_int32), ("n_sep", C.c_int32), ("n_frontal", C.c_int32),
+                ("obs_off", C.c_int32), ("sep_off", C.c_int32), ("front_off", C.c_int32), ("reserved", C.c_int32)]
+
+
+assert C.sizeof(TrainState) == 64 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64 and C.sizeof(PostClique) == 64
 
 _lib = None
 
@@ -348,3 +354,62 @@ class TrainBatch:
         s = self.states[c].cpu().numpy()
         return {"step": int(s[0]), "stop": int(s[1]), "have_avg": int(s[2]),
                 "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[5])}
+
+
+def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt=None):
+    """Sample a whole Bayes tree root -> leaves in one launch.
+
+    entries: list (parents before children) of dicts with keys
+        kparams, mean, std, circular (device tensors), D_model, obs (1-D numpy), sep_cols, front_cols (lists of
+        column indices into the [n, total_dim] sample matrix).
+    -> device tensor [n, total_dim] (float32) of posterior samples."""
+    nc = len(entries)
+    table = (PostClique * nc)()
+    cols, obs = [], []
+    max_D = 1
+    for e, q in zip(entries, table):
+        q.kparams = e["kparams"].data_ptr(); q.mean = e["mean"].data_ptr(); q.std = e["std"].data_ptr()
+        q.circular = e["circular"].data_ptr()
+        q.D_model = int(e["D_model"]); q.n_obs = len(e["obs"]); q.n_sep = len(e["sep_cols"])
+        q.n_frontal = len(e["front_cols"])
+        if q.n_obs + q.n_sep + q.n_frontal > q.D_model:
+            raise ValueError("clique columns exceed its model dimension")
+        q.obs_off = len(obs); obs.extend(float(v) for v in e["obs"])
+        q.sep_off = len(cols); cols.extend(int(v) for v in e["sep_cols"])
+        q.front_off = len(cols); cols.extend(int(v) for v in e["front_cols"])
+        max_D = max(max_D, q.D_model)
+    tbl = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(device)
+    cols_t = torch.tensor(cols if cols else [0], dtype=torch.int32, device=device)
+    obs_t = torch.tensor(obs if obs else [0.0], dtype=torch.float32, device=device)
+    if Zt is None:
+        Zt = torch.randn(total_dim, n, dtype=torch.float32, device=device, generator=generator)
+    Zt = _dev(Zt, "Zt")
+    if tuple(Zt.shape) != (total_dim, n):
+        raise ValueError("Zt must be [total_dim, n] (column-major sample layout)")
+    St = torch.zeros(total_dim, n, dtype=torch.float32, device=device)
+    _check(lib().nfisam_nsf_posterior_walk(C.c_void_p(tbl.data_ptr()), nc, _ptr(cols_t), _ptr(obs_t), max_D, int(K),
+                                           int(H), C.c_float(B), int(L), int(n), _ptr(Zt), _ptr(St), _stream()),
+           "nfisam_nsf_posterior_walk")
+    return St.t().contiguous()
+
+
+POST_DTYPE = np.dtype([("kparams", np.uint64), ("mean", np.uint64), ("std", np.uint64), ("circular", np.uint64),
+                       ("D_model", np.int32), ("n_obs", np.int32), ("n_sep", np.int32), ("n_frontal", np.int32),
+                       ("obs_off", np.int32), ("sep_off", np.int32), ("front_off", np.int32), ("reserved", np.int32)])
+assert POST_DTYPE.itemsize == C.sizeof(PostClique)
+
+
+def posterior_walk_raw(table: np.ndarray, cols: np.ndarray, obs: np.ndarray, total_dim, n, max_D, K, H, B, L, device,
+                       Zt=None):
+    """`posterior_walk` with the clique table already assembled as a numpy array of POST_DTYPE
+    (callers that walk large trees every update cache the per-clique pointers)."""
+    tbl = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+    cols_t = torch.from_numpy(np.ascontiguousarray(cols if cols.size else np.zeros(1), dtype=np.int32)).to(device)
+    obs_t = torch.from_numpy(np.ascontiguousarray(obs if obs.size else np.zeros(1), dtype=np.float32)).to(device)
+    if Zt is None:
+        Zt = torch.randn(total_dim, n, dtype=torch.float32, device=device)
+    St = torch.zeros(total_dim, n, dtype=torch.float32, device=device)
+    _check(lib().nfisam_nsf_posterior_walk(C.c_void_p(tbl.data_ptr()), int(table.shape[0]), _ptr(cols_t), _ptr(obs_t),
+                                           int(max_D), int(K), int(H), C.c_float(B), int(L), int(n), _ptr(Zt), _ptr(St),
+                                           _stream()), "nfisam_nsf_posterior_walk")
+    return St.t().contiguous()

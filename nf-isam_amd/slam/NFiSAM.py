@@ -98,6 +98,19 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
             self._norm_cache = (str(device), mean, std, circ)
         return self._norm_cache[1:]
 
+    def posterior_static(self):
+        """Device pointers and shape constants the tree-walk kernel needs for this clique; computed once
+        after training (parameters of a trained clique model never change) and kept alive by the model."""
+        st = getattr(self, "_post_static", None)
+        if st is None:
+            f0, L, device = self._flow_cfg()
+            kp = self.kernel_params()
+            mean, std, circ = self._norm_dev(device)
+            st = dict(cfg=(f0.K, f0.hidden_dim, f0.B, L), device=device, D_model=f0.dim, keep=(kp, mean, std, circ),
+                      ptrs=(kp.data_ptr(), mean.data_ptr(), std.data_ptr(), circ.data_ptr()))
+            self._post_static = st
+        return st
+
     def _flow_cfg(self):
         f0 = self.flows[0]
         if not self._homogeneous():
@@ -365,6 +378,55 @@ class NFiSAM(FactorGraphSolver):
         stds = np.clip(stds, a_min=1e-5, a_max=None)
         samples = samples / stds
         return torch.Tensor(samples), torch.Tensor(means), torch.Tensor(stds)
+
+    # ---- posterior: the whole tree in one launch ------------------------------
+    def sample_posterior(self, timer: List = None, *args, **kwargs):
+        """Root -> leaves conditional sampling of every clique (reference:
+        FactorGraphSolver.sample_posterior, FactorGraphSolver.py:497-550) as ONE kernel launch: each
+        wave of 64 samples walks all cliques on the device; one D2H copy at the end.  The per-clique
+        device pointers are cached on the model (they do not change after training); only the column
+        indices, which shift as the elimination ordering grows, are rebuilt per update."""
+        start = time.time()
+        num_samples = self._args.posterior_sample_num
+        order = self._elimination_ordering
+        col0, off = {}, 0
+        for v in order:
+            col0[v] = off
+            off += v.dim
+        total_dim = off
+        cliques, stack = [], [self._physical_bayes_tree.root]
+        while stack:
+            c = stack.pop()
+            cliques.append(c)
+            stack.extend(c.children)
+        table = np.zeros(len(cliques), dtype=_nh.POST_DTYPE)
+        cols, obs, cfg, device, max_D = [], [], None, None, 1
+        rmap = self._reverse_ordering_map
+        for j, clique in enumerate(cliques):
+            model = self._clique_density_model[clique]
+            st = model.posterior_static()
+            if cfg is None:
+                cfg, device = st["cfg"], st["device"]
+            elif cfg != st["cfg"]:
+                raise NotImplementedError("the tree walk needs one (K, H, B, L) for all cliques")
+            row = table[j]
+            row["kparams"], row["mean"], row["std"], row["circular"] = st["ptrs"]
+            row["D_model"] = st["D_model"]
+            o = np.asarray(self._clique_true_obs[clique], dtype=np.float64).ravel()
+            sep = [col0[v] + k for v in sorted(clique.separator, key=rmap.__getitem__) for k in range(v.dim)]
+            fro = [col0[v] + k for v in sorted(clique.frontal, key=rmap.__getitem__) for k in range(v.dim)]
+            row["n_obs"], row["n_sep"], row["n_frontal"] = o.size, len(sep), len(fro)
+            row["obs_off"] = len(obs); obs.extend(o.tolist())
+            row["sep_off"] = len(cols); cols.extend(sep)
+            row["front_off"] = len(cols); cols.extend(fro)
+            max_D = max(max_D, st["D_model"])
+        K, H, B, L = cfg
+        S = _nh.posterior_walk_raw(table, np.asarray(cols, dtype=np.int32), np.asarray(obs, dtype=np.float32),
+                                   total_dim, num_samples, max_D, K, H, B, L, device).cpu().numpy()
+        samples = {v: S[:, col0[v]:col0[v] + v.dim] for v in order}
+        if timer is not None:
+            timer.append(time.time() - start)
+        return samples
 
     # ---- model reuse / message construction --------------------------------------------------
     def root_clique_density_model_to_leaf(self, old_clique, new_clique, device=None):

@@ -1,0 +1,57 @@
+"""BASELINE config 5 end to end: Plaza1 range-only dataset (778 poses, 4 landmarks), arguments of
+example/slam/plaza_dataset/run_nfisam.py:5-21 (K=9, n=2000, <=2000 it, lr .01, window 50, tol .01,
+incremental_step=5 -> 156 updates), on the MI355X back end.  Reports wall-clock per incremental update
+with the reference's sub-timers, flow-training samples/s, and trajectory RMSE against the ground truth
+stored in the .fg file.   usage: run_plaza1.py [max_updates] [out.json]"""
+import json, os, sys, tempfile, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
+from slam.NFiSAM import NFiSAM, NFiSAMArgs
+from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+
+max_updates = int(sys.argv[1]) if len(sys.argv) > 1 else 10 ** 9
+out_json = sys.argv[2] if len(sys.argv) > 2 else None
+seed = int(os.environ.get('SEED', '0'))
+np.random.seed(seed); torch.manual_seed(seed)
+nodes, truth, factors = graph_file_parser(os.path.join(ROOT, "tests", "data", "Plaza1EFG", "factor_graph.fg"), "fg")
+steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=5)
+args = NFiSAMArgs(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                  cuda_training=True, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
+                  average_window=50)
+solver = NFiSAM(args)
+rows = []
+t_all = time.time()
+for i, (vs, fs) in enumerate(steps[:max_updates]):
+    for v in vs: solver.add_node(v)
+    for f in fs: solver.add_factor(f)
+    timer = []
+    t0 = time.time()
+    solver.update_physical_and_working_graphs(timer=timer)
+    samples = solver.incremental_inference(timer=timer)
+    dt = time.time() - t0
+    loss = solver._temp_training_loss
+    iters = [int(np.count_nonzero(v)) for v in loss.values()]
+    fit = sum(timer[2:-1:2]) if len(timer) > 2 else 0.0      # [graph, (sample, fit)*, posterior]
+    samp = sum(timer[1:-1:2])
+    poses_ = [v for v in solver.physical_vars if str(v.name).startswith("X")]
+    err_ = np.array([samples[v][:, :2].mean(0) - truth[v][:2] for v in poses_])
+    rmse_ = float(np.sqrt((err_ ** 2).sum(1).mean()))
+    rows.append(dict(update=i, rmse=rmse_, wall=dt, graph=timer[0], sampling=samp, fitting=fit, posterior=timer[-1],
+                     cliques_trained=len(iters), iterations=sum(iters), n_vars=len(solver.physical_vars)))
+    if i % int(os.environ.get('EVERY', '10')) == 0 or i == len(steps) - 1:
+        poses = [v for v in solver.physical_vars if str(v.name).startswith("X")]
+        err = np.array([samples[v][:, :2].mean(0) - truth[v][:2] for v in poses])
+        print("update %3d: %.3f s (graph %.3f, sampling %.3f, fit %.3f [%d cliques, %d it], posterior %.3f) vars %d "
+              "traj RMSE %.2f m" % (i, dt, timer[0], samp, fit, len(iters), sum(iters), timer[-1],
+                                    len(solver.physical_vars), np.sqrt((err ** 2).sum(1).mean())), flush=True)
+total = time.time() - t_all
+w = np.array([r["wall"] for r in rows]); f = np.array([r["fitting"] for r in rows]); it = np.array([r["iterations"] for r in rows])
+summary = dict(updates=len(rows), total_s=total, wall_per_update_mean=float(w.mean()), wall_per_update_median=float(np.median(w)),
+               wall_per_update_max=float(w.max()), fitting_total_s=float(f.sum()), training_sample_iters=float(2000 * it.sum()),
+               flow_training_samples_per_s=float(2000 * it.sum() / max(f.sum(), 1e-9)),
+               sampling_total_s=float(sum(r["sampling"] for r in rows)), posterior_total_s=float(sum(r["posterior"] for r in rows)),
+               graph_total_s=float(sum(r["graph"] for r in rows)))
+print(json.dumps(summary))
+if out_json:
+    json.dump(dict(summary=summary, rows=rows), open(out_json, "w"))

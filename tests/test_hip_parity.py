@@ -264,3 +264,43 @@ def test_argument_errors_are_loud():
         nh.forward(x, kp[:-4], 9, 8, 5.0)
     with pytest.raises(ValueError):
         nh.inverse(x, x, kp, 9, 8, 5.0)       # D would be 6: wrong blob size
+
+
+def test_posterior_tree_walk_equals_per_clique_conditional_sampling():
+    """nfisam_nsf_posterior_walk == a chain of nfisam_nsf_inverse calls with the same latent draws
+    (FactorGraphSolver.sample_posterior semantics, src/slam/FactorGraphSolver.py:497-550)."""
+    K, H, B, n = 9, 8, 5.0, 300
+    for L in (1, 2):
+        rng = np.random.RandomState(10 + L)
+        # sample matrix columns: v0 (3) v1 (2) v2 (3) v3 (1); tree: root {v0,v1} -> child {v2 | v1} -> leaf {v3 | v2, v0[0:2]...}
+        total = 9
+        specs = [dict(n_obs=0, sep=[], front=[0, 1, 2, 3, 4]),                 # root: joint of v0, v1
+                 dict(n_obs=2, sep=[3, 4], front=[5, 6, 7]),                   # obs(2) | v1 -> v2
+                 dict(n_obs=1, sep=[5, 6, 7, 0, 1], front=[8])]                # obs(1) | v2, part of v0 -> v3
+        entries, models = [], []
+        for sp in specs:
+            D = sp["n_obs"] + len(sp["sep"]) + len(sp["front"]) + (1 if sp is specs[1] else 0)   # one model is larger than used
+            blob, _ = make_problem(8, D, K, H, L, seed=int(rng.randint(1000)))
+            kp = kpack(blob, D, K, H, L)
+            mean = dev(rng.randn(D) * 2); std = dev(0.5 + rng.rand(D))
+            circ_np = (rng.rand(D) < 0.3)
+            circ = torch.from_numpy(circ_np.astype(np.uint8)).to(DEV)
+            obs = rng.randn(sp["n_obs"])
+            entries.append(dict(kparams=kp, mean=mean, std=std, circular=circ, D_model=D, obs=obs, sep_cols=sp["sep"],
+                                front_cols=sp["front"]))
+            models.append((kp, mean, std, circ, D, obs))
+        Zt = torch.randn(total, n, device=DEV)
+        S = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
+        assert S.shape == (n, total)
+        ref = torch.zeros(n, total, device=DEV)
+        for sp, (kp, mean, std, circ, D, obs) in zip(specs, models):
+            given = []
+            if sp["n_obs"]:
+                given.append(dev(np.tile(obs, (n, 1))))
+            if sp["sep"]:
+                given.append(ref[:, sp["sep"]])
+            xs = torch.cat(given, 1).contiguous() if given else None
+            z = Zt[sp["front"], :].t().contiguous()
+            out = nh.inverse(z, xs, kp, K, H, B, L, mean=mean, std=std, circular=circ, model_D=D)
+            ref[:, sp["front"]] = out
+        np.testing.assert_allclose(S.cpu().numpy(), ref.cpu().numpy(), atol=2e-5)

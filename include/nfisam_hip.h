@@ -148,9 +148,11 @@ typedef struct nfisam_train_state {
     int32_t stop;        /* set by the device when the early-stop rule fired                 */
     int32_t have_avg;    /* a previous window mean exists                                    */
     float   loss_avg;    /* previous window mean (NFiSAM.py:481-491)                         */
-    float   loss_acc;    /* running sum_p(0.5|z|^2 - logdet) of the iteration in flight      */
+    float   loss_acc;    /* (unused, kept for layout)                                         */
     int32_t domain_err;  /* non-zero if a kernel saw a non-finite loss                       */
     int32_t reserved[10];
+    float   loss_slots[64]; /* running sum_p(0.5|z|^2 - logdet) of the iteration in flight, spread over
+                               64 words so that hundreds of waves do not serialise on one address   */
 } nfisam_train_state;
 
 typedef struct nfisam_adam_cfg {
@@ -167,11 +169,17 @@ typedef struct nfisam_clique {
     float* kparams;              /* [L*kparam_count]                                          */
     float* adam_m;               /* [L*kparam_count] zero-initialised                         */
     float* adam_v;               /* [L*kparam_count] zero-initialised                         */
-    float* kgrad;                /* [L*kparam_count] workspace, zero-initialised              */
+    float* kgrad;                /* [nfisam_nsf_grad_workspace_count(max n of the batch, D,..)] workspace, zero-initialised */
     float* iter_loss;            /* [max_iters] zero-initialised; per-iteration loss (NFiSAM.py:473) */
     nfisam_train_state* state;   /* zero-initialised                                          */
     int32_t n, D;
 } nfisam_clique;
+
+/* Floats the `kgrad` workspace of a clique must hold when the largest clique of its batch has n
+ * particles: small launches (<= 64 tiles) write per-tile partial gradients with plain stores and the
+ * Adam kernel sums them in tile order (no atomics, bitwise-reproducible); larger ones accumulate
+ * with float atomics into a single copy.                                                      */
+size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
 /* One full-batch training iteration of `n_cliques` independent cliques (grid.y = clique):
  * forward + analytic backward + gradient reduction, then a fused Adam update that also records

@@ -58,11 +58,18 @@ __device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
     return r;
 }
 
-__device__ __forceinline__ void atomicAdd4(float* dst, const __attribute__((ext_vector_type(4))) float& v) {
-    atomicAdd(dst + 0, v.x);
-    atomicAdd(dst + 1, v.y);
-    atomicAdd(dst + 2, v.z);
-    atomicAdd(dst + 3, v.w);
+// Gradient sink.  slab = false: accumulate into one shared buffer with float atomics (any number of
+// tiles).  slab = true: this tile owns a private copy of the gradient buffer and every entry is written
+// exactly once per iteration with a plain store; the Adam kernel sums the tiles in a fixed order
+// (no memory-side atomic tail on small launches, bitwise-reproducible training).
+__device__ __forceinline__ void gsink(float* dst, float v, bool slab) {
+    if (slab) *dst = v; else atomicAdd(dst, v);
+}
+__device__ __forceinline__ void gsink4(float* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
+    gsink(dst + 0, v.x, slab);
+    gsink(dst + 1, v.y, slab);
+    gsink(dst + 2, v.z, slab);
+    gsink(dst + 3, v.w, slab);
 }
 
 // =============================================================================================
@@ -80,6 +87,8 @@ struct TrainArgs {
     int max_iters;
     int nll_mode;
     int layer_stride;               // floats between layers in kparams/kgrad (0: kparam_count(D))
+    int wl_floats;                  // LDS floats reserved for the parameter copy (WL variants)
+    int slab;                       // 1: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
 };
 
 template <int K, int H, typename WP>
@@ -111,14 +120,26 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // ---- diagnostic build only (-DNSF_STAMPS): per-wave s_memtime stamps at phase boundaries ---------
 #ifdef NSF_STAMPS
 __device__ unsigned long long g_stamps[64 * 32];
+__device__ unsigned long long g_blk[4096 * 2];
+__device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
 #define STAMP(id)                                                                                   \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         unsigned long long t_;                                                                      \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) g_stamps[w * 32 + (id)] = t_;             \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) g_stamps[((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32 + (id)] = t_;   \
+        if (((id) == 0 || (id) == 9) && lane == 0 && w == 0) {                                                     \
+            const unsigned bid_ = blockIdx.x + gridDim.x * (blockIdx.z + gridDim.z * blockIdx.y);                   \
+            if (bid_ < 4096) g_blk[bid_ * 2 + ((id) == 9)] = __builtin_amdgcn_s_memrealtime();                       \
+        }             \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
+extern "C" int nfisam_debug_read_blocks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 4096 * 2);
+}
+extern "C" int nfisam_debug_write_stamps(const unsigned long long* in) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), in, sizeof(unsigned long long) * 64 * 32);
+}
 extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 32);
 }
@@ -169,6 +190,8 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int D = batched ? cp->D : a.single.D;
     const int L = a.L;
     const float B = a.B;
+    const bool slab = a.slab != 0;
+    if (slab) G += (size_t)blockIdx.x * (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
 
     const int p0 = blockIdx.x * TILE;
     if (p0 >= n) return;
@@ -189,30 +212,72 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     STAMP(0);
 
     const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
-    float* wlds = smem;               // [L*Pk] parameter copy (WL only), 16-byte aligned rows
-    float* xs = smem + (WL ? L * Pk : 0);   // [L][D][XS] layer inputs, dimension-major
+    // parameter range this block needs: everything, or (L == 1, grouped) only its own dims' blocks
+    const int dim_hi = (gridDim.z > 1) ? ((dim_lo + W < D) ? dim_lo + W : D) : D;
+    const int w_lo = (gridDim.z > 1 && dim_lo > 0) ? LY::off(dim_lo) : 0;
+    const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
+    float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only), 16-byte aligned rows
+    float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS] layer inputs, dimension-major
     float* g0 = xs + L * DT;          // [D][XS]
     float* g1 = g0 + DT;              // [D][XS]
     float* ones = g1 + DT;            // [XS] constant 1 (bias column of the gradient GEMMs)
     float* stg = ones + XS + w * (StgRows<K, H>::value * XS);   // wave-private staging tile (MF only)
 
-    // ---- coalesced load of the particle tile, transposed into LDS -------------------------
-    for (int e = threadIdx.x; e < D * TILE; e += blockDim.x) {
-        const int p = e / D, k = e - p * D;
-        const int q = p0 + p;
-        xs[k * XS + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
+    // ---- prologue: ALL global loads first (particle tile + parameter rows), one wait, then LDS ----
+    // The tile is 64*D contiguous floats; element e belongs to particle e / D, column e % D (the
+    // quotient by a reciprocal multiply: exact for e < 2^20).  Rows beyond n read as 0.
+    {
+        constexpr int XB = 16, WB = 4;               // loads in flight per lane: dwords of x, float4 of weights
+        const int nx = D * TILE;
+        const int lim = ((n - p0) < TILE ? (n - p0) : TILE) * D;      // floats of this tile that exist
+        const float* xt = x + (size_t)p0 * D;
+        const float invD = 1.0f / (float)D;
+        const int tot4 = WL ? ((w_hi - w_lo) >> 2) : 0;               // block offsets are multiples of 4 floats
+        const f32x4* wsrc = (const f32x4*)(kparams + w_lo);
+        f32x4* wdst = (f32x4*)wlds;
+        int e0 = threadIdx.x, f0 = threadIdx.x;
+        while (e0 < nx || f0 < tot4) {
+            float xv[XB];
+            f32x4 wv[WB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                xv[u] = (e < lim) ? xt[e] : 0.0f;
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nx) {
+                    int pq = (int)(((float)e + 0.5f) * invD);
+                    int k = e - pq * D;
+                    if (k < 0) { k += D; pq -= 1; }
+                    if (k >= D) { k -= D; pq += 1; }
+                    xs[k * XS + pq] = xv[u];
+                }
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    if (f < tot4) wdst[f] = wv[u];
+                }
+            }
+            e0 += XB * (int)blockDim.x;
+            f0 += WB * (int)blockDim.x;
+        }
     }
     if (threadIdx.x < XS) ones[threadIdx.x] = 1.0f;
-    if constexpr (WL) {   // stage ALL parameters once per block: wide coalesced loads, one exposed latency
-        const int tot4 = (L * Pk) >> 2;     // Pk is a multiple of 4 by construction of the layout
-        const f32x4* src = (const f32x4*)kparams;
-        f32x4* dst = (f32x4*)wlds;
-        for (int e = threadIdx.x; e < tot4; e += blockDim.x) dst[e] = src[e];
-    }
     __syncthreads();
 
     WP kp;
-    if constexpr (WL) kp = wlds; else kp = (cfloat*)kparams;
+    if constexpr (WL) kp = wlds - w_lo; else kp = (cfloat*)kparams;
     STAMP(1);
 
     // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
@@ -275,7 +340,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
 #pragma unroll
                 for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
                 const float r = butterfly<N0>(v, lane);
-                if (lane < PoP) atomicAdd(&Gl[lane], r);
+                if (lane < PoP) gsink(&Gl[lane], r, slab);
                 continue;
             }
             WP blk = lp + LY::off(i);
@@ -354,7 +419,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
 #pragma unroll
                     for (int c = 0; c < (TOT + 63) / 64; ++c) {
                         const int f = c * 64 + lane;
-                        if (f < TOT) atomicAdd(&Gw[f], stg[f]);
+                        if (f < TOT) gsink(&Gw[f], stg[f], slab);
                     }
                     wave_lds_sync();
                 }
@@ -388,11 +453,11 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
 #pragma unroll
                         for (int s4 = 0; s4 < TILE; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
                         // rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = cab*H + j
-                        if (kq >= 2 && cab <= i) atomicAdd4(&Gw0[cab * H + 4 * (kq - 2)], c0);
+                        if (kq >= 2 && cab <= i) gsink4(&Gw0[cab * H + 4 * (kq - 2)], c0, slab);
                     }
                     (void)tot0;
                     // rows 0..7 (kq < 2) are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
-                    if (kq < 2 && r16 <= H) atomicAdd4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1);
+                    if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
                     wave_lds_sync();
                 }
                 STAMP(8);
@@ -411,7 +476,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                             v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
                         }
                         const float r = butterfly<64>(v, lane);
-                        if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                        if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
                     }
                 }
                 {
@@ -427,7 +492,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                             v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
                         }
                         const float r = butterfly<64>(v, lane);
-                        if (c * 64 + lane < TOT) atomicAdd(&Gw[c * 64 + lane], r);
+                        if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
                     }
                 }
                 {
@@ -444,7 +509,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                             for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
                         }
                         const float r = butterfly<64>(v, lane);
-                        if (kc * H + lane < tot) atomicAdd(&Gw[kc * H + lane], r);
+                        if (kc * H + lane < tot) gsink(&Gw[kc * H + lane], r, slab);
                     }
                 }
             }
@@ -464,7 +529,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     if (a.nll_mode) {
         const float tot = wave_sum(lossv);
         if (lane == 0) {
-            float* dst = (st != nullptr) ? &st->loss_acc : a.loss_sum;
+            float* dst = (st != nullptr) ? &st->loss_slots[(blockIdx.x * 7 + blockIdx.z * 13 + w) & 63] : a.loss_sum;
             if (dst != nullptr) atomicAdd(dst, tot);
         }
     }
@@ -478,6 +543,7 @@ struct AdamArgs {
     const nfisam_clique* cliques;
     nfisam_clique single;
     nfisam_adam_cfg cfg;
+    int slab;               // gradient arrives as per-tile slabs (summed here in tile order)
     float log_b1, log_b2;   // ln(beta), computed on the host in double
     int L, K, H;
 };
@@ -516,15 +582,35 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const float step_size = a.cfg.lr / bc1;
     const float inv_bc2s = 1.0f / sqrtf(bc2);
     const float inv_n = 1.0f / (float)n;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
-        const float g = G[j] * inv_n;
-        const float mj = b1 * m[j] + (1.0f - b1) * g;
-        const float vj = b2 * v[j] + (1.0f - b2) * g * g;
-        m[j] = mj;
-        v[j] = vj;
-        const float denom = sqrtf(vj) * inv_bc2s + a.cfg.eps;
-        theta[j] -= step_size * mj / denom;
-        G[j] = 0.0f;
+    // 256 threads = 32 parameters x 8 tile-lanes: with per-tile gradient slabs every tile-lane sums the
+    // tiles tt = tl, tl+8, ... of its parameter (independent loads, issued together), the 8 partial sums
+    // are combined through LDS in a fixed order (bitwise-reproducible), lane 0 applies Adam.
+    __shared__ float s_part[8][33];
+    const int n_tiles = a.slab ? (n + TILE - 1) / TILE : 1;
+    const int pj = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    for (int j0 = blockIdx.x * 32; j0 < P; j0 += gridDim.x * 32) {
+        const int j = j0 + pj;
+        float part = 0.0f;
+        if (j < P) {
+#pragma unroll 8
+            for (int tt = tl; tt < n_tiles; tt += 8) part += G[(size_t)tt * P + j];
+        }
+        s_part[tl][pj] = part;
+        __syncthreads();
+        if (tl == 0 && j < P) {
+            float gs = s_part[0][pj];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) gs += s_part[q][pj];
+            const float g = gs * inv_n;
+            const float mj = b1 * m[j] + (1.0f - b1) * g;
+            const float vj = b2 * v[j] + (1.0f - b2) * g * g;
+            m[j] = mj;
+            v[j] = vj;
+            const float denom = sqrtf(vj) * inv_bc2s + a.cfg.eps;
+            theta[j] -= step_size * mj / denom;
+            if (!a.slab) G[j] = 0.0f;
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -532,13 +618,19 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         s_last = (ticket == (int)gridDim.x - 1);
     }
     __syncthreads();
-    if (s_last && threadIdx.x == 0) {
+    if (!s_last) return;
+    // last block: per-iteration bookkeeping.  The 64 loss slots (written by the previous kernel's
+    // atomics) are read one per lane at agent scope and reduced across the wave.
+    float acc = 0.0f;
+    if (threadIdx.x < 64) {
+        acc = __hip_atomic_load(&st->loss_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st->loss_slots[threadIdx.x] = 0.0f;
+        acc = wave_sum(acc);
+    }
+    if (threadIdx.x == 0) {
         st->reserved[0] = 0;
-        // loss_acc was written by the previous kernel's atomics: read it at agent scope
-        const float acc = __hip_atomic_load(&st->loss_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float loss = acc * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
         iter_loss[t - 1] = loss;
-        st->loss_acc = 0.0f;
         int stop = 0;
         if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; stop = 1; }
         const int wnd = a.cfg.average_window;
@@ -984,29 +1076,42 @@ static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, in
     return NFISAM_OK;
 }
 
-static int launch_train(const TrainArgs& a, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
-    const int W = pick_waves(max_D);
+static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
+    TrainArgs a = a_in;
     const bool mf = use_mfma_grad();
-    // L == 1 and no dL/dx requested: dims are independent -> spread them over grid.z
-    // (only when the launch is small: with thousands of waves in flight the extra blocks just re-load tiles)
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
-    const int groups = (a.L == 1 && a.gx == nullptr && tiles * W <= 2048) ? (max_D + W - 1) / W : 1;
+    // L == 1 and no dL/dx requested: the dims of a tile never exchange data.  When the launch is small
+    // (latency-bound) every (tile, dim) unit becomes its own single-wave block, so that every wave has
+    // a SIMD to itself; with thousands of waves in flight tiles keep their dims together instead.
+    const bool independent_dims = (a.L == 1 && a.gx == nullptr);
+    int W = pick_waves(max_D), groups = 1;
+    if (independent_dims && tiles * max_D <= 1024) { W = 1; groups = max_D; }
+    else if (independent_dims && tiles * W <= 2048) groups = (max_D + W - 1) / W;
     NSF_DISPATCH(K, H, {
-        const size_t base = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS *
-                            sizeof(float);
+        const size_t tile_floats = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
         const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
-        const size_t wbytes = (size_t)a.L * stride * sizeof(float);
+        // parameter floats one block must hold: all layers, or its own dims' blocks when grouped
+        size_t wfloats = (size_t)a.L * stride;
+        if (groups > 1) {
+            const int lo = ((max_D - 1) / W) * W;            // the last group holds the largest blocks
+            wfloats = (size_t)Layout<KK, HH>::off(max_D) - (lo > 0 ? (size_t)Layout<KK, HH>::off(lo) : 0);
+            if (W >= max_D) wfloats = (size_t)Layout<KK, HH>::off(max_D);
+            const size_t first = (size_t)Layout<KK, HH>::off(W < max_D ? W : max_D);
+            if (first > wfloats) wfloats = first;
+        }
         // LDS copy of the parameters: pays when few waves share a SIMD (nothing hides a cold scalar-cache
         // miss per weight row); it must fit next to the tiles.  Large batches keep the scalar path.
         const int wm = weights_mode();
-        const long blocks = (long)((max_n + TILE - 1) / TILE) * n_cliques * groups;
-        const bool fits = base + wbytes <= 150 * 1024;
+        const long blocks = tiles * groups;
+        const bool fits = (tile_floats + wfloats) * sizeof(float) <= 150 * 1024;
         const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096));
+        a.wl_floats = wl ? (int)wfloats : 0;
+        const size_t lds = (tile_floats + (wl ? wfloats : 0)) * sizeof(float);
         int rc;
-        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, groups, base + wbytes, s);
-        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, groups, base, s);
-        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, groups, base + wbytes, s);
-        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, groups, base, s);
+        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, groups, lds, s);
+        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, groups, lds, s);
+        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, groups, lds, s);
+        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, groups, lds, s);
         if (rc) return rc;
     });
     HIP_TRY(hipGetLastError());
@@ -1033,10 +1138,22 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
     return launch_train(a, 1, n, D, K, H, (hipStream_t)stream);
 }
 
+// Small launches use per-tile gradient slabs (kgrad must then hold n_tiles copies, see
+// nfisam_nsf_grad_workspace_count); large ones accumulate with atomics into a single copy.
+static const int kSlabMaxTiles = 64;
+static bool use_slabs(int max_n) { return (max_n + TILE - 1) / TILE <= kSlabMaxTiles; }
+
+extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L) {
+    if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
+    const size_t tiles = use_slabs(n) ? (size_t)((n + TILE - 1) / TILE) : 1;
+    return tiles * (size_t)L * kcount(D, K, H);
+}
+
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, hipStream_t s) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
+    a.slab = use_slabs(max_n) ? 1 : 0;
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = cfg->max_iters; a.nll_mode = 1;
@@ -1047,14 +1164,15 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
     ad.cfg = *cfg;
+    ad.slab = a.slab;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H;
-    // enough blocks to cover the parameters with ~4 per thread, capped (the work is tiny)
+    // 32 parameters per block (x 8 tile-lanes); a few hundred small blocks spread the latency-bound work
     const size_t Pmax = (size_t)L * kcount(max_D, K, H);
-    int ablocks = (int)((Pmax + 1023) / 1024);
+    int ablocks = (int)((Pmax + 31) / 32);
     if (ablocks < 1) ablocks = 1;
-    if (ablocks > 32) ablocks = 32;
+    if (ablocks > 256) ablocks = 256;
     hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

@@ -22,7 +22,7 @@ EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
-    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk",
+    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count",
 ]
 
 
@@ -32,7 +32,8 @@ class HipLibraryMissing(ImportError):
 
 class TrainState(C.Structure):
     _fields_ = [("step", C.c_int32), ("stop", C.c_int32), ("have_avg", C.c_int32), ("loss_avg", C.c_float),
-                ("loss_acc", C.c_float), ("domain_err", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("loss_acc", C.c_float), ("domain_err", C.c_int32), ("reserved", C.c_int32 * 10),
+                ("loss_slots", C.c_float * 64)]
 
 
 class AdamCfg(C.Structure):
@@ -53,7 +54,7 @@ class PostClique(C.Structure):
                 ("obs_off", C.c_int32), ("sep_off", C.c_int32), ("front_off", C.c_int32), ("reserved", C.c_int32)]
 
 
-assert C.sizeof(TrainState) == 64 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64 and C.sizeof(PostClique) == 64
+assert C.sizeof(TrainState) == 320 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64 and C.sizeof(PostClique) == 64
 
 _lib = None
 
@@ -77,6 +78,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.nfisam_nsf_param_count.restype = C.c_size_t
         _lib.nfisam_nsf_kparam_count.restype = C.c_size_t
+        _lib.nfisam_nsf_grad_workspace_count.restype = C.c_size_t
         for name in EXPORTS:
             getattr(_lib, name)   # raises AttributeError if the ABI is incomplete
     return _lib
@@ -278,9 +280,11 @@ class TrainBatch:
                 raise ValueError("kparams size does not match (D,K,H,L)")
         self.m = [torch.zeros_like(p) for p in self.kparams]
         self.v = [torch.zeros_like(p) for p in self.kparams]
-        self.g = [torch.zeros_like(p) for p in self.kparams]
+        self.max_n = max(x.shape[0] for x in xs)
+        self.g = [torch.zeros(int(lib().nfisam_nsf_grad_workspace_count(self.max_n, x.shape[1], int(K), int(H), int(L))),
+                              dtype=torch.float32, device=self.device) for x in self.xs]
         self.iter_loss = [torch.zeros(max(int(max_iters), 1), dtype=torch.float32, device=self.device) for _ in xs]
-        self.states = torch.zeros(len(xs), 16, dtype=torch.int32, device=self.device)
+        self.states = torch.zeros(len(xs), C.sizeof(TrainState) // 4, dtype=torch.int32, device=self.device)
         self.cfg = AdamCfg(lr, beta1, beta2, eps, int(max_iters), int(average_window) if early_stop else 0,
                            loss_delta_tol, 0)
         self.nc = len(xs)
@@ -292,7 +296,7 @@ class TrainBatch:
             d.x = self.xs[c].data_ptr(); d.kparams = self.kparams[c].data_ptr()
             d.adam_m = self.m[c].data_ptr(); d.adam_v = self.v[c].data_ptr(); d.kgrad = self.g[c].data_ptr()
             d.iter_loss = self.iter_loss[c].data_ptr()
-            d.state = self.states.data_ptr() + 64 * c
+            d.state = self.states.data_ptr() + C.sizeof(TrainState) * c
             d.n, d.D = self.xs[c].shape
         raw = np.frombuffer(bytes(self.host_desc), dtype=np.uint8).copy()
         self.dev_desc = torch.from_numpy(raw).to(self.device)

@@ -14,15 +14,38 @@ kp = nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, 0)).to(dev), D, K, H, 
 for _ in range(3):
     nh.backward(x, kp, K, H, B, L, nll_mode=True)
 torch.cuda.synchronize()
+init = (C.c_ulonglong * (64 * 32))()
+init[63 * 32 + 20] = 2 ** 63
+import ctypes
+lib = nh.lib()
+sym = ctypes.c_void_p.in_dll(lib, "g_stamps") if False else None
+# reset min/max slots through a tiny torch kernel is not possible for a __device__ symbol: run once more after zeroing via hipMemcpyToSymbol
+lib.nfisam_debug_write_stamps(init)
+nh.backward(x, kp, K, H, B, L, nll_mode=True)
+torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 32))()
 assert nh.lib().nfisam_debug_read_stamps(buf) == 0
 st = np.array(buf[:]).reshape(64, 32)
 names = ["start", "x+w loaded", "unit start", "theta(MLP fwd)", "spline fwd", "spline bwd", "MLP bwd (VALU)", "phase A (W2 mfma+flush)",
          "phase B (W1,W0 mfma+flush)", "end of layers"]
-W = min(D, 8)
-for w in range(W):
+for w in range(D):
     t = st[w]
     print("wave %d (dim %d):" % (w, w), " ".join("%s=%d" % (names[i].split()[0], t[i] - t[0]) for i in range(10) if t[i] > 0))
     if w > 0:
         seg = [(names[i], int(t[i] - t[i - 1])) for i in range(3, 9)]
         print("    last-unit segments (cycles):", seg, " total kernel:", int(t[9] - t[0]))
+
+
+blk = (C.c_ulonglong * (4096 * 2))()
+assert nh.lib().nfisam_debug_read_blocks(blk) == 0
+bt = np.array(blk[:], dtype=np.int64).reshape(4096, 2)
+nb = ((n + 63) // 64) * (D if L == 1 else 1)
+bt = bt[:nb]
+t0 = bt[:, 0].min()
+start = (bt[:, 0] - t0) / 100.0
+dur = (bt[:, 1] - bt[:, 0]) / 100.0
+end = (bt[:, 1] - t0) / 100.0
+print("blocks %d: start offset us min/med/max %.2f %.2f %.2f | duration us min/med/max %.2f %.2f %.2f | last end %.2f" % (
+    nb, start.min(), np.median(start), start.max(), dur.min(), np.median(dur), dur.max(), end.max()))
+order = np.argsort(end)[-5:]
+print("  slowest-ending blocks (id, start, dur):", [(int(i), round(float(start[i]), 2), round(float(dur[i]), 2)) for i in order])

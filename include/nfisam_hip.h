@@ -181,6 +181,14 @@ typedef struct nfisam_clique {
  * with float atomics into a single copy.                                                      */
 size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
+/* The gradient half of a training iteration on its own (forward + analytic backward + reduction into
+ * each clique's `kgrad` workspace and loss slots, exactly the kernel `nfisam_nsf_train_step` launches
+ * first; no Adam update, no bookkeeping, state->stop / step are still honoured).  With <= 64 tiles the
+ * workspace is overwritten (per-tile slabs), so repeated calls are idempotent: bench.py times this
+ * entry to price the dominant kernel; callers with their own optimiser use it as the gradient oracle. */
+int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                              int max_D, int K, int H, float B, int L, nfisam_stream_t stream);
+
 /* One full-batch training iteration of `n_cliques` independent cliques (grid.y = clique):
  * forward + analytic backward + gradient reduction, then a fused Adam update that also records
  * iter_loss[step], evaluates the reference's window early-stop rule on the device and advances

@@ -1149,22 +1149,27 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     return tiles * (size_t)L * kcount(D, K, H);
 }
 
-static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                        int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, hipStream_t s) {
+static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                        int max_D, int K, int H, float B, int L, int max_iters, hipStream_t s) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.slab = use_slabs(max_n) ? 1 : 0;
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
-    a.B = B; a.L = L; a.max_iters = cfg->max_iters; a.nll_mode = 1;
-    int rc = launch_train(a, n_cliques, max_n, max_D, K, H, s);
+    a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1;
+    return launch_train(a, n_cliques, max_n, max_D, K, H, s);
+}
+
+static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                        int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, hipStream_t s) {
+    int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, s);
     if (rc) return rc;
     AdamArgs ad;
     memset(&ad, 0, sizeof(ad));
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
     ad.cfg = *cfg;
-    ad.slab = a.slab;
+    ad.slab = use_slabs(max_n) ? 1 : 0;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H;
@@ -1184,6 +1189,18 @@ static int check_cfg(const nfisam_adam_cfg* cfg, int K, int H, int L, float B) {
         cfg->max_iters < 0)
         return NFISAM_ERR_ARG;
     return NFISAM_OK;
+}
+
+extern "C" int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                                         int max_D, int K, int H, float B, int L, nfisam_stream_t stream) {
+    if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
+        !nfisam_nsf_supported(K, H))
+        return NFISAM_ERR_ARG;
+    if (cliques_on_host) {
+        if (n_cliques != 1) return NFISAM_ERR_ARG;
+        return enqueue_grad(nullptr, cliques, 1, max_n, max_D, K, H, B, L, 0x7fffffff, (hipStream_t)stream);
+    }
+    return enqueue_grad(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, 0x7fffffff, (hipStream_t)stream);
 }
 
 extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,

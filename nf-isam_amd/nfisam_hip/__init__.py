@@ -22,7 +22,7 @@ EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
-    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count",
+    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient",
 ]
 
 
@@ -310,6 +310,16 @@ class TrainBatch:
             rc = lib().nfisam_nsf_train_step(C.c_void_p(self.dev_desc.data_ptr()), self.nc, 0, self.max_n, self.max_D,
                                              self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg), _stream())
         _check(rc, "nfisam_nsf_train_step")
+
+    def gradient_only(self):
+        """Enqueue only the gradient kernel of an iteration (no Adam, no bookkeeping)."""
+        if self.nc == 1:
+            rc = lib().nfisam_nsf_train_gradient(C.byref(self.host_desc[0]), 1, 1, self.max_n, self.max_D, self.K,
+                                                 self.H, C.c_float(self.B), self.L, _stream())
+        else:
+            rc = lib().nfisam_nsf_train_gradient(C.c_void_p(self.dev_desc.data_ptr()), self.nc, 0, self.max_n,
+                                                 self.max_D, self.K, self.H, C.c_float(self.B), self.L, _stream())
+        _check(rc, "nfisam_nsf_train_gradient")
 
     def prepare(self, use_graph=True):
         """Validate descriptors and (optionally) capture + instantiate the hipGraph of one chunk of

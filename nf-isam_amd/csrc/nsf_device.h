@@ -104,11 +104,21 @@ __device__ __forceinline__ void cond_hidden(WP blk, int i, const float* xs, int 
     float a[H], wr[H];
     load_row<H>(blk + LY::ob0(i), a);
     WP W0 = blk;
-    for (int k = 0; k < i; ++k) {
-        const float xk = xs[k * xstride + lane];
-        load_row<H>(W0 + k * H, wr);
+    // input layer: the only loop whose trip count depends on the dim.  Four (x_k, weight row) pairs are
+    // fetched together so that their LDS / scalar-cache latencies overlap; rows k >= i are still inside
+    // this dim's block (they alias b0 / W1) and are multiplied by 0.
+    for (int k = 0; k < i; k += 4) {
+        float xk[4], wq[4][H];
 #pragma unroll
-        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], xk, a[j]);
+        for (int u = 0; u < 4; ++u) {
+            xk[u] = (k + u < i) ? xs[(k + u) * xstride + lane] : 0.0f;
+            load_row<H>(W0 + (k + u) * H, wq[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wq[u][j], xk[u], a[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h1[j] = ftanh(a[j]);

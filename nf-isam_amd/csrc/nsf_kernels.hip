@@ -122,16 +122,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ unsigned long long g_stamps[64 * 32];
 __device__ unsigned long long g_blk[4096 * 2];
 __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
+#define STAMP_DECL unsigned long long sacc_[16] = {0ull}; unsigned long long sprev_ = 0ull;
 #define STAMP(id)                                                                                   \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         unsigned long long t_;                                                                      \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) g_stamps[((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32 + (id)] = t_;   \
+        if (sprev_ != 0ull) sacc_[(id) & 15] += t_ - sprev_;                                        \
+        sprev_ = t_;                                                                                \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) {                         \
+            const int sw_ = ((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32;                      \
+            g_stamps[sw_ + (id)] = t_;                                                              \
+            g_stamps[sw_ + 16 + ((id) & 15)] = sacc_[(id) & 15];                                    \
+        }                                                                                           \
         if (((id) == 0 || (id) == 9) && lane == 0 && w == 0) {                                                     \
             const unsigned bid_ = blockIdx.x + gridDim.x * (blockIdx.z + gridDim.z * blockIdx.y);                   \
             if (bid_ < 4096) g_blk[bid_ * 2 + ((id) == 9)] = __builtin_amdgcn_s_memrealtime();                       \
-        }             \
+        }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
 extern "C" int nfisam_debug_read_blocks(unsigned long long* out) {
@@ -145,6 +152,7 @@ extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
 }
 #else
 #define STAMP(id) do { } while (0)
+#define STAMP_DECL
 #endif
 
 constexpr int XS = 66;            // LDS row stride (floats) of every [feature][particle] tile
@@ -209,6 +217,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int gp = p0 + lane;
     const bool valid = gp < n;
     const int DT = D * XS;
+    STAMP_DECL
     STAMP(0);
 
     const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
@@ -293,7 +302,9 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
             spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
             xout[i * XS + lane] = z;
         }
+        STAMP(10);
         __syncthreads();
+        STAMP(11);
     }
 
     // ---- backward with recompute, last layer first ------------------------------------------
@@ -372,13 +383,19 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                 }
                 if (need_gx) {
                     WP W0 = blk;
-                    for (int k = 0; k < i; ++k) {
-                        float wr[H];
-                        load_row<H>(W0 + k * H, wr);
-                        float acc = 0.0f;
+                    for (int k = 0; k < i; k += 4) {       // 4 rows in flight (rows >= i alias later weights: unused)
+                        float wq[4][H], acc[4];
 #pragma unroll
-                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga1[j], acc);
-                        atomicAdd(&gprev[k * XS + lane], acc);
+                        for (int u = 0; u < 4; ++u) load_row<H>(W0 + (k + u) * H, wq[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[u] = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < H; ++j) acc[u] = __builtin_fmaf(wq[u][j], ga1[j], acc[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (k + u < i) atomicAdd(&gprev[(k + u) * XS + lane], acc[u]);
                     }
                 }
             }
@@ -514,7 +531,9 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                 }
             }
         }
+        STAMP(12);
         __syncthreads();
+        STAMP(13);
         float* tmp = gcur; gcur = gprev; gprev = tmp;
     }
 

@@ -36,6 +36,13 @@ for w in range(D):
         print("    last-unit segments (cycles):", seg, " total kernel:", int(t[9] - t[0]))
 
 
+acc_names = {1: "prologue", 2: "loop/zero+sync(bwd)", 3: "theta (MLP fwd)", 4: "spline fwd*", 5: "spline fwd+bwd", 6: "MLP bwd", 7: "phase A",
+             8: "phase B", 9: "tail", 10: "fwd-only units", 11: "barrier wait (fwd)", 12: "after last unit (bwd)", 13: "barrier wait (bwd)"}
+print("accumulated cycles per phase over the whole kernel (block 0):")
+for w in range(min(D, 8) if L > 1 else D):
+    a = st[w][16:32]
+    tot = int(st[w][9] - st[w][0]) if st[w][9] > 0 else 0
+    print("  wave %d total %6d: " % (w, tot) + ", ".join("%s=%d" % (acc_names[i], int(a[i])) for i in sorted(acc_names) if a[i] > 0))
 blk = (C.c_ulonglong * (4096 * 2))()
 assert nh.lib().nfisam_debug_read_blocks(blk) == 0
 bt = np.array(blk[:], dtype=np.int64).reshape(4096, 2)

@@ -7,6 +7,7 @@ dispatch (`PriorFactor`, `BinaryFactor`, ...), `.fg` text (de)serialisation, and
     UnarySE2ApproximateGaussianPriorFactor   (reference :682-849)
     SE2RelativeGaussianLikelihoodFactor       (reference :1095-1478)
     SE2R2RangeGaussianLikelihoodFactor        (reference :2510-2751)
+    AmbiguousDataAssociationFactor            (reference :3043-3298; k-way mixture over candidate landmarks)
 The reference draws noise with TransportMaps' `GaussianDistribution.rvs` and then loops over
 samples building `SE2Pose` objects; here the noise comes from numpy's global RNG (seeded by the
 example scripts exactly like the reference's) and the pose algebra is vectorised
@@ -86,15 +87,17 @@ class ImplicitPriorFactor(PriorFactor):
 
 
 class KWayFactor(Factor):
-    pass
+    @property
+    def root_var(self) -> Variable:
+        raise NotImplementedError
 
-
-class AmbiguousDataAssociationFactor(KWayFactor):
-    """Placeholder for dispatch (k-way ambiguous association, reference :3192-3298): next row f-2."""
+    @property
+    def child_vars(self) -> List[Variable]:
+        raise NotImplementedError
 
 
 class BinaryFactorWithNullHypo(BinaryFactor):
-    """Placeholder for dispatch (reference :3300-3462): next row f-2."""
+    """Placeholder for dispatch (reference :3300-3462): not rebuilt."""
 
 
 def _gaussian_noise(cov_chol: np.ndarray, n: int) -> np.ndarray:
@@ -307,6 +310,14 @@ class SE2R2RangeGaussianLikelihoodFactor(LikelihoodFactor, BinaryFactor):
         n = var1_samples.shape[0]
         return (np.sqrt((d ** 2).sum(1)) + self._sigma * np.random.standard_normal(n)).reshape(n, 1)
 
+    def pdf(self, x: np.ndarray) -> np.ndarray:
+        """Likelihood of the stored observation given joint samples x = [var1 | var2] (reference :2680-2700)."""
+        d1 = self.var1.dim
+        t1 = x[:, :d1][:, self.var1.t_dim_indices]
+        t2 = x[:, d1:][:, self.var2.t_dim_indices]
+        r = np.sqrt(((t2 - t1) ** 2).sum(1))
+        return np.exp(-0.5 * ((r - self._observation[0]) / self._sigma) ** 2) / (np.sqrt(2 * np.pi) * self._sigma)
+
     def sample(self, var1=None, var2=None) -> np.ndarray:
         if var1 is None:
             if var2 is None:
@@ -330,6 +341,134 @@ class SE2R2RangeGaussianLikelihoodFactor(LikelihoodFactor, BinaryFactor):
                          str(self.observation[0]), str(self.sigma)])
 
 
+# ---- ambiguous data association: one measurement, k candidate partners ----------------------------
+class BinaryFactorMixture(LikelihoodFactor):
+    """Mixture over `observed_vars` of binary factors of one class between the observer and each
+    candidate (reference :3043-3181).  Simulation splits the sample batch among the hypotheses with a
+    multinomial draw (rows of a sample batch are exchangeable)."""
+
+    def __init__(self, observer_var: Variable, observed_vars: List[Variable], weights: np.ndarray,
+                 binary_factor_class, obs_arr: List, sigma_arr: List):
+        weights = np.asarray(weights, dtype=np.float64)
+        assert np.all(weights > 0) and len(weights) == len(obs_arr) == len(sigma_arr) == len(observed_vars)
+        self.observer_var = observer_var
+        seen, uniq = set(), []
+        for v in observed_vars:
+            if v not in seen:
+                seen.add(v)
+                uniq.append(v)
+        self.observed_vars = uniq
+        self._vars = [observer_var] + self.observed_vars
+        self.weights = weights / weights.sum()
+        self.observations = obs_arr
+        self.sigmas = sigma_arr
+        self.components = [binary_factor_class(observer_var, v, obs_arr[i], sigma_arr[i])
+                           for i, v in enumerate(observed_vars)]
+        self.var2idx, off = {}, 0
+        for v in self._vars:
+            self.var2idx[v] = np.arange(off, off + v.dim)
+            off += v.dim
+        self.comp2idx = {c: np.concatenate((self.var2idx[c.var1], self.var2idx[c.var2])) for c in self.components}
+
+    @property
+    def vars(self):
+        return self._vars
+
+    @property
+    def observation_var(self):
+        return self.components[0].observation_var
+
+    @property
+    def measurement_dim(self):
+        return self.observation_var.dim
+
+    def _split(self, n):
+        counts = np.random.multinomial(n, self.weights)
+        bounds = np.concatenate(([0], np.cumsum(counts)))
+        return [(int(bounds[i]), int(bounds[i + 1])) for i in range(len(self.components))]
+
+    def sample_observations(self, var_samples) -> np.ndarray:
+        """Simulated measurements given samples of every variable of the factor."""
+        n = var_samples[self.observer_var].shape[0]
+        out = np.zeros((n, self.measurement_dim))
+        for (lo, hi), c in zip(self._split(n), self.components):
+            if hi > lo:
+                out[lo:hi] = c.sample(var1=var_samples[c.var1][lo:hi], var2=var_samples[c.var2][lo:hi])
+        return out
+
+    def pdf(self, x: np.ndarray) -> np.ndarray:
+        return sum(c.pdf(x[:, self.comp2idx[c]]) * w for c, w in zip(self.components, self.weights))
+
+    def posterior_weights(self, var2x) -> np.ndarray:
+        """Re-weight the association hypotheses with posterior samples (reference :3158-3181)."""
+        x = np.concatenate([var2x[v] for v in self.vars], axis=1)
+        lik = np.array([c.pdf(x[:, self.comp2idx[c]]) * w for c, w in zip(self.components, self.weights)])
+        tot = lik.sum(0)
+        hw = np.full_like(lik, 0.5)
+        ok = tot > 0
+        hw[:, ok] = lik[:, ok] / tot[ok]
+        return hw.sum(1) / hw.sum()
+
+
+class AmbiguousDataAssociationFactor(BinaryFactorMixture, KWayFactor):
+    """One measurement taken by `observer_var` of ONE of `observed_vars` (reference :3192-3298)."""
+
+    def __init__(self, observer_var: Variable, observed_vars: List[Variable], weights: np.ndarray,
+                 binary_factor_class, observation, sigma):
+        k = len(observed_vars)
+        assert k == len(weights)
+        super().__init__(observer_var, observed_vars, weights, binary_factor_class, [observation] * k, [sigma] * k)
+
+    @property
+    def observation(self) -> np.ndarray:
+        return self.components[0].observation
+
+    @property
+    def root_var(self) -> Variable:
+        return self.observer_var
+
+    @property
+    def child_vars(self) -> List[Variable]:
+        return self.observed_vars
+
+    def sample_observer(self, var2sample) -> np.ndarray:
+        """Samples of the observer given samples of all candidates."""
+        n = var2sample[self.observed_vars[0]].shape[0]
+        out = np.zeros((n, self.observer_var.dim))
+        for (lo, hi), c in zip(self._split(n), self.components):
+            if hi <= lo:
+                continue
+            if c.var1 == self.observer_var:
+                out[lo:hi] = c.sample(var1=None, var2=var2sample[c.var2][lo:hi])
+            elif c.var2 == self.observer_var:
+                out[lo:hi] = c.sample(var1=var2sample[c.var1][lo:hi], var2=None)
+            else:
+                raise ValueError("None of the vars of component matches the observer var.")
+        return out
+
+    @classmethod
+    def construct_from_text(cls, line: str, variables):
+        tok = line.strip().split()
+        if tok[0] != cls.__name__:
+            raise ValueError("The factor name is incorrect")
+        name_to_var = {v.name: v for v in variables}
+        i_obs, i_seen, i_w = tok.index("Observer") + 1, tok.index("Observed") + 1, tok.index("Weights") + 1
+        i_cls, i_meas, i_sig = tok.index("Binary") + 1, tok.index("Observation") + 1, tok.index("Sigma") + 1
+        observed = [name_to_var[t] for t in tok[i_seen:i_w - 1]]
+        weights = np.array(tok[i_w:i_cls - 1], dtype=float)
+        klass = _FACTOR_CLASSES[tok[i_cls]]
+        if i_sig - i_meas - 1 != 1:
+            raise NotImplementedError("vector-valued ambiguous measurements are not used by the shipped graphs")
+        return cls(name_to_var[tok[i_obs]], observed, weights, klass, float(tok[i_meas]), float(tok[i_sig]))
+
+    def __str__(self):
+        return " ".join(["Factor", self.__class__.__name__, "Observer", str(self.observer_var.name), "Observed"] +
+                        [str(v.name) for v in self.observed_vars] + ["Weights"] + [str(w) for w in self.weights] +
+                        ["Binary", self.components[0].__class__.__name__, "Observation",
+                         str(float(np.ravel(self.observation)[0])), "Sigma", str(self.components[0].sigma)])
+
+
 _FACTOR_CLASSES = {c.__name__: c for c in (UnarySE2ApproximateGaussianPriorFactor,
                                            SE2RelativeGaussianLikelihoodFactor,
-                                           SE2R2RangeGaussianLikelihoodFactor)}
+                                           SE2R2RangeGaussianLikelihoodFactor,
+                                           AmbiguousDataAssociationFactor)}

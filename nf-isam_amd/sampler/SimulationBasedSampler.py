@@ -23,8 +23,8 @@ class SimulationBasedSampler:
 
     def sample(self, num_samples: int):
         priors, binaries, null_hypo, assoc = unpack_prior_binary_nh_da_factors(self.factors)
-        if null_hypo or assoc:
-            raise NotImplementedError("null-hypothesis / ambiguous-association factors: next row (SURVEY.md §8 f-2)")
+        if null_hypo:
+            raise NotImplementedError("null-hypothesis factors are not rebuilt (SURVEY.md §8 f-2)")
         drawn = {}
         for f in priors:                              # assumes priors do not overlap
             s = f.sample(num_samples)
@@ -70,6 +70,20 @@ class SimulationBasedSampler:
                 if stalled > len(queue):
                     raise ValueError("Some factors connect variables that cannot be simulated: " +
                                      " ".join(str(q) for q in queue))
+        # data-association factors (k-way): a simulated measurement if every end is sampled, otherwise
+        # they may only be used to draw their observer (reference :99-113)
+        for f in assoc:
+            if all(v in drawn for v in f.vars):
+                true_obs.append(np.asarray(f.observation, dtype=np.float64).ravel())
+                obs_cols.append(f.sample_observations({v: drawn[v] for v in f.vars}))
+                obs_vars.append(f.observation_var)
+            else:
+                missing = [v for v in f.vars if v not in drawn]
+                if missing == [f.observer_var]:
+                    drawn[f.observer_var] = f.sample_observer(drawn)
+                else:
+                    raise ValueError("Some variables of the data association have not been sampled: " +
+                                     " ".join(str(v.name) for v in missing))
         for f in deferred:
             if f.var1 in drawn and f.var2 in drawn:
                 observe(f)

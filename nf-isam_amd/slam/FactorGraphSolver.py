@@ -342,11 +342,14 @@ def run_incrementally(case_dir: str, solver: FactorGraphSolver, nodes_factors_by
     with open(f"{run_dir}/parameters", "w+") as f:
         f.write(solver._args.jsonStr())
     step_timer, step_list, posterior_sampling_timer, fitting_timer = [], [], [], []
+    mixtures = []
     for i, (step_nodes, step_factors) in enumerate(nodes_factors_by_step):
         for node in step_nodes:
             solver.add_node(node)
         for factor in step_factors:
             solver.add_factor(factor)
+            if hasattr(factor, "posterior_weights"):
+                mixtures.append(factor)
         step_list.append(i)
         prefix = f"{run_dir}/step{i}"
         detailed_timer, clique_dim_timer = [], []
@@ -364,6 +367,11 @@ def run_incrementally(case_dir: str, solver: FactorGraphSolver, nodes_factors_by
         fitting_timer.append(sum(detailed_timer[1:-1]))
         np.savetxt(fname=prefix, X=np.hstack([cur_sample[v] for v in solver.elimination_ordering]))
         np.savetxt(fname=prefix + "_dim_time", X=np.array(clique_dim_timer))
+        if mixtures:   # posterior weights of the data-association hypotheses (reference :913-933)
+            with open(prefix + ".hypoweights", "w+") as f:
+                for factor in mixtures:
+                    w = factor.posterior_weights(cur_sample)
+                    f.write(" ".join(str(v.name) for v in factor.vars) + " : " + ",".join(str(x) for x in w) + "\n")
         for name, vals in (("step_timing", step_timer), ("step_list", step_list),
                            ("posterior_sampling_timer", posterior_sampling_timer), ("fitting_timer", fitting_timer)):
             with open(f"{run_dir}/{name}", "w+") as f:

@@ -46,7 +46,8 @@ def group_nodes_factors_incrementally(nodes: List[Variable], factors: List[Facto
             else:
                 raise ValueError("Unknown factors: " + str(f))
         elif isinstance(f, AmbiguousDataAssociationFactor):
-            raise NotImplementedError("ambiguous data association factors: next row (SURVEY.md §8 f-2)")
+            kind = "pose_obsv" if f.child_vars[0].type == VariableType.Pose else "lmk_obsv"
+            attach(f.root_var, kind, fidx)
     if incremental_step is None or incremental_step > max_t + 1 or incremental_step <= 0:
         incremental_step = max_t + 1
     out, new_vars, new_factors, seen_lmks = [], [], [], set()

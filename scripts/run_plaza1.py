@@ -14,7 +14,8 @@ max_updates = int(sys.argv[1]) if len(sys.argv) > 1 else 10 ** 9
 out_json = sys.argv[2] if len(sys.argv) > 2 else None
 seed = int(os.environ.get('SEED', '0'))
 np.random.seed(seed); torch.manual_seed(seed)
-nodes, truth, factors = graph_file_parser(os.path.join(ROOT, "tests", "data", "Plaza1EFG", "factor_graph.fg"), "fg")
+dataset = os.environ.get("DATASET", "Plaza1EFG")
+nodes, truth, factors = graph_file_parser(os.path.join(ROOT, "tests", "data", dataset, "factor_graph.fg"), "fg")
 steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=5)
 args = NFiSAMArgs(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
                   cuda_training=True, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,

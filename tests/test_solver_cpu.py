@@ -247,3 +247,54 @@ def _off(order, name):
             return off
         off += 3 if v.startswith("X") else 2
     raise KeyError(name)
+
+
+def test_ambiguous_data_association_factor():
+    from factors.Factors import AmbiguousDataAssociationFactor
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nodes, truth, factors = read_factor_graph_from_file(os.path.join(ROOT, "tests", "data", "Plaza1ADA0.4EFG",
+                                                                      "factor_graph.fg"))
+    ada = [f for f in factors if isinstance(f, AmbiguousDataAssociationFactor)]
+    assert len(nodes) == 782 and len(factors) == 1584 and len(ada) == 279
+    f = ada[0]
+    assert str(Factor.construct_from_text(str(f), nodes)) == str(f)
+    assert f.root_var.name == "X4" and [v.name for v in f.child_vars] == ["L1", "L0", "L2", "L3"]
+    np.testing.assert_allclose(f.weights, 0.25)
+    steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=5)
+    assert len(steps) == 156 and sum(len(s[1]) for s in steps) == len(factors)
+    # simulated measurements: a multinomial split of the batch over the four hypotheses
+    np.random.seed(0)
+    name = {v.name: v for v in nodes}
+    centers = {"L0": (0.0, 0.0), "L1": (10.0, 0.0), "L2": (20.0, 0.0), "L3": (30.0, 0.0)}
+    n = 4000
+    drawn = {name[k]: np.tile(np.array(c), (n, 1)) for k, c in centers.items()}
+    drawn[name["X4"]] = np.tile(np.array([0.0, 0.0, 0.3]), (n, 1))
+    o = f.sample_observations(drawn)
+    assert o.shape == (n, 1)
+    for d in (0.0, 10.0, 20.0, 30.0):          # a quarter of the simulated ranges sits near each candidate
+        assert abs(np.mean(np.abs(o[:, 0] - d) < 3 * f.components[0].sigma) - 0.25) < 0.03
+    # hypothesis weights: put the pose where only L2 explains the measured range
+    r = float(f.observation[0])
+    drawn[name["X4"]] = np.tile(np.array([20.0 - r, 0.0, 0.0]), (n, 1))
+    w = f.posterior_weights(drawn)
+    assert abs(w.sum() - 1) < 1e-9 and np.argmax(w) == 2 and w[2] > 0.9
+    # the clique sampler turns a fully-sampled ADA factor into an observation column
+    X3, X4 = name["X3"], name["X4"]
+    odo = [g for g in factors if isinstance(g, SE2RelativeGaussianLikelihoodFactor) and g.var2 == X4][0]
+    prior = UnarySE2ApproximateGaussianPriorFactor(X3, SE2Pose(*truth[X3]), np.eye(3) * 1e-4)
+
+    class _LmPrior(UnarySE2ApproximateGaussianPriorFactor.__mro__[1]):   # ExplicitPriorFactor
+        def __init__(self, v, c):
+            self._v, self._c = v, c
+
+        @property
+        def vars(self):
+            return [self._v]
+
+        def sample(self, n, **kw):
+            return np.tile(np.array(self._c), (n, 1)) + 0.1 * np.random.randn(n, 2)
+    fs = [prior, odo, f] + [_LmPrior(name[k], truth[name[k]]) for k in centers]
+    pattern = [name[k] for k in ("L3", "L2", "L1", "L0")] + [X4, X3]
+    samples, order, obs = SimulationBasedSampler(fs, pattern).sample(300)
+    assert samples.shape == (300, 1 + 8 + 6) and [v.name for v in order][0].startswith("O")
+    np.testing.assert_allclose(obs, f.observation)

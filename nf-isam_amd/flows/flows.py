@@ -11,6 +11,7 @@ Deliberate difference: `forward` returns z and log_det in the mathematically cor
 layout; the reference returns a scrambled one (flows.py:88-93).  Pass
 `reference_scramble=True` to reproduce the reference's return value bit-for-layout.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -60,9 +61,38 @@ class _NSFFunction(torch.autograd.Function):
         return gx, _nh.unpack(kg, D, K, H, 1), None, None, None, None
 
 
+def _init_bounds(dim, K, H):
+    """Per-parameter half-width of the reference initialisation, in the reference's parameter order:
+    init_param ~ U(-1/2, 1/2) (flows.py:62-63); nn.Linear default = U(+-1/sqrt(fan_in)) for weight and bias."""
+    Po = 3 * K - 1
+    parts = [np.full(Po, 0.5, dtype=np.float32)]
+    for i in range(1, dim):
+        for fan_in, cnt in ((i, H * i), (i, H), (H, H * H), (H, H), (H, Po * H), (H, Po)):
+            parts.append(np.full(cnt, 1.0 / np.sqrt(fan_in), dtype=np.float32))
+    return np.concatenate(parts)
+
+
+_bounds_cache = {}
+
+
+def init_reference_blob(dim, K, H, device, generator=None):
+    """Freshly initialised parameters of one NSF_AR layer as ONE flat device tensor (reference order)."""
+    key = (dim, K, H, str(device))
+    if key not in _bounds_cache:
+        _bounds_cache[key] = torch.from_numpy(_init_bounds(dim, K, H)).to(device)
+    b = _bounds_cache[key]
+    return (torch.rand(b.shape, device=device, generator=generator) * 2.0 - 1.0) * b
+
+
 class NSF_AR(nn.Module):
     """Neural spline flow, auto-regressive [Durkan et al. 2019] (reference: flows.py:43-137).
-    K is the number of spline bins, B the tail bound."""
+    K is the number of spline bins, B the tail bound.
+
+    Two construction modes.  The reference's: `NSF_AR(dim, K, B, hidden_dim)` builds `init_param` and
+    the `layers` ModuleList of FCNNs right away.  The solver's: `NSF_AR.from_kernel_params(...)` wraps a
+    kernel-layout parameter blob that already lives on the device and builds the nn.Module tree only if
+    somebody asks for it (`.layers`, `.init_param`, `.parameters()`, `state_dict()`): constructing ~90
+    module objects and moving ~90 tiny tensors per clique costs more host time than training the clique."""
 
     def __init__(self, dim, K=5, B=5.0, hidden_dim=8, base_network=FCNN, reference_scramble=False):
         super().__init__()
@@ -73,12 +103,66 @@ class NSF_AR(nn.Module):
         self.B = B
         self.hidden_dim = hidden_dim
         self.reference_scramble = reference_scramble
-        self.layers = nn.ModuleList()
-        self.init_param = nn.Parameter(torch.Tensor(3 * K - 1))
-        for i in range(1, dim):
-            self.layers += [base_network(i, 3 * K - 1, hidden_dim)]
-        self.reset_parameters()
         self._kcache = None
+        self._lazy_kparams = None
+        self._build_modules()
+        self.reset_parameters()
+
+    def _build_modules(self):
+        self.layers = nn.ModuleList()
+        self.init_param = nn.Parameter(torch.Tensor(3 * self.K - 1))
+        for i in range(1, self.dim):
+            self.layers += [FCNN(i, 3 * self.K - 1, self.hidden_dim)]
+
+    @classmethod
+    def from_kernel_params(cls, dim, K, B, hidden_dim, kparams):
+        """Wrap a kernel-layout blob [kparam_count(dim, K, H)] (device tensor) without building modules."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.dim, self.K, self.B, self.hidden_dim = dim, K, B, hidden_dim
+        self.reference_scramble = False
+        self._kcache = None
+        self._lazy_kparams = kparams
+        return self
+
+    def _materialize(self):
+        """Build the nn.Module tree from the wrapped kernel blob (rare: only for module-level access)."""
+        kp = self._lazy_kparams
+        self._lazy_kparams = None
+        self._build_modules()
+        self.to(kp.device)
+        self.load_kernel_params(kp)
+
+    def __getattr__(self, name):
+        if name in ("layers", "init_param") and self.__dict__.get("_lazy_kparams") is not None:
+            self._materialize()
+        return super().__getattr__(name)
+
+    def parameters(self, recurse: bool = True):
+        if self.__dict__.get("_lazy_kparams") is not None:
+            self._materialize()
+        return super().parameters(recurse)
+
+    def named_parameters(self, *args, **kwargs):
+        if self.__dict__.get("_lazy_kparams") is not None:
+            self._materialize()
+        return super().named_parameters(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        if self.__dict__.get("_lazy_kparams") is not None:
+            self._materialize()
+        return super().state_dict(*args, **kwargs)
+
+    def _apply(self, fn, recurse=True):
+        if self.__dict__.get("_lazy_kparams") is not None:
+            self._lazy_kparams = fn(self._lazy_kparams)
+            return self
+        return super()._apply(fn, recurse)
+
+    @property
+    def device(self):
+        kp = self.__dict__.get("_lazy_kparams")
+        return kp.device if kp is not None else self.init_param.device
 
     def reset_parameters(self):
         init.uniform_(self.init_param, -1 / 2, 1 / 2)
@@ -90,6 +174,9 @@ class NSF_AR(nn.Module):
 
     def kernel_params(self):
         """Kernel-layout blob of the current parameters (cached until a parameter is modified)."""
+        kp = self.__dict__.get("_lazy_kparams")
+        if kp is not None:
+            return kp
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._kcache is None or self._kcache[0] != key:
             with torch.no_grad():
@@ -100,6 +187,9 @@ class NSF_AR(nn.Module):
     def load_kernel_params(self, kparams):
         """Write a kernel-layout blob (e.g. the result of the fused training loop) back into the
         nn.Parameters."""
+        if self.__dict__.get("_lazy_kparams") is not None:
+            self._lazy_kparams = kparams
+            return
         blob = _nh.unpack(kparams, self.dim, self.K, self.hidden_dim, 1)
         off = 0
         with torch.no_grad():
@@ -117,7 +207,8 @@ class NSF_AR(nn.Module):
     # ---- reference API -----------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
         x = self._check(x, self.dim)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        lazy = self.__dict__.get("_lazy_kparams") is not None
+        if torch.is_grad_enabled() and (x.requires_grad or (not lazy and any(p.requires_grad for p in self.parameters()))):
             z, ld = _NSFFunction.apply(x, self.reference_blob(), self.dim, self.K, self.hidden_dim, self.B)
         else:
             z, ld, _ = _nh.forward(x, self.kernel_params(), self.K, self.hidden_dim, self.B, 1)

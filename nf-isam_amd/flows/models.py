@@ -37,7 +37,16 @@ class NormalizingFlowModel(nn.Module):
             f.load_kernel_params(kparams[l * Pk:(l + 1) * Pk])
 
     def _needs_grad(self, x):
-        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not torch.is_grad_enabled():
+            return False
+        if x.requires_grad:
+            return True
+        for f in self.flows:
+            if isinstance(f, NSF_AR) and f.__dict__.get("_lazy_kparams") is not None:
+                continue          # frozen, solver-trained layer: nothing to differentiate
+            if any(p.requires_grad for p in f.parameters()):
+                return True
+        return False
 
     # ---- reference API -----------------------------------------------------------------------
     def forward(self, x):

@@ -22,7 +22,6 @@ from typing import List
 
 import numpy as np
 import torch
-from scipy.stats import circmean
 
 import nfisam_hip as _nh
 from flows.flows import NSF_AR
@@ -115,7 +114,7 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
         f0 = self.flows[0]
         if not self._homogeneous():
             raise NotImplementedError("the fused sampling kernel needs identical NSF_AR layers")
-        return f0, len(self.flows), next(f0.parameters()).device
+        return f0, len(self.flows), f0.device
 
     # ---- reference API: host-visible (un)normalisation (NFiSAM.py:96-118) ---------------------
     def normalize_samples(self, samples, init_dim):
@@ -298,32 +297,40 @@ class NFiSAM(FactorGraphSolver):
         if len(test_samples) > 0:
             testing_data, _, _ = self.normalize_training_samples(test_samples, circular_dim_list, a.flow_type)
 
-        flows = [NSF_AR(dim=aug_clique_dim, K=a.num_knots, hidden_dim=a.hidden_dim).to(device)
-                 for _ in range(a.flow_number)]
-        normal_clique = CustomMultivariateNormal(dim=aug_clique_dim, device=device)
-        normal_separator = CustomMultivariateNormal(dim=aug_separator_dim, device=device) \
-            if aug_separator_dim > 0 else None
-        model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, circular_dim_list, means,
-                                                  stds)
-        f0 = flows[0]
+        # Parameters are initialised directly on the device in the reference's order (one op per layer) and
+        # trained as kernel-layout blobs; the nn.Module tree of each NSF_AR is only built on demand.
+        from flows.flows import init_reference_blob
+        K, H, B, L = a.num_knots, a.hidden_dim, 5.0, a.flow_number
+        if not _nh.supported(K, H):
+            raise ValueError("no kernel instantiation for num_knots=%d, hidden_dim=%d" % (K, H))
+        kp0 = torch.cat([_nh.pack(init_reference_blob(aug_clique_dim, K, H, device), aug_clique_dim, K, H, 1)
+                         for _ in range(L)])
         x_dev = training_data.to(device).contiguous()
         logger = logging.getLogger("flows on clique")
 
         opt_start = time.time()
-        tb = _nh.TrainBatch([x_dev], [model.kernel_params().clone()], f0.K, f0.hidden_dim, f0.B, a.flow_number,
-                            lr=a.learning_rate, max_iters=a.flow_iterations, average_window=a.average_window,
-                            loss_delta_tol=a.loss_delta_tol, early_stop=(testing_data is None))
+        tb = _nh.TrainBatch([x_dev], [kp0], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                            average_window=a.average_window, loss_delta_tol=a.loss_delta_tol,
+                            early_stop=(testing_data is None))
         if testing_data is None:
             iters = tb.run(use_graph=True)[0]
             if iters < a.flow_iterations:
                 logger.info(f"Early stopping at iter {iters}")
         else:
+            f0 = NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, kp0)
             iters = self._fit_with_validation(tb, testing_data.to(device).contiguous(), f0, logger)
-        model.load_kernel_params(tb.kparams[0])
         torch.cuda.synchronize()
         opt_end = time.time()
         if timer is not None:
             timer.append(opt_end - opt_start)
+        Pk = _nh.kparam_count(aug_clique_dim, K, H)
+        trained = tb.kparams[0]
+        flows = [NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, trained[l * Pk:(l + 1) * Pk]) for l in range(L)]
+        normal_clique = CustomMultivariateNormal(dim=aug_clique_dim, device=device)
+        normal_separator = CustomMultivariateNormal(dim=aug_separator_dim, device=device) \
+            if aug_separator_dim > 0 else None
+        model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, circular_dim_list, means,
+                                                  stds)
 
         clique_name = ''.join([str(var.name) for var in clique.vars])
         self._temp_training_loss[clique_name] = [float(v) for v in tb.iter_loss[0].cpu().numpy().astype(np.float64)]
@@ -368,7 +375,8 @@ class NFiSAM(FactorGraphSolver):
         ci = np.where(circular_dim_list)[0]
         ei = np.setdiff1d(np.arange(aug_clique_dim), ci)
         if len(ci) > 0:
-            means[ci] = circmean(samples[:, ci], high=np.pi, low=-np.pi, axis=0)
+            # scipy.stats.circmean(., high=pi, low=-pi) in closed form: direction of the mean resultant
+            means[ci] = theta_to_pipi(np.arctan2(np.sin(samples[:, ci]).sum(0), np.cos(samples[:, ci]).sum(0)))
             shifted = theta_to_pipi(samples[:, ci] - means[ci])
             stds[ci] = np.std(shifted, axis=0)
             samples[:, ci] = shifted

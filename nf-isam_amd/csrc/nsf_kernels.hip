@@ -203,8 +203,12 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
 
     const int p0 = blockIdx.x * TILE;
     if (p0 >= n) return;
+    // state words as per-lane loads issued now and consumed only after the prologue's global loads have
+    // been issued too: one exposed memory round trip instead of two
+    int st_stop = 0, st_step = 0;
     if (st != nullptr) {
-        if (st->stop != 0 || st->step >= a.max_iters) return;
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -260,6 +264,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            if (st_stop != 0 || st_step >= a.max_iters) return;      // block-uniform (first consumer of the state loads)
 #pragma unroll
             for (int u = 0; u < XB; ++u) {
                 const int e = e0 + u * (int)blockDim.x;
@@ -583,6 +588,23 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const int D = batched ? cp->D : a.single.D;
 
     __shared__ int s_step, s_stop, s_last;
+    // Every block fetches the 64 loss slots right away (they were completed by the previous kernel, and
+    // only the block that turns out to be last uses / zeroes them): the latency overlaps the parameter loads.
+    float slot = 0.0f;
+    if (threadIdx.x < 64)
+        slot = __hip_atomic_load(&st->loss_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int PoP = pad4(3 * a.K - 1);
+    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
+    const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
+    // first pass's operands are requested before the state words are consumed (one round trip, not two)
+    const int pj0 = threadIdx.x & 31, tl0 = threadIdx.x >> 5, jf = blockIdx.x * 32 + pj0;
+    const int n_tiles0 = a.slab ? (n + TILE - 1) / TILE : 1;
+    float pre_g = 0.0f, pre_m = 0.0f, pre_v = 0.0f, pre_t = 0.0f;
+    if (jf < P) {
+#pragma unroll 8
+        for (int tt = tl0; tt < n_tiles0; tt += 8) pre_g += G[(size_t)tt * P + jf];
+        if (tl0 == 0) { pre_m = m[jf]; pre_v = v[jf]; pre_t = theta[jf]; }
+    }
     if (threadIdx.x == 0) {
         s_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -590,10 +612,6 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     __syncthreads();
     if (s_stop != 0 || s_step >= a.cfg.max_iters) return;
     const int t = s_step + 1;
-
-    const int PoP = pad4(3 * a.K - 1);
-    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
-    const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
 
     const float b1 = a.cfg.beta1, b2 = a.cfg.beta2;
     const float bc1 = -expm1f((float)t * a.log_b1);
@@ -607,10 +625,13 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     __shared__ float s_part[8][33];
     const int n_tiles = a.slab ? (n + TILE - 1) / TILE : 1;
     const int pj = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    bool first = true;
     for (int j0 = blockIdx.x * 32; j0 < P; j0 += gridDim.x * 32) {
         const int j = j0 + pj;
         float part = 0.0f;
-        if (j < P) {
+        if (first) {
+            part = pre_g;
+        } else if (j < P) {
 #pragma unroll 8
             for (int tt = tl; tt < n_tiles; tt += 8) part += G[(size_t)tt * P + j];
         }
@@ -621,15 +642,17 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
 #pragma unroll
             for (int q = 1; q < 8; ++q) gs += s_part[q][pj];
             const float g = gs * inv_n;
-            const float mj = b1 * m[j] + (1.0f - b1) * g;
-            const float vj = b2 * v[j] + (1.0f - b2) * g * g;
+            const float mo = first ? pre_m : m[j], vo = first ? pre_v : v[j], to = first ? pre_t : theta[j];
+            const float mj = b1 * mo + (1.0f - b1) * g;
+            const float vj = b2 * vo + (1.0f - b2) * g * g;
             m[j] = mj;
             v[j] = vj;
             const float denom = sqrtf(vj) * inv_bc2s + a.cfg.eps;
-            theta[j] -= step_size * mj / denom;
+            theta[j] = to - step_size * mj / denom;
             if (!a.slab) G[j] = 0.0f;
         }
         __syncthreads();
+        first = false;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -638,13 +661,11 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    // last block: per-iteration bookkeeping.  The 64 loss slots (written by the previous kernel's
-    // atomics) are read one per lane at agent scope and reduced across the wave.
+    // last block: per-iteration bookkeeping (loss record, window early stop, step counter)
     float acc = 0.0f;
     if (threadIdx.x < 64) {
-        acc = __hip_atomic_load(&st->loss_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st->loss_slots[threadIdx.x] = 0.0f;
-        acc = wave_sum(acc);
+        acc = wave_sum(slot);
     }
     if (threadIdx.x == 0) {
         st->reserved[0] = 0;

@@ -4,8 +4,6 @@
 NSF_AR of the same shape and no autograd graph is needed, all layers run in ONE fused kernel
 launch (layers chained in LDS); otherwise the flows are applied one after the other (each one a
 kernel launch with an analytic-VJP backward)."""
-import math
-
 import torch
 import torch.nn as nn
 
@@ -48,40 +46,42 @@ class NormalizingFlowModel(nn.Module):
                 return True
         return False
 
-    # ---- reference API -----------------------------------------------------------------------
+    # ---- layer-by-layer path (heterogeneous flows, or an autograd graph is wanted) ---------------
+    def _chain(self, value, method_name, order):
+        total = None
+        for flow in order:
+            value, ld = getattr(flow, method_name)(value)
+            total = ld if total is None else total + ld
+        if total is None:
+            total = value.new_zeros(value.shape[0])
+        return value, total
+
+    def _bind_prior(self, like):
+        # the prior follows the first batch's device (the reference's one-shot check, models.py:12-15)
+        if self._prior_device_check:
+            return
+        dev = str(like.device)
+        if self.prior._device != dev:
+            self.prior = self.prior.to(dev)
+        self._prior_device_check = True
+
+    # ---- reference API: forward -> (z, prior_logprob, log_det); inverse -> (x, log_det) ---------
     def forward(self, x):
-        if not self._prior_device_check:
-            if self.prior._device != x.device.__str__():
-                self.prior = self.prior.to(x.device.__str__())
-            self._prior_device_check = True
+        self._bind_prior(x)
         if self._homogeneous() and not self._needs_grad(x):
             f0 = self.flows[0]
-            xc = f0._check(x, f0.dim)
-            z, log_det, lp = _nh.forward(xc, self.kernel_params(), f0.K, f0.hidden_dim, f0.B, len(self.flows),
-                                         want_logprob=True)
-            return z, lp - log_det, log_det
-        m, _ = x.shape
-        log_det = torch.zeros(m, device=x.device)
-        for flow in self.flows:
-            x, ld = flow.forward(x)
-            log_det = log_det + ld
-        z, prior_logprob = x, self.prior.log_prob(x)
-        return z, prior_logprob, log_det
+            z, log_det, lp = _nh.forward(f0._check(x, f0.dim), self.kernel_params(), f0.K, f0.hidden_dim, f0.B,
+                                         len(self.flows), want_logprob=True)
+            return z, lp - log_det, log_det           # the kernel's log-prob includes the log-det
+        z, log_det = self._chain(x, "forward", self.flows)
+        return z, self.prior.log_prob(z), log_det
 
     def inverse(self, z):
         if self._homogeneous():
             f0 = self.flows[0]
-            zc = f0._check(z, f0.dim)
-            return _nh.inverse(zc, None, self.kernel_params(), f0.K, f0.hidden_dim, f0.B, len(self.flows),
-                               want_logdet=True)
-        m, _ = z.shape
-        log_det = torch.zeros(m, device=z.device)
-        for flow in self.flows[::-1]:
-            z, ld = flow.inverse(z)
-            log_det = log_det + ld
-        return z, log_det
+            return _nh.inverse(f0._check(z, f0.dim), None, self.kernel_params(), f0.K, f0.hidden_dim, f0.B,
+                               len(self.flows), want_logdet=True)
+        return self._chain(z, "inverse", list(self.flows)[::-1])
 
     def sample(self, n_samples):
-        z = self.prior.sample((n_samples,), )
-        x, _ = self.inverse(z)
-        return x
+        return self.inverse(self.prior.sample((int(n_samples),)))[0]

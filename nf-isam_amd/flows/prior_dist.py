@@ -1,72 +1,109 @@
-"""flows.prior_dist — base densities (reference: src/flows/prior_dist.py:5-70).
+"""flows.prior_dist — base densities of the flows (API of the reference's src/flows/prior_dist.py:5-70:
+`CustomMultivariateNormal(dim, device)` and `MultivariateNormalVonmises(circular_dim_list, device)` with
+`log_prob`, `sample`, `to`, `cpu`, `is_cpu`, `dim`, `_device`).
 
-N(0, I) only needs `log_prob` / `sample`; the fused kernels evaluate the prior log-probability
-themselves, these classes exist for the module surface and for host-side code."""
+The base density of NF-iSAM's flows is the standard normal, for which neither a covariance
+factorisation nor torch.distributions bookkeeping is needed: log N(z; 0, I) = -|z|^2/2 - D/2 log 2pi and
+sampling is `randn`.  (The fused kernels evaluate this term themselves; these classes serve host code
+and the module surface.)  Constructing one costs nothing, which matters because the solver creates
+two per trained clique.
+"""
+import math
+
 import torch
-from torch.distributions import MultivariateNormal, Normal, VonMises
+
+_LOG_2PI = math.log(2.0 * math.pi)
 
 
-class CustomMultivariateNormal(MultivariateNormal):
-    """Standard normal of dimension `dim` that remembers its device string."""
+class CustomMultivariateNormal(object):
+    """N(0, I_dim) bound to a device string."""
 
     def __init__(self, dim: int, device: str = "cpu") -> None:
-        self._dim = dim
-        self._device = device
-        self._loc = torch.zeros(dim).to(device)
-        self._scale_tril = torch.eye(dim).to(device)
-        super().__init__(self._loc, scale_tril=self._scale_tril)
+        self._dim = int(dim)
+        self._device = str(device)
 
-    def cpu(self):
-        return CustomMultivariateNormal(dim=self._dim, device="cpu")
+    # -- density / sampling ----------------------------------------------------------------------
+    def log_prob(self, value: torch.Tensor) -> torch.Tensor:
+        if value.shape[-1] != self._dim:
+            raise ValueError("expected last dimension %d, got %d" % (self._dim, value.shape[-1]))
+        return -0.5 * (value * value).sum(-1) - 0.5 * self._dim * _LOG_2PI
 
-    def is_cpu(self):
-        return self._device == "cpu"
+    def sample(self, sample_shape=torch.Size()) -> torch.Tensor:
+        shape = tuple(sample_shape) + (self._dim,)
+        return torch.randn(shape, device=self._device)
 
+    def rsample(self, sample_shape=torch.Size()) -> torch.Tensor:
+        return self.sample(sample_shape)
+
+    # -- the attributes the flow container and the solver look at -------------------------------------
     @property
     def dim(self) -> int:
         return self._dim
 
-    def to(self, device: str):
-        return CustomMultivariateNormal(dim=self._dim, device=str(device))
+    @property
+    def mean(self) -> torch.Tensor:
+        return torch.zeros(self._dim, device=self._device)
+
+    @property
+    def covariance_matrix(self) -> torch.Tensor:
+        return torch.eye(self._dim, device=self._device)
+
+    def is_cpu(self) -> bool:
+        return self._device == "cpu"
+
+    def to(self, device) -> "CustomMultivariateNormal":
+        return CustomMultivariateNormal(self._dim, str(device))
+
+    def cpu(self) -> "CustomMultivariateNormal":
+        return self.to("cpu")
+
+    def __repr__(self) -> str:
+        return "CustomMultivariateNormal(dim=%d, device=%r)" % (self._dim, self._device)
 
 
 class MultivariateNormalVonmises(object):
-    """Product of N(0,1) (Euclidean dims) and VonMises(0,1) (circular dims).  Only reachable from the
-    reference's undefined `NSF_AR_CS` flow type; kept for the module surface."""
+    """Independent columns: N(0, 1) for Euclidean ones, VonMises(0, 1) for circular ones.  In the
+    reference this prior is only reachable through the undefined `NSF_AR_CS` flow type;
+    it is kept because it is part of the module surface."""
 
     def __init__(self, circular_dim_list, device="cpu") -> None:
-        self._device = device
-        self._circular_dim_list = list(circular_dim_list)
-        self._dist = []
-        for circular in self._circular_dim_list:
-            if circular:
-                self._dist.append(VonMises(loc=torch.tensor([0.0]).to(device),
-                                           concentration=torch.tensor([1.0]).to(device)))
-            else:
-                self._dist.append(Normal(loc=torch.tensor([0.0]).to(device), scale=torch.tensor([1.0]).to(device)))
+        self._circular = [bool(c) for c in circular_dim_list]
+        self._device = str(device)
+        self._vm = None
 
-    def sample(self, sample_shape: tuple):
-        cols = [d.sample((sample_shape[0],)) for d in self._dist]
-        return torch.cat(cols, 1).to(self._device)
+    def _vonmises(self):
+        if self._vm is None:
+            self._vm = torch.distributions.VonMises(torch.zeros(1, device=self._device),
+                                                    torch.ones(1, device=self._device))
+        return self._vm
 
-    def log_prob(self, x):
-        assert len(self._dist) == x.shape[1]
-        res = self._dist[0].log_prob(x[:, 0])
-        for i in range(1, x.shape[1]):
-            res = res + self._dist[i].log_prob(x[:, i])
-        return res
+    def sample(self, sample_shape: tuple) -> torch.Tensor:
+        n = int(sample_shape[0])
+        out = torch.randn(n, len(self._circular), device=self._device)
+        for c, circ in enumerate(self._circular):
+            if circ:
+                out[:, c] = self._vonmises().sample((n,))[:, 0]
+        return out
 
-    def cpu(self):
-        return MultivariateNormalVonmises(self._circular_dim_list, device="cpu")
-
-    def is_cpu(self):
-        return self._device == "cpu"
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[1] != len(self._circular):
+            raise ValueError("expected %d columns" % len(self._circular))
+        total = torch.zeros(x.shape[0], device=x.device)
+        for c, circ in enumerate(self._circular):
+            col = x[:, c]
+            total = total + (self._vonmises().log_prob(col) if circ else -0.5 * col * col - 0.5 * _LOG_2PI)
+        return total
 
     @property
     def dim(self) -> int:
-        return len(self._circular_dim_list)
+        return len(self._circular)
 
-    def to(self, device: str):
-        # the reference returns a CustomMultivariateNormal with a list as `dim` here (prior_dist.py:69-70,
-        # a bug in dead code); the sensible behaviour is kept instead
-        return MultivariateNormalVonmises(self._circular_dim_list, device=str(device))
+    def is_cpu(self) -> bool:
+        return self._device == "cpu"
+
+    def to(self, device) -> "MultivariateNormalVonmises":
+        # (the reference returns a CustomMultivariateNormal with a list as `dim` here, prior_dist.py:69-70)
+        return MultivariateNormalVonmises(self._circular, str(device))
+
+    def cpu(self) -> "MultivariateNormalVonmises":
+        return self.to("cpu")

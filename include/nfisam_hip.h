@@ -24,12 +24,16 @@
  * H hidden width, Po = 3K-1, B tail bound (5.0 in the reference, flows.py:51), L flow layers.
  *
  * Parameter storage ("kernel layout", float32, one block of `nfisam_nsf_kparam_count`
- * floats per flow layer, layers concatenated).  With PoP = Po rounded up to a multiple of 4:
+ * floats per flow layer, layers concatenated):
  *     init_param[PoP]
  *     for i = 1..D-1:  W0t[i][H]  b0[H]  W1t[H][H]  b1[H]  W2t[H][PoP]  b2[PoP]
  * where W*t are the TRANSPOSES ([in][out]) of the reference's nn.Linear weights
- * (flows.py:31-37), so that every weight row a wavefront consumes is contiguous and can be
- * fetched with scalar loads.  Padding entries are zero and stay zero under training.
+ * (flows.py:31-37), so that every weight row a wavefront consumes is contiguous (16-byte
+ * aligned rows: scalar loads or ds_read_b128).  The PoP = 2*HP output columns are two halves,
+ *     [ K width logits  | first floor(K/2) derivative logits | 0-pad to HP ]
+ *     [ K height logits | remaining derivative logits        | 0-pad to HP ],  HP = 4*ceil((K + floor(K/2))/4)
+ * (the reference's order is widths | heights | derivatives, flows.py:84-88): the two lanes that share
+ * a particle in the training kernel each own one half.  Padding entries are zero and stay zero under training.
  * `nfisam_nsf_layout_map` gives the permutation to/from the reference's parameter order
  * (init_param, layers.{i-1}.network.{0,2,4}.{weight,bias}; flows.py:57-59).
  */
@@ -176,9 +180,10 @@ typedef struct nfisam_clique {
 } nfisam_clique;
 
 /* Floats the `kgrad` workspace of a clique must hold when the largest clique of its batch has n
- * particles: small launches (<= 64 tiles) write per-tile partial gradients with plain stores and the
- * Adam kernel sums them in tile order (no atomics, bitwise-reproducible); larger ones accumulate
- * with float atomics into a single copy.                                                      */
+ * particles: launches of <= 128 particle tiles write per-tile partial gradients with plain stores and
+ * the Adam kernel sums them in tile order (no atomics); larger ones accumulate with float atomics
+ * into a single copy.  A tile is 32 particles (two-lanes-per-particle kernel, launches that leave
+ * SIMDs idle) or 64 (one lane per particle, big batches); the count is the upper bound of both.   */
 size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
 /* The gradient half of a training iteration on its own (forward + analytic backward + reduction into

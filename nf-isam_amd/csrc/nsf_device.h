@@ -32,10 +32,28 @@ constexpr int TILE = 64;              // particles per wave-tile (one per lane)
 __host__ __device__ constexpr int pad4(int v) { return (v + 3) & ~3; }
 
 // ---- kernel-layout offsets (see include/nfisam_hip.h) --------------------------------------
+// The 3K-1 spline logits of one dim are stored as two halves of HP floats:
+//   half 0 = [ K width logits  | first ND0 derivative logits | 0-pad ]
+//   half 1 = [ K height logits | last  ND1 derivative logits | 0-pad ]
+// Widths and heights go through the same softmax -> cumsum -> knot pipeline, so in the training kernel
+// two neighbouring lanes share one particle, one half each (nsf_split.h); the one-lane-per-particle
+// inference kernels address the same layout through iw/ih/idv.
+__host__ __device__ constexpr int nd0_of(int K) { return K / 2; }                 // ceil((K-1)/2)
+__host__ __device__ constexpr int hp_of(int K) { return pad4(K + nd0_of(K)); }
+__host__ __device__ constexpr int pop_of(int K) { return 2 * hp_of(K); }
+__host__ __device__ constexpr int out_col(int K, int o) {     // reference output index o in [0,3K-1) -> column
+    return o < K ? o : (o < 2 * K ? hp_of(K) + (o - K)
+                                   : ((o - 2 * K) < nd0_of(K) ? K + (o - 2 * K) : hp_of(K) + K + (o - 2 * K - nd0_of(K))));
+}
 template <int K, int H>
 struct Layout {
     static constexpr int Po = 3 * K - 1;
-    static constexpr int PoP = pad4(Po);
+    static constexpr int ND0 = nd0_of(K), ND1 = K - 1 - ND0;
+    static constexpr int HP = hp_of(K);
+    static constexpr int PoP = pop_of(K);
+    __host__ __device__ static constexpr int iw(int j) { return j; }                // width logit j
+    __host__ __device__ static constexpr int ih(int j) { return HP + j; }           // height logit j
+    __host__ __device__ static constexpr int idv(int j) { return j < ND0 ? K + j : HP + K + (j - ND0); }  // interior knot j+1
     static constexpr int kFixed = H + H * H + H + H * PoP + PoP;   // block size without W0t
     __host__ __device__ static constexpr int block(int i) { return i * H + kFixed; }
     __host__ __device__ static constexpr int off(int i) {          // offset of dim i's block, i >= 1
@@ -196,16 +214,18 @@ __device__ __forceinline__ void rq_math(float vs, float Xk, float dx, float Yk, 
 template <int K, int PoP, bool INV>
 __device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], float B, Spline<K>& S,
                                             float& out, float& lad) {
+    using LY = Layout<K, 8>;          // only the output-column accessors are used (independent of H)
+    static_assert(PoP == LY::PoP, "theta rows follow the kernel layout");
     S.inside = (v >= -B) && (v <= B);             // false for NaN (utils.py:31)
     const float vs = S.inside ? v : 0.0f;
-    float mw = th[0], mh = th[K];
+    float mw = th[LY::iw(0)], mh = th[LY::ih(0)];
 #pragma unroll
-    for (int j = 1; j < K; ++j) { mw = fmaxf(mw, th[j]); mh = fmaxf(mh, th[K + j]); }
+    for (int j = 1; j < K; ++j) { mw = fmaxf(mw, th[LY::iw(j)]); mh = fmaxf(mh, th[LY::ih(j)]); }
     float sw = 0.0f, sh = 0.0f;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        S.pw[j] = fexp(th[j] - mw); sw += S.pw[j];
-        S.ph[j] = fexp(th[K + j] - mh); sh += S.ph[j];
+        S.pw[j] = fexp(th[LY::iw(j)] - mw); sw += S.pw[j];
+        S.ph[j] = fexp(th[LY::ih(j)] - mh); sh += S.ph[j];
     }
     const float iw = frcp(sw), ih = frcp(sh);
     const float mix = 1.0f - kMinBin * (float)K, twoB = 2.0f * B;
@@ -225,7 +245,7 @@ __device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], flo
     S.ud0 = kBoundLogit; S.ud1 = kBoundLogit;
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
-        const float dj = th[2 * K + j];
+        const float dj = th[LY::idv(j)];
         if (S.k == j + 1) S.ud0 = dj;
         if (S.k == j) S.ud1 = dj;
     }
@@ -240,6 +260,10 @@ __device__ __forceinline__ void spline_eval(float v, const float (&th)[PoP], flo
 template <int K, int PoP>
 __device__ __forceinline__ float spline_backward(const Spline<K>& S, float B, float gz, float gl,
                                                  float (&gth)[PoP]) {
+    using LY = Layout<K, 8>;
+    static_assert(PoP == LY::PoP, "theta rows follow the kernel layout");
+#pragma unroll
+    for (int o = 0; o < PoP; ++o) gth[o] = 0.0f;      // pads stay 0
     const int k = S.k;
     const float w = S.dx, h = S.dy, d0 = S.d0, d1 = S.d1, t = S.t;
     const float iw = frcp(w);
@@ -283,8 +307,8 @@ __device__ __forceinline__ float spline_backward(const Spline<K>& S, float B, fl
     for (int m = 0; m < K; ++m) {
         const float cw = (m < k) ? cw1 : ((m == k) ? cw2 : 0.0f);
         const float ch = (m < k) ? ch1 : ((m == k) ? ch2 : 0.0f);
-        gth[m] = S.pw[m] * (cw - dotw);
-        gth[K + m] = S.ph[m] * (ch - doth);
+        gth[LY::iw(m)] = S.pw[m] * (cw - dotw);
+        gth[LY::ih(m)] = S.ph[m] * (ch - doth);
     }
     const float gd0 = G_d0 * fsigmoid(S.ud0), gd1 = G_d1 * fsigmoid(S.ud1);
 #pragma unroll
@@ -292,10 +316,8 @@ __device__ __forceinline__ float spline_backward(const Spline<K>& S, float B, fl
         float v = 0.0f;
         if (k == j + 1) v = gd0;
         if (k == j) v = gd1;
-        gth[2 * K + j] = v;
+        gth[LY::idv(j)] = v;
     }
-#pragma unroll
-    for (int o = 3 * K - 1; o < PoP; ++o) gth[o] = 0.0f;
     if (!S.inside) {
 #pragma unroll
         for (int o = 0; o < PoP; ++o) gth[o] = 0.0f;

@@ -21,6 +21,7 @@
 
 #include "../../include/nfisam_hip.h"
 #include "nsf_device.h"
+#include "nsf_split.h"
 
 using namespace nsf;
 
@@ -66,6 +67,10 @@ __device__ __forceinline__ void gsink(float* dst, float v, bool slab) {
     if (slab) *dst = v; else atomicAdd(dst, v);
 }
 __device__ __forceinline__ void gsink4(float* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
+    if (slab) {   // every destination of a 4-group is 16-byte aligned (kernel-layout rows are multiples of 4 floats)
+        *(__attribute__((ext_vector_type(4))) float*)dst = v;
+        return;
+    }
     gsink(dst + 0, v.x, slab);
     gsink(dst + 1, v.y, slab);
     gsink(dst + 2, v.z, slab);
@@ -88,7 +93,8 @@ struct TrainArgs {
     int nll_mode;
     int layer_stride;               // floats between layers in kparams/kgrad (0: kparam_count(D))
     int wl_floats;                  // LDS floats reserved for the parameter copy (WL variants)
-    int slab;                       // 1: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
+    int slab;                       // != 0: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
+    int tile;                       // host only: particles per tile (kernel family)
 };
 
 template <int K, int H, typename WP>
@@ -162,6 +168,7 @@ struct StgRows {
     static constexpr int PoP = Layout<K, H>::PoP;
     static constexpr int a = 16 * ((PoP + 15) / 16), b = PoP + 16, c = 3 * H + 16;
     static constexpr int value = (a > b ? (a > c ? a : c) : (b > c ? b : c));
+    static constexpr int split = PoP + 16 + 3 * H;      // nsf_train2_kernel: gth | h2 | pad to +16 | ga2 | ga1 | h1
 };
 
 // Lanes of ONE wave exchange data through LDS: the hardware executes a wave's LDS operations in
@@ -560,6 +567,366 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
 }
 
 // =============================================================================================
+// training / VJP kernel, two lanes per particle (nsf_split.h): a wave covers 32 particles, so the same
+// clique spreads over twice as many waves / CUs and every unit issues about half the instructions.
+// Same arguments, LDS plan and gradient sinks as nsf_train_kernel, with TILE2 / XS2 in place of TILE / XS.
+// =============================================================================================
+template <int K, int H>
+__device__ __forceinline__ void load_theta2(const float* lp, int i, const float* xin, int p, int hf,
+                                            float (&h1m)[H / 2], float (&h1o)[H / 2], float (&h2m)[H / 2],
+                                            float (&h2o)[H / 2], float (&th)[hp_of(K)]) {
+    using LY = Layout<K, H>;
+    if (i == 0) {
+        load_row<LY::HP>(lp + LY::HP * hf, th);
+    } else {
+        const float* blk = lp + LY::off(i);
+        cond_hidden2<K, H>(blk, i, xin, p, hf, h1m, h1o, h2m, h2o);
+        cond_theta2<K, H>(blk, i, hf, h2m, h2o, th);
+    }
+}
+
+template <int K, int H, bool WL>
+__global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP, HP = LY::HP, HH = H / 2;
+    constexpr int NT = (PoP + 15) / 16;                       // 16-row output tiles of gth
+    constexpr int UO = K + LY::ND0;                           // used outputs per half (the rest is padding)
+    static_assert(H == 8, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
+    const float* x = batched ? cp->x : a.single.x;
+    float* kparams = batched ? cp->kparams : a.single.kparams;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int L = a.L;
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    if (slab) G += (size_t)blockIdx.x * (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+
+    const int p0 = blockIdx.x * TILE2;
+    if (p0 >= n) return;
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int lane = threadIdx.x & 63;
+    const int hf = lane & 1, p = lane >> 1;               // half (axis) and particle of this lane
+    const int mo = HH * hf, oo = HH - mo;                 // my / the partner's hidden-unit offset
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int dim_lo = blockIdx.z * W;
+    const int dim_step = (gridDim.z > 1) ? D : W;
+    if (dim_lo >= D) return;
+    const int gp = p0 + p;
+    const bool valid = gp < n;
+    const int DT = D * XS2;
+    STAMP_DECL
+    STAMP(0);
+
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    const int dim_hi = (gridDim.z > 1) ? ((dim_lo + W < D) ? dim_lo + W : D) : D;
+    const int w_lo = (gridDim.z > 1 && dim_lo > 0) ? LY::off(dim_lo) : 0;
+    const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
+    float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only)
+    float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS2] layer inputs, dimension-major
+    float* g0 = xs + L * DT;          // [D][XS2]
+    float* g1 = g0 + DT;              // [D][XS2]
+    float* ones = g1 + DT;            // [XS2]
+    float* stg = ones + XS2 + w * (StgRows<K, H>::split * XS2);   // wave-private staging tile
+
+    // ---- prologue: all global loads first (particle tile + parameter rows), one wait, then LDS ----
+    {
+        constexpr int XB = 8, WB = 4;
+        const int nx = D * TILE2;
+        const int lim = ((n - p0) < TILE2 ? (n - p0) : TILE2) * D;
+        const float* xt = x + (size_t)p0 * D;
+        const float invD = 1.0f / (float)D;
+        const int tot4 = WL ? ((w_hi - w_lo) >> 2) : 0;
+        const f32x4* wsrc = (const f32x4*)(kparams + w_lo);
+        f32x4* wdst = (f32x4*)wlds;
+        int e0 = threadIdx.x, f0 = threadIdx.x;
+        while (e0 < nx || f0 < tot4) {
+            float xv[XB];
+            f32x4 wv[WB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                xv[u] = (e < lim) ? xt[e] : 0.0f;
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (st_stop != 0 || st_step >= a.max_iters) return;      // block-uniform
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nx) {
+                    int pq = (int)(((float)e + 0.5f) * invD);
+                    int k = e - pq * D;
+                    if (k < 0) { k += D; pq -= 1; }
+                    if (k >= D) { k -= D; pq += 1; }
+                    xs[k * XS2 + pq] = xv[u];
+                }
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    if (f < tot4) wdst[f] = wv[u];
+                }
+            }
+            e0 += XB * (int)blockDim.x;
+            f0 += WB * (int)blockDim.x;
+        }
+    }
+    if (threadIdx.x < XS2) ones[threadIdx.x] = 1.0f;
+    __syncthreads();
+
+    const float* kp;
+    if constexpr (WL) kp = wlds - w_lo; else kp = kparams;
+    STAMP(1);
+
+    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    for (int l = 0; l + 1 < L; ++l) {
+        const float* lp = kp + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        float* xout = xs + (l + 1) * DT;
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP];
+            load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
+            Spline2<K> S;
+            float z, lad;
+            spline_eval2<K, false>(xin[i * XS2 + p], th, hf, B, S, z, lad);
+            if (hf == 0) xout[i * XS2 + p] = z;
+        }
+        STAMP(10);
+        __syncthreads();
+        STAMP(11);
+    }
+
+    // ---- backward with recompute, last layer first ------------------------------------------
+    float lossv = 0.0f;
+    float* gcur = g0;
+    float* gprev = g1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const bool need_gx = (l > 0) || (a.gx != nullptr);
+        const float* lp = kp + (size_t)l * Pk;
+        float* Gl = G + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        if (need_gx) {
+            for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
+            __syncthreads();
+        }
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP], gth[HP];
+            STAMP(2);
+            load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
+            STAMP(3);
+            Spline2<K> S;
+            float z, lad;
+            spline_eval2<K, false>(xin[i * XS2 + p], th, hf, B, S, z, lad);
+            STAMP(4);
+            float gz, gl;
+            if (a.nll_mode) {
+                gl = -1.0f;
+                gz = last ? z : gcur[i * XS2 + p];
+                if (valid && hf == 0) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+            } else {
+                gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS2 + p];
+            }
+            if (!valid) { gz = 0.0f; gl = 0.0f; }
+            const float gxs = spline_backward2<K>(S, hf, B, gz, gl, gth);
+            if (need_gx && hf == 0) atomicAdd(&gprev[i * XS2 + p], gxs);
+            STAMP(5);
+
+            if (i == 0) {   // init_param: plain sum over particles of gth
+                constexpr int N0 = (HP <= 8) ? 8 : ((HP <= 16) ? 16 : 32);
+                float v[N0];
+#pragma unroll
+                for (int t = 0; t < N0; ++t) v[t] = (t < HP) ? gth[t] : 0.0f;
+                const float r = butterfly2<N0>(v, p);
+                if (p < HP) gsink(&Gl[HP * hf + p], r, slab);
+                continue;
+            }
+            const float* blk = lp + LY::off(i);
+            float* Gb = Gl + LY::off(i);
+            // ---- per-particle back-propagation through the conditioner (VALU, partial sums + DPP) ----
+            float ga2m[HH], ga1m[HH];
+            {
+                const float* W2 = blk + LY::oW2(i) + HP * hf;
+                float pm[HH], po[HH];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    float wr[HP], wo[HP];
+                    load_row<HP>(W2 + (mo + kk) * PoP, wr);
+                    load_row<HP>(W2 + (oo + kk) * PoP, wo);
+                    float am = 0.0f, ao = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < UO; ++o) {
+                        am = __builtin_fmaf(wr[o], gth[o], am);
+                        ao = __builtin_fmaf(wo[o], gth[o], ao);
+                    }
+                    pm[kk] = am; po[kk] = ao;
+                }
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    const float gh2 = pm[kk] + pswap(po[kk]);
+                    ga2m[kk] = gh2 * (1.0f - h2m[kk] * h2m[kk]);
+                }
+                const float* W1 = blk + LY::oW1(i) + mo;
+                float qm[HH], qo[HH];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    float wr[HH], wo[HH];
+                    load_row<HH>(W1 + (mo + kk) * H, wr);
+                    load_row<HH>(W1 + (oo + kk) * H, wo);
+                    float am = 0.0f, ao = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < HH; ++jj) {
+                        am = __builtin_fmaf(wr[jj], ga2m[jj], am);
+                        ao = __builtin_fmaf(wo[jj], ga2m[jj], ao);
+                    }
+                    qm[kk] = am; qo[kk] = ao;
+                }
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    const float gh1 = qm[kk] + pswap(qo[kk]);
+                    ga1m[kk] = gh1 * (1.0f - h1m[kk] * h1m[kk]);
+                }
+                if (need_gx) {
+                    const float* W0 = blk + mo;
+                    for (int k = 0; k < i; k += 2) {       // the pair splits two input columns (row i aliases b0: unused)
+                        float w0[HH], w1[HH];
+                        load_row<HH>(W0 + k * H, w0);
+                        load_row<HH>(W0 + (k + 1) * H, w1);
+                        float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < HH; ++jj) {
+                            r0 = __builtin_fmaf(w0[jj], ga1m[jj], r0);
+                            r1 = __builtin_fmaf(w1[jj], ga1m[jj], r1);
+                        }
+                        const float t0 = r0 + pswap(r0), t1 = r1 + pswap(r1);
+                        const int kk = k + hf;
+                        if (kk < i) atomicAdd(&gprev[kk * XS2 + p], hf ? t1 : t0);
+                    }
+                }
+            }
+            STAMP(6);
+            // ======== weight gradients on the matrix cores: one staging round for all three GEMMs ========
+            //   dW2t | db2 = [h2, 1]^T (x) gth ;  dW1t | db1 = [h1, 1]^T (x) ga2 ;  dW0t | db0 = [x, 1]^T (x) ga1
+            {
+                constexpr int R2 = PoP + 16;                   // first row of the ga2 | ga1 | h1 group
+#pragma unroll
+                for (int o = 0; o < HP; ++o) stg[(HP * hf + o) * XS2 + p] = gth[o];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    stg[(PoP + mo + kk) * XS2 + p] = h2m[kk];
+                    stg[(R2 + mo + kk) * XS2 + p] = ga2m[kk];
+                    stg[(R2 + H + mo + kk) * XS2 + p] = ga1m[kk];
+                    stg[(R2 + 2 * H + mo + kk) * XS2 + p] = h1m[kk];
+                }
+                wave_lds_sync();
+                // operand rows: lane&15 = feature, lane>>4 = particle within the k-group of 4; the bias column
+                // (and the unused columns beyond it) read the constant-one row
+                const float* pa = stg + r16 * XS2 + kq;                                    // gth rows 16t + r16
+                const float* pb = ((r16 < H) ? (stg + (PoP + r16) * XS2) : ones) + kq;     // [h2 | 1]
+                const float* pa2 = stg + (R2 + r16) * XS2 + kq;                            // rows 0..7 ga2, 8..15 ga1
+                const float* pb1 = ((r16 < H) ? (stg + (R2 + 2 * H + r16) * XS2) : ones) + kq;   // [h1 | 1]
+                f32x4 cacc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
+                float areg[TILE2 / 4];
+#pragma unroll
+                for (int s4 = 0; s4 < TILE2; s4 += 4) {
+                    const float b = pb[s4];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) cacc[t] = mfma4(pa[t * 16 * XS2 + s4], b, cacc[t]);
+                    areg[s4 / 4] = pa2[s4];
+                    c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
+                }
+                STAMP(7);
+                // C layout: col = lane&15 (= c), rows 4*(lane>>4)+r: four consecutive outputs per lane
+                float* Gw2 = Gb + LY::oW2(i);
+                if (slab) {
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw2[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+                    }
+                } else {
+                    // atomics: transpose through LDS to the flat order so that a wave's 64 atomics hit 256
+                    // consecutive bytes (scattered float atomics serialise in the memory pipeline)
+                    wave_lds_sync();
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) {
+                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                            }
+                    }
+                    wave_lds_sync();
+                    constexpr int TOT = (H + 1) * PoP;
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        const int f = c * 64 + lane;
+                        if (f < TOT) atomicAdd(&Gw2[f], stg[f]);
+                    }
+                }
+                // rows 0..7 (kq < 2) of c1 are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
+                if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+                // x tiles (16 input columns each); column i is the bias (ones row)
+                float* Gw0 = Gb;
+                for (int ct = 0; ct * 16 <= i; ++ct) {
+                    const int cab = ct * 16 + r16;
+                    const float* pb0 = ((cab < i) ? (xin + cab * XS2) : ones) + kq;
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < TILE2; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
+                    // rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = cab*H + j
+                    if (kq >= 2 && cab <= i) gsink4(&Gw0[cab * H + 4 * (kq - 2)], c0, slab);
+                }
+                wave_lds_sync();
+            }
+            STAMP(8);
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        float* tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
+        for (int e = threadIdx.x; e < D * TILE2; e += blockDim.x) {
+            const int pp = e / D, k = e - pp * D;
+            const int q = p0 + pp;
+            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * XS2 + pp];
+        }
+    }
+    STAMP(9);
+    if (a.nll_mode) {
+        const float tot = wave_sum(lossv);
+        if (lane == 0) {
+            float* dst = (st != nullptr) ? &st->loss_slots[(blockIdx.x * 7 + blockIdx.z * 13 + w) & 63] : a.loss_sum;
+            if (dst != nullptr) atomicAdd(dst, tot);
+        }
+    }
+}
+
+// =============================================================================================
 // Adam (torch.optim.Adam defaults, src/slam/NFiSAM.py:425,475) + loss record + window early stop
 // (NFiSAM.py:473,481-491).  One block per clique.
 // =============================================================================================
@@ -567,7 +934,7 @@ struct AdamArgs {
     const nfisam_clique* cliques;
     nfisam_clique single;
     nfisam_adam_cfg cfg;
-    int slab;               // gradient arrives as per-tile slabs (summed here in tile order)
+    int slab;               // 0: one gradient buffer; else particles per tile: per-tile slabs, summed here in tile order
     float log_b1, log_b2;   // ln(beta), computed on the host in double
     int L, K, H;
 };
@@ -593,12 +960,12 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     float slot = 0.0f;
     if (threadIdx.x < 64)
         slot = __hip_atomic_load(&st->loss_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int PoP = pad4(3 * a.K - 1);
+    const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
     // first pass's operands are requested before the state words are consumed (one round trip, not two)
     const int pj0 = threadIdx.x & 31, tl0 = threadIdx.x >> 5, jf = blockIdx.x * 32 + pj0;
-    const int n_tiles0 = a.slab ? (n + TILE - 1) / TILE : 1;
+    const int n_tiles0 = a.slab ? (n + a.slab - 1) / a.slab : 1;
     float pre_g = 0.0f, pre_m = 0.0f, pre_v = 0.0f, pre_t = 0.0f;
     if (jf < P) {
 #pragma unroll 8
@@ -623,7 +990,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     // tiles tt = tl, tl+8, ... of its parameter (independent loads, issued together), the 8 partial sums
     // are combined through LDS in a fixed order (bitwise-reproducible), lane 0 applies Adam.
     __shared__ float s_part[8][33];
-    const int n_tiles = a.slab ? (n + TILE - 1) / TILE : 1;
+    const int n_tiles = n_tiles0;
     const int pj = threadIdx.x & 31, tl = threadIdx.x >> 5;
     bool first = true;
     for (int j0 = blockIdx.x * 32; j0 < P; j0 += gridDim.x * 32) {
@@ -969,7 +1336,7 @@ extern "C" size_t nfisam_nsf_param_count(int D, int K, int H) {
     return c;
 }
 static size_t kcount(int D, int K, int H) {
-    const size_t PoP = (size_t)pad4(3 * K - 1);
+    const size_t PoP = (size_t)pop_of(K);
     const size_t kfixed = (size_t)H + (size_t)H * H + H + (size_t)H * PoP + PoP;
     return PoP + (size_t)(D - 1) * kfixed + (size_t)H * ((size_t)(D - 1) * D / 2);
 }
@@ -979,10 +1346,10 @@ extern "C" size_t nfisam_nsf_kparam_count(int D, int K, int H) {
 }
 extern "C" int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map) {
     if (D < 1 || K < 1 || H < 1 || map == nullptr) return NFISAM_ERR_ARG;
-    const int Po = 3 * K - 1, PoP = pad4(Po);
+    const int Po = 3 * K - 1, PoP = pop_of(K);
     const size_t Pk = kcount(D, K, H);
     for (size_t j = 0; j < Pk; ++j) map[j] = -1;
-    for (int o = 0; o < Po; ++o) map[o] = o;
+    for (int o = 0; o < Po; ++o) map[out_col(K, o)] = o;
     size_t toff = Po, koff = PoP;
     for (int i = 1; i < D; ++i) {
         const size_t tW0 = toff, tb0 = tW0 + (size_t)H * i, tW1 = tb0 + H, tb1 = tW1 + (size_t)H * H,
@@ -993,8 +1360,8 @@ extern "C" int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map) {
         for (int j = 0; j < H; ++j) map[kb0 + j] = (int32_t)(tb0 + j);
         for (int k = 0; k < H; ++k) for (int j = 0; j < H; ++j) map[kW1 + (size_t)k * H + j] = (int32_t)(tW1 + (size_t)j * H + k);
         for (int j = 0; j < H; ++j) map[kb1 + j] = (int32_t)(tb1 + j);
-        for (int k = 0; k < H; ++k) for (int o = 0; o < Po; ++o) map[kW2 + (size_t)k * PoP + o] = (int32_t)(tW2 + (size_t)o * H + k);
-        for (int o = 0; o < Po; ++o) map[kb2 + o] = (int32_t)(tb2 + o);
+        for (int k = 0; k < H; ++k) for (int o = 0; o < Po; ++o) map[kW2 + (size_t)k * PoP + out_col(K, o)] = (int32_t)(tW2 + (size_t)o * H + k);
+        for (int o = 0; o < Po; ++o) map[kb2 + out_col(K, o)] = (int32_t)(tb2 + o);
         toff += torch_block(i, K, H);
         koff = kb2 + PoP;
     }
@@ -1116,7 +1483,66 @@ static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, in
     return NFISAM_OK;
 }
 
+// Training kernel family, chosen per launch: "split" (two lanes per particle, 32-particle tiles) while the
+// launch leaves SIMDs idle -- it halves the instructions per wave and doubles the waves -- and "wide" (one
+// lane per particle, 64-particle tiles: no duplicated scalar spline work, half the gradient copies) once the
+// chip is full.  NFISAM_TRAIN=wide|split forces one family (A/B measurements).
+static int train_tile(int n_cliques, int max_n, int max_D) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("NFISAM_TRAIN");
+        forced = (e == nullptr) ? 0 : (strcmp(e, "wide") == 0 ? TILE : (strcmp(e, "split") == 0 ? TILE2 : 0));
+    }
+    if (forced) return forced;
+    const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
+    return waves <= 1280 ? TILE2 : TILE;
+}
+
+template <int KK, int HH, bool WL>
+static int launch_train2_variant(const TrainArgs& a, int n_cliques, int max_n, int W, int groups, size_t lds,
+                                 hipStream_t s) {
+    int rc = set_lds(nsf_train2_kernel<KK, HH, WL>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nsf_train2_kernel<KK, HH, WL>), dim3((max_n + TILE2 - 1) / TILE2, n_cliques, groups),
+                       dim3(64 * W), lds, s, a);
+    return NFISAM_OK;
+}
+
+static int launch_train2(const TrainArgs& a_in, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
+    TrainArgs a = a_in;
+    const long tiles = (long)((max_n + TILE2 - 1) / TILE2) * n_cliques;
+    // L == 1 and no dL/dx requested: the dims of a tile never exchange data, so a small (latency-bound) launch
+    // turns every (tile, dim) unit into its own single-wave block; big batches keep a tile's dims together.
+    const bool independent_dims = (a.L == 1 && a.gx == nullptr);
+    int W = pick_waves(max_D), groups = 1;
+    if (independent_dims && tiles * max_D <= 2048) { W = 1; groups = max_D; }
+    else if (independent_dims && tiles * W <= 4096) groups = (max_D + W - 1) / W;
+    NSF_DISPATCH(K, H, {
+        const size_t tile_floats = (((size_t)a.L + 2) * max_D + 1 + (size_t)W * StgRows<KK, HH>::split) * XS2;
+        const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
+        size_t wfloats = (size_t)a.L * stride;
+        if (groups > 1) {
+            const int lo = ((max_D - 1) / W) * W;            // the last group holds the largest blocks
+            wfloats = (size_t)Layout<KK, HH>::off(max_D) - (lo > 0 ? (size_t)Layout<KK, HH>::off(lo) : 0);
+            if (W >= max_D) wfloats = (size_t)Layout<KK, HH>::off(max_D);
+            const size_t first = (size_t)Layout<KK, HH>::off(W < max_D ? W : max_D);
+            if (first > wfloats) wfloats = first;
+        }
+        // the lanes of a pair read different weight rows: LDS copy whenever it fits, global loads otherwise
+        const bool wl = weights_mode() != 0 && (tile_floats + wfloats) * sizeof(float) <= 150 * 1024;
+        a.wl_floats = wl ? (int)wfloats : 0;
+        const size_t lds = (tile_floats + (wl ? wfloats : 0)) * sizeof(float);
+        int rc;
+        if (wl) rc = launch_train2_variant<KK, HH, true>(a, n_cliques, max_n, W, groups, lds, s);
+        else rc = launch_train2_variant<KK, HH, false>(a, n_cliques, max_n, W, groups, lds, s);
+        if (rc) return rc;
+    });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
 static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D, int K, int H, hipStream_t s) {
+    if (a_in.tile == TILE2) return launch_train2(a_in, n_cliques, max_n, max_D, K, H, s);
     TrainArgs a = a_in;
     const bool mf = use_mfma_grad();
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
@@ -1161,7 +1587,7 @@ static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max
 extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
                                    size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
                                    float* gx, float* loss_sum, nfisam_stream_t stream) {
-    if (D >= 1 && layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
+    if (D >= 1 && layer_stride != 0 && (layer_stride < kcount(D, K, H) || (layer_stride & 3) != 0)) return NFISAM_ERR_ARG;
     if (x == nullptr || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
         (!nll_mode && gz == nullptr))
         return NFISAM_ERR_ARG;
@@ -1175,17 +1601,28 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
     a.single.D = D;
     a.gz = gz; a.gl = gl; a.gx = gx; a.loss_sum = loss_sum;
     a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0; a.layer_stride = (int)layer_stride;
+    a.tile = train_tile(1, n, D);
     return launch_train(a, 1, n, D, K, H, (hipStream_t)stream);
 }
 
 // Small launches use per-tile gradient slabs (kgrad must then hold n_tiles copies, see
 // nfisam_nsf_grad_workspace_count); large ones accumulate with atomics into a single copy.
-static const int kSlabMaxTiles = 64;
-static bool use_slabs(int max_n) { return (max_n + TILE - 1) / TILE <= kSlabMaxTiles; }
+static int slab_max_tiles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NFISAM_SLAB_MAX_TILES");
+        v = (e != nullptr) ? atoi(e) : 128;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+static bool use_slabs(int max_n, int tile) { return (max_n + tile - 1) / tile <= slab_max_tiles(); }
 
+// Upper bound over both kernel families (the family is picked per launch from the whole batch's size).
 extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L) {
     if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
-    const size_t tiles = use_slabs(n) ? (size_t)((n + TILE - 1) / TILE) : 1;
+    const size_t tiles = use_slabs(n, TILE2) ? (size_t)((n + TILE2 - 1) / TILE2)
+                                             : (use_slabs(n, TILE) ? (size_t)((n + TILE - 1) / TILE) : 1);
     return tiles * (size_t)L * kcount(D, K, H);
 }
 
@@ -1193,7 +1630,8 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
                         int max_D, int K, int H, float B, int L, int max_iters, hipStream_t s) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
-    a.slab = use_slabs(max_n) ? 1 : 0;
+    a.tile = train_tile(n_cliques, max_n, max_D);
+    a.slab = use_slabs(max_n, a.tile) ? a.tile : 0;
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1;
@@ -1209,7 +1647,8 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
     ad.cfg = *cfg;
-    ad.slab = use_slabs(max_n) ? 1 : 0;
+    const int tile = train_tile(n_cliques, max_n, max_D);
+    ad.slab = use_slabs(max_n, tile) ? tile : 0;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H;

@@ -12,10 +12,22 @@ rng = np.random.RandomState(0)
 x = torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev)
 kp = nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, 0)).to(dev), D, K, H, L)
 tb = nh.TrainBatch([x], [kp], K, H, B, L, lr=0.01, max_iters=iters, early_stop=False)
+import time
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 if graph:
     tb.run(use_graph=True)
 else:
     for _ in range(iters):
         tb.step()
 torch.cuda.synchronize()
-print("done", tb.state())
+dt = time.perf_counter() - t0
+print("done", tb.state(), "%.2f us/iteration (host wall clock incl. graph build)" % (dt / iters * 1e6))
+if graph:
+    tb.reset() if hasattr(tb, "reset") else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tb.run(use_graph=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("second run (graph cached): %.2f us/iteration" % (dt / iters * 1e6))

@@ -59,7 +59,18 @@ def test_pack_unpack_roundtrip_and_transposes():
     assert torch.equal(nh.unpack(kb, D, K, H, L), blob)
     # spot-check: W2t[k][o] of dim i=2 equals W2[o][k]
     init, nets = O.unpack(blob[:P], D, K, H)
-    Po, PoP = 3 * K - 1, (3 * K - 1 + 3) // 4 * 4
+    Po = 3 * K - 1
+    ND0 = K // 2
+    HP = (K + ND0 + 3) // 4 * 4
+    PoP = 2 * HP
+
+    def col(o):     # reference output index -> kernel column (include/nfisam_hip.h)
+        if o < K:
+            return o
+        if o < 2 * K:
+            return HP + (o - K)
+        j = o - 2 * K
+        return K + j if j < ND0 else HP + K + (j - ND0)
     kfixed = H + H * H + H + H * PoP + PoP
     i = 2
     off = PoP + (i - 1) * kfixed + H * ((i - 1) * i // 2)
@@ -67,7 +78,7 @@ def test_pack_unpack_roundtrip_and_transposes():
     W2 = nets[i - 1][4]
     for k in (0, 3, 7):
         for o in (0, 13, 25):
-            assert kb[off + oW2 + k * PoP + o] == W2[o, k]
+            assert kb[off + oW2 + k * PoP + col(o)] == W2[o, k]
     W0 = nets[i - 1][0]
     assert kb[off + 1 * H + 5] == W0[5, 1]
 

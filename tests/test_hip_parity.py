@@ -136,15 +136,16 @@ def test_multilayer_against_oracle(n, D, K, L):
     lossc, gradc, lpc, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
     kg, gx, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
     assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L
-    grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3)
-    grad_close(gx.cpu().numpy() / n, gxc, rtol=2e-3)
+    # fp32 rounding grows with the number of chained layers (absolute tolerance relative to the largest entry)
+    grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3, atol=2e-5 * L)
+    grad_close(gx.cpu().numpy() / n, gxc, rtol=2e-3, atol=2e-5 * L)
     # generic VJP
     rng = np.random.RandomState(n)
     gz = rng.randn(n, D).astype(np.float32); gl = rng.randn(n).astype(np.float32)
     grad4, gx4 = CO.backward(x, blob, gz, gl, K, H, B, L, dtype=np.float64)
     kg2, gx2, _ = nh.backward(dev(x), kp, K, H, B, L, gz=dev(gz), gl=dev(gl), want_gx=True)
-    grad_close(nh.unpack(kg2, D, K, H, L).cpu().numpy(), grad4, rtol=2e-3, atol=5e-5)
-    grad_close(gx2.cpu().numpy(), gx4, rtol=2e-3, atol=5e-5)
+    grad_close(nh.unpack(kg2, D, K, H, L).cpu().numpy(), grad4, rtol=2e-3, atol=5e-5 * max(1, L - 1))
+    grad_close(gx2.cpu().numpy(), gx4, rtol=2e-3, atol=5e-5 * max(1, L - 1))
     # inverse of forward
     xb, ldb = nh.inverse(z, None, kp, K, H, B, L, want_logdet=True)
     inside = np.abs(x).max(1) < 4.9
@@ -331,11 +332,14 @@ def test_training_is_bitwise_reproducible_for_small_single_layer_launches():
             assert float(torch.quantile((outs[0] - outs[1]).abs(), 0.99)) < 2e-3
 
 
-def test_large_launch_uses_atomics_and_still_matches_oracle():
-    """> 64 tiles: single gradient buffer + float atomics (workspace is one copy)."""
-    K, H, B, L, n, D = 9, 8, 5.0, 1, 64 * 70, 4
+@pytest.mark.parametrize("n", [64 * 140, 64 * 300], ids=["split-kernel", "wide-kernel"])
+def test_large_launch_uses_atomics_and_still_matches_oracle(n):
+    """> 128 tiles: single gradient buffer + float atomics (workspace is one copy).  The smaller case still
+    runs the two-lanes-per-particle kernel (<= 1280 waves), the larger one the one-lane-per-particle kernel."""
+    K, H, B, L, D = 9, 8, 5.0, 1, 4
     assert nh.lib().nfisam_nsf_grad_workspace_count(n, D, K, H, L) == nh.kparam_count(D, K, H)
-    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == 32 * nh.kparam_count(D, K, H)
+    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == 63 * nh.kparam_count(D, K, H)
+    assert nh.lib().nfisam_nsf_grad_workspace_count(6000, D, K, H, L) == 94 * nh.kparam_count(D, K, H)
     blob, x = make_problem(n, D, K, H, L, seed=8, spread=1.0)
     tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, L)], K, H, B, L, lr=0.02, max_iters=5, early_stop=False)
     for _ in range(5):

@@ -148,15 +148,15 @@ int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int 
 
 /* Device-resident control block of one clique's training run. */
 typedef struct nfisam_train_state {
-    int32_t step;        /* iterations completed so far                                      */
+    int32_t step;        /* iterations completed and recorded so far (advances when a chunk is closed) */
     int32_t stop;        /* set by the device when the early-stop rule fired                 */
     int32_t have_avg;    /* a previous window mean exists                                    */
     float   loss_avg;    /* previous window mean (NFiSAM.py:481-491)                         */
     float   loss_acc;    /* (unused, kept for layout)                                         */
     int32_t domain_err;  /* non-zero if a kernel saw a non-finite loss                       */
     int32_t reserved[10];
-    float   loss_slots[64]; /* running sum_p(0.5|z|^2 - logdet) of the iteration in flight, spread over
-                               64 words so that hundreds of waves do not serialise on one address   */
+    float   loss_slots[64]; /* (unused since ABI 1100: the per-iteration loss sums live in a ring behind the
+                               gradient copies of the kgrad workspace; kept for layout)              */
 } nfisam_train_state;
 
 typedef struct nfisam_adam_cfg {
@@ -195,10 +195,10 @@ int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int c
                               int max_D, int K, int H, float B, int L, nfisam_stream_t stream);
 
 /* One full-batch training iteration of `n_cliques` independent cliques (grid.y = clique):
- * forward + analytic backward + gradient reduction, then a fused Adam update that also records
- * iter_loss[step], evaluates the reference's window early-stop rule on the device and advances
- * state->step.  Cliques whose state->stop is set or whose step reached max_iters are skipped, so
- * the call can be replayed (e.g. from a hipGraph) without host intervention.
+ * forward + analytic backward + gradient reduction, the Adam update, and a one-wave bookkeeping kernel
+ * that records iter_loss[step], evaluates the reference's window early-stop rule on the device and
+ * advances state->step.  Cliques whose state->stop is set or whose step reached max_iters are skipped,
+ * so the call can be replayed without host intervention.
  * `cliques` is a DEVICE array unless n_cliques==1 and `cliques_on_host` is non-zero.
  * All cliques share K, H, B, L and the Adam configuration; n and D may differ.             */
 int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
@@ -206,9 +206,10 @@ int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliqu
                           nfisam_stream_t stream);
 
 /* Convenience loop == the `for i in range(flow_iterations)` loop of NFiSAM.fit_clique_density_model
- * (slam/NFiSAM.py:451-491) for a batch of independent cliques.  Enqueues iterations in chunks of
- * `average_window` (captured once as a hipGraph and replayed) and SYNCHRONISES WITH THE HOST after
- * each chunk to read the stop flags.  host_cliques: HOST array of descriptors (device pointers
+ * (slam/NFiSAM.py:451-491) for a batch of independent cliques.  Enqueues iterations in chunks (the
+ * largest divisor of `average_window` that is <= 128; 50 without early stopping): 2 kernels per iteration
+ * plus one bookkeeping kernel per chunk -- the only writer of state->step / stop -- captured once as a
+ * hipGraph and replayed, and SYNCHRONISES WITH THE HOST after each chunk to read the stop flags.  host_cliques: HOST array of descriptors (device pointers
  * inside); dev_cliques: the same array in device memory.  iters_run[n_cliques] (host) receives the
  * iterations each clique ran.                                                                */
 int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,

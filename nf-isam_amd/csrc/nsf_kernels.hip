@@ -95,6 +95,7 @@ struct TrainArgs {
     int wl_floats;                  // LDS floats reserved for the parameter copy (WL variants)
     int slab;                       // != 0: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
     int tile;                       // host only: particles per tile (kernel family)
+    int iter_idx;                   // iteration index inside the chunk (state->step advances once per chunk)
 };
 
 template <int K, int H, typename WP>
@@ -162,6 +163,10 @@ extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
 #endif
 
 constexpr int XS = 66;            // LDS row stride (floats) of every [feature][particle] tile
+// Per-iteration loss sums live behind the gradient slabs in the kgrad workspace: a ring of LOSS_RING
+// iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
+// bookkeeping kernel that closes a chunk of iterations consumes and clears them.
+constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
 // staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operand up to row PoP+15
 template <int K, int H>
 struct StgRows {
@@ -206,7 +211,9 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int L = a.L;
     const float B = a.B;
     const bool slab = a.slab != 0;
-    if (slab) G += (size_t)blockIdx.x * (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    const size_t gstride = (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    float* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
+    if (slab) G += (size_t)blockIdx.x * gstride;
 
     const int p0 = blockIdx.x * TILE;
     if (p0 >= n) return;
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (st_stop != 0 || st_step >= a.max_iters) return;      // block-uniform (first consumer of the state loads)
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform (first consumer of the state loads)
 #pragma unroll
             for (int u = 0; u < XB; ++u) {
                 const int e = e0 + u * (int)blockDim.x;
@@ -560,7 +567,9 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     if (a.nll_mode) {
         const float tot = wave_sum(lossv);
         if (lane == 0) {
-            float* dst = (st != nullptr) ? &st->loss_slots[(blockIdx.x * 7 + blockIdx.z * 13 + w) & 63] : a.loss_sum;
+            float* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                   ((blockIdx.x * 7 + blockIdx.z * 13 + w) & (LOSS_SLOTS - 1))]
+                                         : a.loss_sum;
             if (dst != nullptr) atomicAdd(dst, tot);
         }
     }
@@ -605,7 +614,9 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
     const int L = a.L;
     const float B = a.B;
     const bool slab = a.slab != 0;
-    if (slab) G += (size_t)blockIdx.x * (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    const size_t gstride = (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    float* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
+    if (slab) G += (size_t)blockIdx.x * gstride;
 
     const int p0 = blockIdx.x * TILE2;
     if (p0 >= n) return;
@@ -665,7 +676,7 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
                     wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (st_stop != 0 || st_step >= a.max_iters) return;      // block-uniform
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform
 #pragma unroll
             for (int u = 0; u < XB; ++u) {
                 const int e = e0 + u * (int)blockDim.x;
@@ -920,7 +931,9 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
     if (a.nll_mode) {
         const float tot = wave_sum(lossv);
         if (lane == 0) {
-            float* dst = (st != nullptr) ? &st->loss_slots[(blockIdx.x * 7 + blockIdx.z * 13 + w) & 63] : a.loss_sum;
+            float* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                   ((blockIdx.x * 7 + blockIdx.z * 13 + w) & (LOSS_SLOTS - 1))]
+                                         : a.loss_sum;
             if (dst != nullptr) atomicAdd(dst, tot);
         }
     }
@@ -937,29 +950,25 @@ struct AdamArgs {
     int slab;               // 0: one gradient buffer; else particles per tile: per-tile slabs, summed here in tile order
     float log_b1, log_b2;   // ln(beta), computed on the host in double
     int L, K, H;
+    int iter_idx;           // iteration index inside the chunk
+    int chunk;              // bookkeeping kernel: iterations to close
+    int max_n;              // largest n of the batch (number of slabs in every workspace)
 };
 
 __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
-    // grid = (ADAM_BLOCKS, n_cliques).  Every block reads step/stop at its start; the block that
-    // finishes LAST (ticket) does the per-iteration bookkeeping, so no block can observe a step or
-    // stop value written during the same launch.
+    // grid = (ADAM_BLOCKS, n_cliques).  state->step / stop only change in the bookkeeping kernel that closes a
+    // chunk, never during this launch, so every block derives the same iteration number t.
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
     float* theta = batched ? cp->kparams : a.single.kparams;
     float* m = batched ? cp->adam_m : a.single.adam_m;
     float* v = batched ? cp->adam_v : a.single.adam_v;
     float* G = batched ? cp->kgrad : a.single.kgrad;
-    float* iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
     nfisam_train_state* st = batched ? cp->state : a.single.state;
     const int n = batched ? cp->n : a.single.n;
     const int D = batched ? cp->D : a.single.D;
 
-    __shared__ int s_step, s_stop, s_last;
-    // Every block fetches the 64 loss slots right away (they were completed by the previous kernel, and
-    // only the block that turns out to be last uses / zeroes them): the latency overlaps the parameter loads.
-    float slot = 0.0f;
-    if (threadIdx.x < 64)
-        slot = __hip_atomic_load(&st->loss_slots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int s_step, s_stop;
     const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
@@ -977,8 +986,8 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (s_stop != 0 || s_step >= a.cfg.max_iters) return;
-    const int t = s_step + 1;
+    const int t = s_step + a.iter_idx + 1;
+    if (s_stop != 0 || t > a.cfg.max_iters) return;
 
     const float b1 = a.cfg.beta1, b2 = a.cfg.beta2;
     const float bc1 = -expm1f((float)t * a.log_b1);
@@ -1021,40 +1030,64 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         __syncthreads();
         first = false;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(&st->reserved[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (ticket == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // last block: per-iteration bookkeeping (loss record, window early stop, step counter)
-    float acc = 0.0f;
-    if (threadIdx.x < 64) {
-        st->loss_slots[threadIdx.x] = 0.0f;
-        acc = wave_sum(slot);
-    }
-    if (threadIdx.x == 0) {
-        st->reserved[0] = 0;
-        const float loss = acc * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
-        iter_loss[t - 1] = loss;
+}
+
+// Closes a chunk of iterations (one wave per clique): turns the ring's loss sums into iter_loss entries
+// (NFiSAM.py:473), evaluates the window early-stop rule (NFiSAM.py:481-491) and advances state->step.
+// It is the only writer of step / stop, and it runs alone between chunks: the training and Adam kernels of a
+// chunk all see the same state.
+__global__ void __launch_bounds__(64) nsf_bookkeep_kernel(AdamArgs a) {
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    float* iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int lane = threadIdx.x;
+    const int s0 = st->step;
+    if (st->stop != 0 || s0 >= a.cfg.max_iters) return;
+    const int cnt = (a.chunk < a.cfg.max_iters - s0) ? a.chunk : (a.cfg.max_iters - s0);
+    const int PoP = pop_of(a.K);
+    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
+    const size_t P = (size_t)a.L * (size_t)(PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
+    const size_t copies = a.slab ? (size_t)((a.max_n + a.slab - 1) / a.slab) : (size_t)1;
+    float* ring = G + copies * P;
+    const float inv_n = 1.0f / (float)n;
+    const int wnd = a.cfg.average_window;
+    for (int it = 0; it < cnt; ++it) {
+        float* slot = ring + ((s0 + it) & (LOSS_RING - 1)) * LOSS_SLOTS;
+        const float part = slot[lane];
+        slot[lane] = 0.0f;
+        const float loss = wave_sum(part) * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
+        const int t = s0 + it + 1;
         int stop = 0;
-        if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; stop = 1; }
-        const int wnd = a.cfg.average_window;
-        if (wnd > 0 && (t % wnd) == 0) {
-            float s = loss;
-            for (int j = t - wnd; j < t - 1; ++j) s += iter_loss[j];
-            const float nw = s / (float)wnd;
-            if (st->have_avg != 0 && st->loss_avg != 0.0f) {
-                const float delta = fabsf(1.0f - nw / st->loss_avg);
-                if (delta < a.cfg.loss_delta_tol) stop = 1;
+        if (lane == 0) {
+            iter_loss[t - 1] = loss;
+            if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; stop = 1; }
+            if (wnd > 0 && (t % wnd) == 0) {
+                float s = loss;
+                for (int j = t - wnd; j < t - 1; ++j) s += iter_loss[j];
+                const float nw = s / (float)wnd;
+                if (st->have_avg != 0 && st->loss_avg != 0.0f) {
+                    const float delta = fabsf(1.0f - nw / st->loss_avg);
+                    if (delta < a.cfg.loss_delta_tol) stop = 1;
+                }
+                st->loss_avg = nw;
+                st->have_avg = 1;
             }
-            st->loss_avg = nw;
-            st->have_avg = 1;
         }
-        if (stop) st->stop = 1;
-        st->step = t;
+        stop = __shfl(stop, 0, 64);
+        if (stop) {
+            if (lane == 0) { st->stop = 1; st->step = t; }
+            // later iterations of this chunk were already applied by the Adam launches (the chunk length
+            // divides the window, so the rule can only fire on a chunk's last iteration; a non-finite loss
+            // ends the run anyway): clear their sums and leave
+            for (int r = it + 1; r < cnt; ++r) ring[((s0 + r) & (LOSS_RING - 1)) * LOSS_SLOTS + lane] = 0.0f;
+            return;
+        }
     }
+    if (lane == 0) st->step = s0 + cnt;
 }
 
 // =============================================================================================
@@ -1319,7 +1352,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
         else return NFISAM_ERR_ARG;                                 \
     } while (0)
 
-extern "C" int nfisam_abi_version(void) { return 1000; }
+extern "C" int nfisam_abi_version(void) { return 1100; }
 extern "C" int nfisam_last_hip_error(void) { return g_last_hip_error; }
 extern "C" int nfisam_nsf_supported(int K, int H) {
     return (H == 8 && (K == 5 || K == 6 || K == 9 || K == 12)) ? 1 : 0;
@@ -1623,26 +1656,23 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
     const size_t tiles = use_slabs(n, TILE2) ? (size_t)((n + TILE2 - 1) / TILE2)
                                              : (use_slabs(n, TILE) ? (size_t)((n + TILE - 1) / TILE) : 1);
-    return tiles * (size_t)L * kcount(D, K, H);
+    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS;
 }
 
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                        int max_D, int K, int H, float B, int L, int max_iters, hipStream_t s) {
+                        int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.tile = train_tile(n_cliques, max_n, max_D);
     a.slab = use_slabs(max_n, a.tile) ? a.tile : 0;
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
-    a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1;
+    a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
     return launch_train(a, n_cliques, max_n, max_D, K, H, s);
 }
 
-static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                        int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, hipStream_t s) {
-    int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, s);
-    if (rc) return rc;
-    AdamArgs ad;
+static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques,
+                           int max_n, int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg) {
     memset(&ad, 0, sizeof(ad));
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
@@ -1651,7 +1681,18 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     ad.slab = use_slabs(max_n, tile) ? tile : 0;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
-    ad.L = L; ad.K = K; ad.H = H;
+    ad.L = L; ad.K = K; ad.H = H; ad.max_n = max_n;
+}
+
+// iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel
+static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                        int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
+                        hipStream_t s) {
+    int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s);
+    if (rc) return rc;
+    AdamArgs ad;
+    fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
+    ad.iter_idx = iter_idx;
     // 32 parameters per block (x 8 tile-lanes); a few hundred small blocks spread the latency-bound work
     const size_t Pmax = (size_t)L * kcount(max_D, K, H);
     int ablocks = (int)((Pmax + 31) / 32);
@@ -1660,6 +1701,27 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
+}
+
+// closes a chunk of `chunk` iterations: loss record, early-stop rule, step counter
+static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                               int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s) {
+    AdamArgs ad;
+    fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
+    ad.chunk = chunk;
+    hipLaunchKernelGGL(nsf_bookkeep_kernel, dim3(n_cliques), dim3(64), 0, s, ad);
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+// Iterations per chunk: the early-stop rule is evaluated when a chunk is closed, so the chunk length has to
+// divide the window (the rule then only ever fires on a chunk's last iteration, as in the reference loop).
+static int chunk_length(const nfisam_adam_cfg* cfg) {
+    const int wnd = cfg->average_window;
+    if (wnd <= 0) return 50;
+    int c = wnd < LOSS_RING ? wnd : LOSS_RING;
+    while (wnd % c != 0) --c;
+    return c;
 }
 
 static int check_cfg(const nfisam_adam_cfg* cfg, int K, int H, int L, float B) {
@@ -1677,9 +1739,9 @@ extern "C" int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cli
         return NFISAM_ERR_ARG;
     if (cliques_on_host) {
         if (n_cliques != 1) return NFISAM_ERR_ARG;
-        return enqueue_grad(nullptr, cliques, 1, max_n, max_D, K, H, B, L, 0x7fffffff, (hipStream_t)stream);
+        return enqueue_grad(nullptr, cliques, 1, max_n, max_D, K, H, B, L, 0x7fffffff, 0, (hipStream_t)stream);
     }
-    return enqueue_grad(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, 0x7fffffff, (hipStream_t)stream);
+    return enqueue_grad(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, 0x7fffffff, 0, (hipStream_t)stream);
 }
 
 extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
@@ -1688,11 +1750,12 @@ extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques
     int rc = check_cfg(cfg, K, H, L, B);
     if (rc) return rc;
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1) return NFISAM_ERR_ARG;
-    if (cliques_on_host) {
-        if (n_cliques != 1) return NFISAM_ERR_ARG;
-        return enqueue_step(nullptr, cliques, 1, max_n, max_D, K, H, B, L, cfg, (hipStream_t)stream);
-    }
-    return enqueue_step(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, cfg, (hipStream_t)stream);
+    const nfisam_clique* dev = cliques_on_host ? nullptr : cliques;
+    const nfisam_clique* single = cliques_on_host ? cliques : nullptr;
+    if (cliques_on_host && n_cliques != 1) return NFISAM_ERR_ARG;
+    rc = enqueue_step(dev, single, n_cliques, max_n, max_D, K, H, B, L, cfg, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return enqueue_bookkeeping(dev, single, n_cliques, max_n, max_D, K, H, L, cfg, 1, (hipStream_t)stream);
 }
 
 // ---- training plan: descriptors + (optionally) a hipGraph of `chunk` iterations, built once ----
@@ -1730,7 +1793,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     p->host.assign(host_cliques, host_cliques + n_cliques);
     p->dev = dev_cliques;
     p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
-    p->chunk = (cfg->average_window > 0) ? cfg->average_window : 50;
+    p->chunk = chunk_length(cfg);
     p->hst.resize(n_cliques);
     for (int c = 0; c < n_cliques; ++c) {
         if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { delete p; return NFISAM_ERR_ARG; }
@@ -1746,7 +1809,10 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         if (e == hipSuccess) {
             const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
             for (int it = 0; it < p->chunk && status == NFISAM_OK; ++it)
-                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, p->cap);
+                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap);
+            if (status == NFISAM_OK)
+                status = enqueue_bookkeeping(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
+                                             p->cap);
             e = hipStreamEndCapture(p->cap, &p->graph);
         }
         if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
@@ -1778,9 +1844,12 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
         } else {
             for (int it = 0; it < p->chunk; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
-                                      &p->cfg, work);
+                                      &p->cfg, it, work);
                 if (rc) return rc;
             }
+            int rcb = enqueue_bookkeeping(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
+                                          p->chunk, work);
+            if (rcb) return rcb;
         }
         done += p->chunk;
         for (int c = 0; c < p->n_cliques; ++c)

@@ -1036,7 +1036,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
 // (NFiSAM.py:473), evaluates the window early-stop rule (NFiSAM.py:481-491) and advances state->step.
 // It is the only writer of step / stop, and it runs alone between chunks: the training and Adam kernels of a
 // chunk all see the same state.
-__global__ void __launch_bounds__(64) nsf_bookkeep_kernel(AdamArgs a) {
+__global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
     float* G = batched ? cp->kgrad : a.single.kgrad;
@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(64) nsf_bookkeep_kernel(AdamArgs a) {
     nfisam_train_state* st = batched ? cp->state : a.single.state;
     const int n = batched ? cp->n : a.single.n;
     const int D = batched ? cp->D : a.single.D;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s0 = st->step;
     if (st->stop != 0 || s0 >= a.cfg.max_iters) return;
     const int cnt = (a.chunk < a.cfg.max_iters - s0) ? a.chunk : (a.cfg.max_iters - s0);
@@ -1055,39 +1055,53 @@ __global__ void __launch_bounds__(64) nsf_bookkeep_kernel(AdamArgs a) {
     float* ring = G + copies * P;
     const float inv_n = 1.0f / (float)n;
     const int wnd = a.cfg.average_window;
-    for (int it = 0; it < cnt; ++it) {
+    __shared__ float s_loss[LOSS_RING];
+    __shared__ float s_wsum[4];
+    // all iterations of the chunk at once: wave w sums the slots of iterations w, w+4, ... (independent loads)
+    for (int it = w; it < cnt; it += 4) {
         float* slot = ring + ((s0 + it) & (LOSS_RING - 1)) * LOSS_SLOTS;
         const float part = slot[lane];
         slot[lane] = 0.0f;
         const float loss = wave_sum(part) * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
-        const int t = s0 + it + 1;
-        int stop = 0;
-        if (lane == 0) {
-            iter_loss[t - 1] = loss;
-            if (!(loss == loss) || fabsf(loss) > 3.0e38f) { st->domain_err = 1; stop = 1; }
-            if (wnd > 0 && (t % wnd) == 0) {
-                float s = loss;
-                for (int j = t - wnd; j < t - 1; ++j) s += iter_loss[j];
-                const float nw = s / (float)wnd;
-                if (st->have_avg != 0 && st->loss_avg != 0.0f) {
-                    const float delta = fabsf(1.0f - nw / st->loss_avg);
-                    if (delta < a.cfg.loss_delta_tol) stop = 1;
-                }
-                st->loss_avg = nw;
-                st->have_avg = 1;
+        if (lane == 0) { s_loss[it] = loss; iter_loss[s0 + it] = loss; }
+    }
+    __syncthreads();
+    // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)
+    int bad_at = cnt;
+    for (int it = threadIdx.x; it < cnt; it += blockDim.x) {
+        const float l = s_loss[it];
+        if (!(l == l) || fabsf(l) > 3.0e38f) bad_at = (it < bad_at) ? it : bad_at;
+    }
+    bad_at = __reduce_min_sync(~0ull, bad_at);                 // per wave
+    __shared__ int s_bad[4];
+    if (lane == 0) s_bad[w] = bad_at;
+    __syncthreads();
+    bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
+    if (bad_at < cnt) {
+        if (threadIdx.x == 0) { st->domain_err = 1; st->stop = 1; st->step = s0 + bad_at + 1; }
+        return;
+    }
+    const int t_end = s0 + cnt;
+    if (wnd > 0 && (t_end % wnd) == 0) {        // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
+        float s = 0.0f;
+        for (int j = t_end - wnd + (int)threadIdx.x; j < t_end; j += blockDim.x)
+            s += (j >= s0) ? s_loss[j - s0] : iter_loss[j];
+        s = wave_sum(s);
+        if (lane == 0) s_wsum[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float nw = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) / (float)wnd;
+            int stop = 0;
+            if (st->have_avg != 0 && st->loss_avg != 0.0f) {
+                const float delta = fabsf(1.0f - nw / st->loss_avg);
+                if (delta < a.cfg.loss_delta_tol) stop = 1;
             }
-        }
-        stop = __shfl(stop, 0, 64);
-        if (stop) {
-            if (lane == 0) { st->stop = 1; st->step = t; }
-            // later iterations of this chunk were already applied by the Adam launches (the chunk length
-            // divides the window, so the rule can only fire on a chunk's last iteration; a non-finite loss
-            // ends the run anyway): clear their sums and leave
-            for (int r = it + 1; r < cnt; ++r) ring[((s0 + r) & (LOSS_RING - 1)) * LOSS_SLOTS + lane] = 0.0f;
-            return;
+            st->loss_avg = nw;
+            st->have_avg = 1;
+            if (stop) st->stop = 1;
         }
     }
-    if (lane == 0) st->step = s0 + cnt;
+    if (threadIdx.x == 0) st->step = t_end;
 }
 
 // =============================================================================================
@@ -1709,7 +1723,7 @@ static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_cl
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
     ad.chunk = chunk;
-    hipLaunchKernelGGL(nsf_bookkeep_kernel, dim3(n_cliques), dim3(64), 0, s, ad);
+    hipLaunchKernelGGL(nsf_bookkeep_kernel, dim3(n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
 }
@@ -1769,7 +1783,8 @@ struct nfisam_train_plan {
     hipEvent_t ev = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    std::vector<nfisam_train_state> hst;
+    nfisam_train_state* hst = nullptr;     // pinned host copy of the cliques' states
+    bool contiguous = false;               // the states form one device array: one copy per chunk
 };
 
 extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
@@ -1778,6 +1793,7 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->ev) (void)hipEventDestroy(p->ev);
     if (p->cap) (void)hipStreamDestroy(p->cap);
+    if (p->hst) (void)hipHostFree(p->hst);
     delete p;
     return NFISAM_OK;
 }
@@ -1794,9 +1810,14 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     p->dev = dev_cliques;
     p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
     p->chunk = chunk_length(cfg);
-    p->hst.resize(n_cliques);
+    if (hipHostMalloc((void**)&p->hst, sizeof(nfisam_train_state) * (size_t)n_cliques, hipHostMallocDefault) != hipSuccess) {
+        delete p;
+        return NFISAM_ERR_LAUNCH;
+    }
+    p->contiguous = true;
     for (int c = 0; c < n_cliques; ++c) {
-        if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { delete p; return NFISAM_ERR_ARG; }
+        if (host_cliques[c].state != host_cliques[0].state + c) p->contiguous = false;
+        if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { nfisam_nsf_train_plan_destroy(p); return NFISAM_ERR_ARG; }
         p->max_n = host_cliques[c].n > p->max_n ? host_cliques[c].n : p->max_n;
         p->max_D = host_cliques[c].D > p->max_D ? host_cliques[c].D : p->max_D;
     }
@@ -1826,6 +1847,19 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     return NFISAM_OK;
 }
 
+static hipError_t read_states(nfisam_train_plan* p, hipStream_t work) {
+    hipError_t e = hipSuccess;
+    if (p->contiguous) {
+        e = hipMemcpyAsync(p->hst, p->host[0].state, sizeof(nfisam_train_state) * (size_t)p->n_cliques,
+                           hipMemcpyDeviceToHost, work);
+    } else {
+        for (int c = 0; c < p->n_cliques && e == hipSuccess; ++c)
+            e = hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost, work);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(work);
+    return e;
+}
+
 extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_run, nfisam_stream_t stream) {
     if (p == nullptr) return NFISAM_ERR_ARG;
     hipStream_t user = (hipStream_t)stream;
@@ -1852,10 +1886,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
             if (rcb) return rcb;
         }
         done += p->chunk;
-        for (int c = 0; c < p->n_cliques; ++c)
-            HIP_TRY(hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost,
-                                   work));
-        HIP_TRY(hipStreamSynchronize(work));
+        HIP_TRY(read_states(p, work));
         read_back = true;
         bool all_stopped = true;
         for (int c = 0; c < p->n_cliques; ++c) {
@@ -1864,12 +1895,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
         }
         if (all_stopped || status != NFISAM_OK) break;
     }
-    if (!read_back) {
-        for (int c = 0; c < p->n_cliques; ++c)
-            HIP_TRY(hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost,
-                                   work));
-        HIP_TRY(hipStreamSynchronize(work));
-    }
+    if (!read_back) HIP_TRY(read_states(p, work));
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;
 }

@@ -1265,6 +1265,7 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_pos
     const bool valid = p < n;
     const size_t pp = valid ? (size_t)p : 0;
     float* xs = smem;                       // [Dmax][TILE]
+    int zoff = 0;                           // latent rows are consumed in walk order
     for (int c = 0; c < n_cliques; ++c) {
         const nfisam_post_clique q = table[c];
         const int n_obs = q.n_obs, Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
@@ -1285,7 +1286,7 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_pos
                 float h1[H], h2[H], th[PoP];
                 load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
                 // layer L-1 consumes the latent draw; lower layers consume the previous layer's output
-                const float zin = (l == L - 1) ? Zt[(size_t)cols[q.front_off + (i - Ds)] * n + pp] : xs[i * TILE + lane];
+                const float zin = (l == L - 1) ? Zt[(size_t)(zoff + (i - Ds)) * n + pp] : xs[i * TILE + lane];
                 Spline<K> S;
                 float xi, lad;
                 spline_eval<K, PoP, true>(zin, th, B, S, xi, lad);
@@ -1297,7 +1298,180 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_pos
             if (circ[i]) v = wrap_pi(v);
             if (valid) St[(size_t)cols[q.front_off + (i - Ds)] * n + p] = v;
         }
+        zoff += q.n_frontal;
         // the next clique may read the columns just written by THIS lane only: program order suffices
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same walk, latency-engineered for trees of hundreds of small cliques (one trained flow each, all
+// parameters cold): a wave covers 32 samples with two lanes per sample (nsf_split.h), and while it computes
+// clique c from LDS it has the parameters, normalisation constants, column indices and latent draws of clique
+// c+1 in flight into registers (software pipeline, one LDS double buffer per wave).  Only the separator
+// samples (produced by the ancestors a moment earlier) are read on the critical path.
+// ---------------------------------------------------------------------------------------------
+struct WalkArgs {
+    const nfisam_post_clique* table;
+    const int32_t* cols;
+    const float* obs;
+    const float* Zt;
+    float* St;
+    float B;
+    int n_cliques, L, n;
+    int wmax;      // floats of one parameter buffer
+    int dmax;      // largest clique dimension
+};
+
+template <int K, int H>
+__device__ __forceinline__ int walk_range_start(int Ds) { return Ds > 0 ? Layout<K, H>::off(Ds) : 0; }
+
+// A 64-byte clique descriptor fetched as 16 dwords by lanes 0..15 (vector memory: returns in order with the
+// other prefetch loads, unlike a scalar load that every later LDS wait would have to wait for), made
+// wave-uniform with readlane.
+__device__ __forceinline__ int desc_fetch(const nfisam_post_clique* e, int lane) {
+    return (lane < 16) ? ((const int*)e)[lane] : 0;
+}
+__device__ __forceinline__ nfisam_post_clique desc_uniform(int tw) {
+    static_assert(sizeof(nfisam_post_clique) == 64, "descriptor is 16 dwords");
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = __builtin_amdgcn_readlane(tw, k);
+    nfisam_post_clique q;
+    __builtin_memcpy(&q, d, sizeof(q));
+    return q;
+}
+
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_posterior_walk2_kernel(WalkArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int HP = LY::HP, HH = H / 2;
+    constexpr int R = 8;                       // float4 of parameters in flight per lane
+    constexpr int FP = 4;                      // latent columns in flight per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int hf = lane & 1, p = lane >> 1;
+    const int gp = blockIdx.x * TILE2 + p;
+    const bool valid = gp < a.n;
+    const size_t pp = valid ? (size_t)gp : 0;
+    const int n = a.n, L = a.L, dmax = a.dmax;
+    const float B = a.B;
+    float* wb = smem;                                   // [2][wmax] parameters of the current / next clique
+    float* aux = wb + 2 * (size_t)a.wmax;               // [2][4][dmax]: mean, std, circular, obs
+    int* colb = (int*)(aux + 8 * dmax);                 // [2][dmax] separator then frontal column indices
+    float* zb = (float*)(colb + 2 * dmax);              // [2][dmax][XS2] latent draws
+    float* xs = zb + 2 * dmax * XS2;                    // [dmax][XS2] row being reconstructed
+
+    // ---- clique 0: plain synchronous loads into buffer 0 ------------------------------------------
+    nfisam_post_clique q = a.table[0];
+    {
+        const int Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const int start = walk_range_start<K, H>(Ds), len = LY::off(D) - start, Pk = LY::count(q.D_model);
+        const int len4 = len >> 2;
+        for (int l = 0; l < L; ++l) {
+            const f32x4* src = (const f32x4*)(q.kparams + (size_t)l * Pk + start);
+            f32x4* dst = (f32x4*)(wb + (size_t)l * len);
+            for (int f = lane; f < len4; f += 64) dst[f] = src[f];
+        }
+        if (lane < D) {
+            aux[lane] = q.mean[lane]; aux[dmax + lane] = q.std[lane]; aux[2 * dmax + lane] = q.circular[lane] ? 1.0f : 0.0f;
+        }
+        if (lane < q.n_obs) aux[3 * dmax + lane] = a.obs[q.obs_off + lane];
+        if (lane < q.n_sep + q.n_frontal) colb[lane] = a.cols[q.sep_off + lane];
+        for (int j = 0; j < q.n_frontal; ++j) if (hf == 0) zb[j * XS2 + p] = a.Zt[(size_t)j * n + pp];
+    }
+    nfisam_post_clique qn = q;
+    if (a.n_cliques > 1) qn = desc_uniform(desc_fetch(a.table + 1, lane));
+    wave_lds_sync();
+    int zoff = 0;
+    for (int c = 0; c < a.n_cliques; ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        const int n_obs = q.n_obs, Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const float* ax = aux + cur * 4 * dmax;
+        const int* cl = colb + cur * dmax;
+        const bool more = (c + 1 < a.n_cliques);
+        // ---- 1. given columns: true observations, then the separator samples written by the ancestors.  The
+        //         even lane of a pair is the one that wrote them (program order makes them visible to it).
+        for (int k = 0; k < Ds; ++k) {
+            float v = 0.0f;
+            if (k < n_obs) v = ax[3 * dmax + k];
+            else if (hf == 0) v = a.St[(size_t)cl[k - n_obs] * n + pp];
+            const float d = v - ax[k];
+            if (hf == 0) xs[k * XS2 + p] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+        }
+        wave_lds_sync();
+        // ---- 2. next clique: everything that does not depend on this one goes in flight now ----------
+        const int tw2 = (c + 2 < a.n_cliques) ? desc_fetch(a.table + c + 2, lane) : 0;
+        const int nDs = qn.n_obs + qn.n_sep, nD = nDs + qn.n_frontal;
+        const int nstart = walk_range_start<K, H>(nDs), nlen = LY::off(nD) - nstart, nPk = LY::count(qn.D_model);
+        const int nlen4 = nlen >> 2, ntot4 = more ? L * nlen4 : 0;
+        f32x4 pf[R];
+        float pm = 0.0f, ps = 1.0f, pc = 0.0f, po = 0.0f, pz[FP];
+        int pcol = 0;
+        const int nz0 = zoff + q.n_frontal;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int f = lane + 64 * r;
+            pf[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < ntot4) {
+                const int l = f / nlen4, o = f - l * nlen4;
+                pf[r] = ((const f32x4*)(qn.kparams + (size_t)l * nPk + nstart))[o];
+            }
+        }
+        if (more) {
+            if (lane < nD) { pm = qn.mean[lane]; ps = qn.std[lane]; pc = qn.circular[lane] ? 1.0f : 0.0f; }
+            if (lane < qn.n_obs) po = a.obs[qn.obs_off + lane];
+            if (lane < qn.n_sep + qn.n_frontal) pcol = a.cols[qn.sep_off + lane];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) pz[j] = (j < qn.n_frontal) ? a.Zt[(size_t)(nz0 + j) * n + pp] : 0.0f;
+        }
+        // ---- 3. this clique, from LDS only --------------------------------------------------------------
+        {
+            const int start = walk_range_start<K, H>(Ds), len = LY::off(D) - start;
+            const float* zc = zb + cur * dmax * XS2;
+            for (int l = L - 1; l >= 0; --l) {
+                const float* lp = wb + (size_t)cur * a.wmax + (size_t)l * len - start;
+                for (int i = Ds; i < D; ++i) {
+                    float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP];
+                    load_theta2<K, H>(lp, i, xs, p, hf, h1m, h1o, h2m, h2o, th);
+                    const float zin = (l == L - 1) ? zc[(i - Ds) * XS2 + p] : xs[i * XS2 + p];
+                    Spline2<K> S;
+                    float xi, lad;
+                    spline_eval2<K, true>(zin, th, hf, B, S, xi, lad);
+                    if (hf == 0) xs[i * XS2 + p] = xi;
+                    wave_lds_sync();
+                }
+            }
+            for (int i = Ds; i < D; ++i) {
+                float v = xs[i * XS2 + p] * ax[dmax + i] + ax[i];
+                if (ax[2 * dmax + i] != 0.0f) v = wrap_pi(v);
+                if (valid && hf == 0) a.St[(size_t)cl[q.n_sep + (i - Ds)] * n + gp] = v;
+            }
+        }
+        zoff = nz0;
+        // ---- 4. land the next clique's data in the other buffer -----------------------------------------
+        if (more) {
+            float* wn = wb + (size_t)nxt * a.wmax;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int f = lane + 64 * r;
+                if (f < ntot4) ((f32x4*)wn)[f] = pf[r];          // layer l at l*nlen: f = l*nlen4 + o
+            }
+            for (int f = lane + 64 * R; f < ntot4; f += 64) {      // big cliques: the rest, synchronously
+                const int l = f / nlen4, o = f - l * nlen4;
+                ((f32x4*)wn)[f] = ((const f32x4*)(qn.kparams + (size_t)l * nPk + nstart))[o];
+            }
+            float* an = aux + nxt * 4 * dmax;
+            if (lane < nD) { an[lane] = pm; an[dmax + lane] = ps; an[2 * dmax + lane] = pc; }
+            if (lane < qn.n_obs) an[3 * dmax + lane] = po;
+            if (lane < qn.n_sep + qn.n_frontal) colb[nxt * dmax + lane] = pcol;
+            float* zn = zb + nxt * dmax * XS2;
+#pragma unroll
+            for (int j = 0; j < FP; ++j) if (j < qn.n_frontal && hf == 0) zn[j * XS2 + p] = pz[j];
+            for (int j = FP; j < qn.n_frontal; ++j) if (hf == 0) zn[j * XS2 + p] = a.Zt[(size_t)(nz0 + j) * n + pp];
+            wave_lds_sync();
+        }
+        q = qn;
+        if (c + 2 < a.n_cliques) qn = desc_uniform(tw2);
     }
 }
 
@@ -1472,12 +1646,28 @@ extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_
         L < 1 || !(B > 0))
         return NFISAM_ERR_ARG;
     if (n == 0 || n_cliques == 0) return NFISAM_OK;
-    const size_t lds = (size_t)max_D * TILE * sizeof(float);
     NSF_DISPATCH(K, H, {
-        int rc = set_lds(nsf_posterior_walk_kernel<KK, HH>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((nsf_posterior_walk_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
-                           (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, Zt, St);
+        // pipelined two-lanes-per-sample walk when its LDS double buffer fits (a clique needs at most the
+        // parameter blocks of all its max_D dims), else the plain one-lane-per-sample walk
+        const size_t wmax = (size_t)L * (size_t)Layout<KK, HH>::off(max_D);
+        const size_t lds2 = (2 * wmax + 8 * (size_t)max_D + 2 * (size_t)max_D + (size_t)3 * max_D * XS2) * sizeof(float);
+        const char* walk_env = getenv("NFISAM_WALK");          // "plain" forces the one-lane walk (tests, A/B)
+        const bool force_plain = (walk_env != nullptr && strcmp(walk_env, "plain") == 0);
+        if (lds2 <= 150 * 1024 && max_D <= 64 && !force_plain) {
+            int rc = set_lds(nsf_posterior_walk2_kernel<KK, HH>, lds2);
+            if (rc) return rc;
+            WalkArgs wa;
+            wa.table = table; wa.cols = cols; wa.obs = obs; wa.Zt = Zt; wa.St = St; wa.B = B;
+            wa.n_cliques = n_cliques; wa.L = L; wa.n = n; wa.wmax = (int)wmax; wa.dmax = max_D;
+            hipLaunchKernelGGL((nsf_posterior_walk2_kernel<KK, HH>), dim3((n + TILE2 - 1) / TILE2), dim3(64), lds2,
+                               (hipStream_t)stream, wa);
+        } else {
+            const size_t lds = (size_t)max_D * TILE * sizeof(float);
+            int rc = set_lds(nsf_posterior_walk_kernel<KK, HH>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_posterior_walk_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
+                               (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, Zt, St);
+        }
     });
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

@@ -88,8 +88,8 @@ class BayesTreeNode(object):
         return isinstance(other, BayesTreeNode) and self.frontal == other.frontal and self.separator == other.separator
 
     def __hash__(self) -> int:
-        return hash((tuple(sorted(str(v.name) for v in self.separator)),
-                     tuple(sorted(str(v.name) for v in self.frontal))))
+        # order-independent over the two variable sets (consistent with __eq__); no sorting, no strings
+        return hash(frozenset(self.frontal)) ^ (hash(frozenset(self.separator)) * 1000003)
 
 
 class BayesTree(object):

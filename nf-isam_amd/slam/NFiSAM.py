@@ -397,41 +397,54 @@ class NFiSAM(FactorGraphSolver):
         start = time.time()
         num_samples = self._args.posterior_sample_num
         order = self._elimination_ordering
-        col0, off = {}, 0
+        # every variable owns a permanent column range of the sample matrix (assigned when first seen), so a
+        # clique's column indices never change and are cached on its model together with the device pointers
+        pcol = self.__dict__.setdefault("_post_col", {})
+        total_dim = self.__dict__.get("_post_total", 0)
         for v in order:
-            col0[v] = off
-            off += v.dim
-        total_dim = off
+            if v not in pcol:
+                pcol[v] = total_dim
+                total_dim += v.dim
+        self._post_total = total_dim
         cliques, stack = [], [self._physical_bayes_tree.root]
         while stack:
             c = stack.pop()
             cliques.append(c)
             stack.extend(c.children)
-        table = np.zeros(len(cliques), dtype=_nh.POST_DTYPE)
-        cols, obs, cfg, device, max_D = [], [], None, None, 1
+        rows, cols, obs, cfg, device, max_D = [], [], [], None, None, 1
         rmap = self._reverse_ordering_map
-        for j, clique in enumerate(cliques):
+        for clique in cliques:
             model = self._clique_density_model[clique]
-            st = model.posterior_static()
+            e = model.__dict__.get("_post_entry")
+            if e is None:
+                st = model.posterior_static()
+                o = np.asarray(self._clique_true_obs[clique], dtype=np.float32).ravel()
+                sep = [pcol[v] + k for v in sorted(clique.separator, key=rmap.__getitem__) for k in range(v.dim)]
+                fro = [pcol[v] + k for v in sorted(clique.frontal, key=rmap.__getitem__) for k in range(v.dim)]
+                row = np.zeros(1, dtype=_nh.POST_DTYPE)
+                row["kparams"], row["mean"], row["std"], row["circular"] = st["ptrs"]
+                row["D_model"] = st["D_model"]
+                row["n_obs"], row["n_sep"], row["n_frontal"] = o.size, len(sep), len(fro)
+                e = dict(row=row, cols=np.asarray(sep + fro, dtype=np.int32), obs=o, cfg=st["cfg"], device=st["device"],
+                         D_model=st["D_model"])
+                model.__dict__["_post_entry"] = e
             if cfg is None:
-                cfg, device = st["cfg"], st["device"]
-            elif cfg != st["cfg"]:
+                cfg, device = e["cfg"], e["device"]
+            elif cfg != e["cfg"]:
                 raise NotImplementedError("the tree walk needs one (K, H, B, L) for all cliques")
-            row = table[j]
-            row["kparams"], row["mean"], row["std"], row["circular"] = st["ptrs"]
-            row["D_model"] = st["D_model"]
-            o = np.asarray(self._clique_true_obs[clique], dtype=np.float64).ravel()
-            sep = [col0[v] + k for v in sorted(clique.separator, key=rmap.__getitem__) for k in range(v.dim)]
-            fro = [col0[v] + k for v in sorted(clique.frontal, key=rmap.__getitem__) for k in range(v.dim)]
-            row["n_obs"], row["n_sep"], row["n_frontal"] = o.size, len(sep), len(fro)
-            row["obs_off"] = len(obs); obs.extend(o.tolist())
-            row["sep_off"] = len(cols); cols.extend(sep)
-            row["front_off"] = len(cols); cols.extend(fro)
-            max_D = max(max_D, st["D_model"])
+            rows.append(e["row"]); cols.append(e["cols"]); obs.append(e["obs"])
+            if e["D_model"] > max_D:
+                max_D = e["D_model"]
+        table = np.concatenate(rows)
+        n_obs, n_sep = table["n_obs"].astype(np.int64), table["n_sep"].astype(np.int64)
+        n_col = n_sep + table["n_frontal"]
+        table["obs_off"] = np.cumsum(n_obs) - n_obs
+        table["sep_off"] = np.cumsum(n_col) - n_col
+        table["front_off"] = table["sep_off"] + n_sep
         K, H, B, L = cfg
-        S = _nh.posterior_walk_raw(table, np.asarray(cols, dtype=np.int32), np.asarray(obs, dtype=np.float32),
-                                   total_dim, num_samples, max_D, K, H, B, L, device).cpu().numpy()
-        samples = {v: S[:, col0[v]:col0[v] + v.dim] for v in order}
+        S = _nh.posterior_walk_raw(table, np.concatenate(cols), np.concatenate(obs), total_dim, num_samples, max_D,
+                                   K, H, B, L, device).cpu().numpy()
+        samples = {v: S[:, pcol[v]:pcol[v] + v.dim] for v in order}
         if timer is not None:
             timer.append(time.time() - start)
         return samples

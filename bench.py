@@ -13,7 +13,7 @@ A "step" is ONE full-batch training iteration (forward + analytic backward + gra
 no data-path collective: independent cliques never exchange data).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
-  roofline     : dominant kernel (nsf_train_kernel) algorithmic FLOP / its average launch
+  roofline     : dominant kernel (nsf_train2_kernel) algorithmic FLOP / its average launch
                  duration, measured live with HIP events, against the fp32 peak of gfx950
                  (157.3 TFLOP/s = f32 MFMA peak = f32 packed-VALU peak).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
@@ -295,12 +295,13 @@ def main():
             "final_loss": float(il[-1]), "first_loss": float(il[0]),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "nsf_train_kernel<9,8>", "kernel_us": kern_us,
+                         "kernel": "nsf_train2_kernel<9,8,true>", "kernel_us": kern_us,
                          "flop_per_launch": launch_flops,
                          "note": "fp32 VALU/transcendental-issue-bound kernel, latency-bound on this single-clique "
-                                 "workload (189 MFLOP per launch = 1.2 us at peak; 7 dependent unit passes per "
-                                 "wave); priced against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 "
-                                 "VALU). Algorithmic HBM bytes: 98 KB (x) + 110 KB parameters per launch."},
+                                 "workload (189 MFLOP per launch = 1.2 us at peak; 128 tiles x 6 waves on 128 of "
+                                 "256 CUs, 7 dependent unit passes per wave); priced against the fp32 peak "
+                                 "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU). Algorithmic HBM bytes: 98 KB (x) + "
+                                 "110 KB parameters per launch."},
         }
         if args.no_update_bench:
             out["wall_clock_per_incremental_update"] = None

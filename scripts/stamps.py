@@ -11,8 +11,9 @@ n, D, L, K, H, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 9, 8, 5
 rng = np.random.RandomState(0)
 x = torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev)
 kp = nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, 0)).to(dev), D, K, H, L)
+tb = nh.TrainBatch([x], [kp], K, H, B, L, lr=0.01, max_iters=100000, early_stop=False)   # per-tile slab path, as in training
 for _ in range(3):
-    nh.backward(x, kp, K, H, B, L, nll_mode=True)
+    tb.gradient_only()
 torch.cuda.synchronize()
 init = (C.c_ulonglong * (64 * 32))()
 init[63 * 32 + 20] = 2 ** 63
@@ -21,7 +22,7 @@ lib = nh.lib()
 sym = ctypes.c_void_p.in_dll(lib, "g_stamps") if False else None
 # reset min/max slots through a tiny torch kernel is not possible for a __device__ symbol: run once more after zeroing via hipMemcpyToSymbol
 lib.nfisam_debug_write_stamps(init)
-nh.backward(x, kp, K, H, B, L, nll_mode=True)
+tb.gradient_only()
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 32))()
 assert nh.lib().nfisam_debug_read_stamps(buf) == 0
@@ -46,7 +47,7 @@ for w in range(min(D, 8) if L > 1 else D):
 blk = (C.c_ulonglong * (4096 * 2))()
 assert nh.lib().nfisam_debug_read_blocks(blk) == 0
 bt = np.array(blk[:], dtype=np.int64).reshape(4096, 2)
-nb = ((n + 63) // 64) * (D if L == 1 else 1)
+nb = ((n + 31) // 32) * (D if L == 1 else 1)
 bt = bt[:nb]
 t0 = bt[:, 0].min()
 start = (bt[:, 0] - t0) / 100.0

@@ -16,10 +16,10 @@ seed = int(os.environ.get('SEED', '0'))
 np.random.seed(seed); torch.manual_seed(seed)
 dataset = os.environ.get("DATASET", "Plaza1EFG")
 nodes, truth, factors = graph_file_parser(os.path.join(ROOT, "tests", "data", dataset, "factor_graph.fg"), "fg")
-steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=5)
-args = NFiSAMArgs(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
-                  cuda_training=True, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
-                  average_window=50)
+steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(os.environ.get("STEP", "5")))
+args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000")), local_sample_num=2000,
+                  learning_rate=.01, hidden_dim=8, cuda_training=True, elimination_method="pose_first",
+                  training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50)
 solver = NFiSAM(args)
 rows = []
 t_all = time.time()

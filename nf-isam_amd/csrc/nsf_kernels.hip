@@ -2063,16 +2063,18 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     int status = NFISAM_OK, done = 0;
     bool read_back = false;
     while (done < p->cfg.max_iters) {
-        if (p->exec) {
+        const int left = p->cfg.max_iters - done;
+        const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
+        if (p->exec && todo == p->chunk) {
             HIP_TRY(hipGraphLaunch(p->exec, work));
         } else {
-            for (int it = 0; it < p->chunk; ++it) {
+            for (int it = 0; it < todo; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
                                       &p->cfg, it, work);
                 if (rc) return rc;
             }
             int rcb = enqueue_bookkeeping(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
-                                          p->chunk, work);
+                                          todo, work);
             if (rcb) return rcb;
         }
         done += p->chunk;

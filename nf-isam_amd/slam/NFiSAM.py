@@ -305,26 +305,43 @@ class NFiSAM(FactorGraphSolver):
             raise ValueError("no kernel instantiation for num_knots=%d, hidden_dim=%d" % (K, H))
         kp0 = torch.cat([_nh.pack(init_reference_blob(aug_clique_dim, K, H, device), aug_clique_dim, K, H, 1)
                          for _ in range(L)])
-        x_dev = training_data.to(device).contiguous()
         logger = logging.getLogger("flows on clique")
 
         opt_start = time.time()
-        tb = _nh.TrainBatch([x_dev], [kp0], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
-                            average_window=a.average_window, loss_delta_tol=a.loss_delta_tol,
-                            early_stop=(testing_data is None))
         if testing_data is None:
+            # Training plans (device buffers + the captured hipGraph of one chunk of iterations) are kept per
+            # clique shape and re-used: the batch and the fresh parameters are copied into the plan's buffers,
+            # Adam moments / state / loss record are cleared in place.
+            n_train = int(training_data.shape[0])
+            key = (n_train, aug_clique_dim, K, H, L, float(a.learning_rate), int(a.flow_iterations),
+                   int(a.average_window), float(a.loss_delta_tol), str(device))
+            plans = self.__dict__.setdefault("_train_plans", {})
+            tb = plans.get(key)
+            if tb is None:
+                tb = _nh.TrainBatch([torch.empty(n_train, aug_clique_dim, dtype=torch.float32, device=device)],
+                                    [torch.zeros_like(kp0)], K, H, B, L, lr=a.learning_rate,
+                                    max_iters=a.flow_iterations, average_window=a.average_window,
+                                    loss_delta_tol=a.loss_delta_tol, early_stop=True)
+                plans[key] = tb
+            tb.xs[0].copy_(training_data)
+            tb.reset(kparams=[kp0])
             iters = tb.run(use_graph=True)[0]
             if iters < a.flow_iterations:
                 logger.info(f"Early stopping at iter {iters}")
+            keep_plan = True
         else:
+            x_dev = training_data.to(device).contiguous()
+            tb = _nh.TrainBatch([x_dev], [kp0], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                                average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
             f0 = NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, kp0)
             iters = self._fit_with_validation(tb, testing_data.to(device).contiguous(), f0, logger)
+            keep_plan = False
         torch.cuda.synchronize()
         opt_end = time.time()
         if timer is not None:
             timer.append(opt_end - opt_start)
         Pk = _nh.kparam_count(aug_clique_dim, K, H)
-        trained = tb.kparams[0]
+        trained = tb.kparams[0].clone() if keep_plan else tb.kparams[0]
         flows = [NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, trained[l * Pk:(l + 1) * Pk]) for l in range(L)]
         normal_clique = CustomMultivariateNormal(dim=aug_clique_dim, device=device)
         normal_separator = CustomMultivariateNormal(dim=aug_separator_dim, device=device) \
@@ -335,7 +352,8 @@ class NFiSAM(FactorGraphSolver):
         clique_name = ''.join([str(var.name) for var in clique.vars])
         self._temp_training_loss[clique_name] = [float(v) for v in tb.iter_loss[0].cpu().numpy().astype(np.float64)]
         self.last_fit_iterations = iters
-        tb.close()
+        if not keep_plan:
+            tb.close()
         return model
 
     def _fit_with_validation(self, tb, testing_data, f0, logger):
@@ -425,8 +443,8 @@ class NFiSAM(FactorGraphSolver):
                 row["kparams"], row["mean"], row["std"], row["circular"] = st["ptrs"]
                 row["D_model"] = st["D_model"]
                 row["n_obs"], row["n_sep"], row["n_frontal"] = o.size, len(sep), len(fro)
-                e = dict(row=row, cols=np.asarray(sep + fro, dtype=np.int32), obs=o, cfg=st["cfg"], device=st["device"],
-                         D_model=st["D_model"])
+                e = dict(row=row.tobytes(), cols=np.asarray(sep + fro, dtype=np.int32), obs=o, cfg=st["cfg"],
+                         device=st["device"], D_model=st["D_model"])
                 model.__dict__["_post_entry"] = e
             if cfg is None:
                 cfg, device = e["cfg"], e["device"]
@@ -435,7 +453,7 @@ class NFiSAM(FactorGraphSolver):
             rows.append(e["row"]); cols.append(e["cols"]); obs.append(e["obs"])
             if e["D_model"] > max_D:
                 max_D = e["D_model"]
-        table = np.concatenate(rows)
+        table = np.frombuffer(b"".join(rows), dtype=_nh.POST_DTYPE).copy()
         n_obs, n_sep = table["n_obs"].astype(np.int64), table["n_sep"].astype(np.int64)
         n_col = n_sep + table["n_frontal"]
         table["obs_off"] = np.cumsum(n_obs) - n_obs

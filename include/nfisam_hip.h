@@ -129,7 +129,8 @@ typedef struct nfisam_post_clique {
  * launch: for every clique in `table` order (root first) sample its frontal columns conditioned on its
  * true observations and on the separator columns sampled earlier, exactly as n_cliques successive
  * conditional_sample_given_observation calls would (slam/NFiSAM.py:120-155), but without leaving
- * the device.  Zt[total_dim][n]: standard-normal draws, St[total_dim][n]: output samples, both
+ * the device.  Zt[total_dim][n]: standard-normal draws, consumed in WALK order (the j-th frontal column of
+ * clique c takes row sum_{c'<c} n_frontal(c') + j), St[total_dim][n]: output samples (rows = columns of `cols`), both
  * COLUMN-major; cols/obs: device arrays indexed by the table; max_D: largest D_model.        */
 int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs,
                               int max_D, int K, int H, float B, int L, int n, const float* Zt, float* St,
@@ -179,7 +180,8 @@ typedef struct nfisam_clique {
     int32_t n, D;
 } nfisam_clique;
 
-/* Floats the `kgrad` workspace of a clique must hold when the largest clique of its batch has n
+/* Floats the `kgrad` workspace of a clique must hold (gradient copies + a ring of 128 x 64 per-iteration
+ * loss words behind them) when the largest clique of its batch has n
  * particles: launches of <= 128 particle tiles write per-tile partial gradients with plain stores and
  * the Adam kernel sums them in tile order (no atomics); larger ones accumulate with float atomics
  * into a single copy.  A tile is 32 particles (two-lanes-per-particle kernel, launches that leave
@@ -188,7 +190,7 @@ size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
 /* The gradient half of a training iteration on its own (forward + analytic backward + reduction into
  * each clique's `kgrad` workspace and loss slots, exactly the kernel `nfisam_nsf_train_step` launches
- * first; no Adam update, no bookkeeping, state->stop / step are still honoured).  With <= 64 tiles the
+ * first; no Adam update, no bookkeeping, state->stop / step are still honoured).  With <= 128 tiles the
  * workspace is overwritten (per-tile slabs), so repeated calls are idempotent: bench.py times this
  * entry to price the dominant kernel; callers with their own optimiser use it as the gradient oracle. */
 int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,

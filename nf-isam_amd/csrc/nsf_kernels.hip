@@ -1603,7 +1603,8 @@ static int set_lds(KernelT kernel, size_t bytes) {
 extern "C" int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
                                   int L, size_t layer_stride, float* z, float* logdet, float* logprob,
                                   nfisam_stream_t stream) {
-    if (x == nullptr || kparams == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0)) return NFISAM_ERR_ARG;
+    // an empty batch may come with null data pointers
+    if ((n != 0 && x == nullptr) || kparams == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0)) return NFISAM_ERR_ARG;
     if (layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
     if (n == 0) return NFISAM_OK;
     const int W = pick_waves(D);
@@ -1623,7 +1624,7 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
                                   const float* stdv, const uint8_t* circular, float* x_out, float* logdet,
                                   nfisam_stream_t stream) {
     if (D >= 1 && layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
-    if (z == nullptr || kparams == nullptr || x_out == nullptr || n < 0 || D < 1 || Ds < 0 || Ds >= D || L < 1 ||
+    if ((n != 0 && (z == nullptr || x_out == nullptr)) || kparams == nullptr || n < 0 || D < 1 || Ds < 0 || Ds >= D || L < 1 ||
         !(B > 0) || (Ds > 0 && x_sep == nullptr) || (mean != nullptr && stdv == nullptr))
         return NFISAM_ERR_ARG;
     if (n == 0) return NFISAM_OK;
@@ -1725,12 +1726,11 @@ static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, in
 // lane per particle, 64-particle tiles: no duplicated scalar spline work, half the gradient copies) once the
 // chip is full.  NFISAM_TRAIN=wide|split forces one family (A/B measurements).
 static int train_tile(int n_cliques, int max_n, int max_D) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("NFISAM_TRAIN");
-        forced = (e == nullptr) ? 0 : (strcmp(e, "wide") == 0 ? TILE : (strcmp(e, "split") == 0 ? TILE2 : 0));
+    const char* e = getenv("NFISAM_TRAIN");            // read per call: tests switch families in-process
+    if (e != nullptr) {
+        if (strcmp(e, "wide") == 0) return TILE;
+        if (strcmp(e, "split") == 0) return TILE2;
     }
-    if (forced) return forced;
     const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
     return waves <= 1280 ? TILE2 : TILE;
 }
@@ -1825,7 +1825,7 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
                                    size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
                                    float* gx, float* loss_sum, nfisam_stream_t stream) {
     if (D >= 1 && layer_stride != 0 && (layer_stride < kcount(D, K, H) || (layer_stride & 3) != 0)) return NFISAM_ERR_ARG;
-    if (x == nullptr || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
+    if ((n != 0 && x == nullptr) || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
         (!nll_mode && gz == nullptr))
         return NFISAM_ERR_ARG;
     if (n == 0) return NFISAM_OK;

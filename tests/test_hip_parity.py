@@ -50,6 +50,22 @@ def grad_close(got, ref, rtol=1e-3, atol=2e-5):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol * max(1.0, float(np.abs(ref).max())))
 
 
+@pytest.fixture(params=["auto", "wide", "split"])
+def family(request):
+    """Training-kernel family: chosen per launch by the library ("auto": two lanes per particle for these
+    small launches), or forced through NFISAM_TRAIN (read per call)."""
+    old = os.environ.get("NFISAM_TRAIN")
+    if request.param == "auto":
+        os.environ.pop("NFISAM_TRAIN", None)
+    else:
+        os.environ["NFISAM_TRAIN"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("NFISAM_TRAIN", None)
+    else:
+        os.environ["NFISAM_TRAIN"] = old
+
+
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[4:-4] for p in CASES])
 class TestAgainstReferenceGolden:
     def test_forward(self, path):
@@ -62,7 +78,7 @@ class TestAgainstReferenceGolden:
         # the reference's own (scrambled) return value is the fixed permutation of ours
         np.testing.assert_allclose(z.cpu().numpy().T.reshape(-1).reshape(n, D), g["z_raw"], atol=Z_ATOL)
 
-    def test_nll_gradients(self, path):
+    def test_nll_gradients(self, path, family):
         g, n, D, K, H, B = load(path)
         kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
         kg, _, loss = nh.backward(dev(g["x"]), kp, K, H, B, nll_mode=True)
@@ -73,7 +89,7 @@ class TestAgainstReferenceGolden:
         # padding entries of the kernel layout never receive gradient
         assert float(kg[torch.from_numpy(nh.layout_map(D, K, H) < 0).to(DEV)].abs().sum()) == 0.0
 
-    def test_adam_trajectory(self, path):
+    def test_adam_trajectory(self, path, family):
         g, n, D, K, H, B = load(path)
         kp = kpack(O.blob_from_state_dict(sd_of(g, "p0"), D), D, K, H)
         tb = nh.TrainBatch([dev(g["x"])], [kp], K, H, B, 1, lr=float(g["adam_lr"]), max_iters=10, early_stop=False)
@@ -122,9 +138,12 @@ def make_problem(n, D, K, H, L, seed, spread=1.6):
     return blob.numpy().astype(np.float32), x.numpy().astype(np.float32)
 
 
-@pytest.mark.parametrize("n,D,K,L", [(100, 5, 6, 2), (333, 6, 9, 4), (70, 12, 9, 3), (64, 1, 9, 2), (129, 20, 5, 1)])
-def test_multilayer_against_oracle(n, D, K, L):
-    """No usable multi-layer reference exists: parity is against the oracle."""
+@pytest.mark.parametrize("n,D,K,L", [(100, 5, 6, 2), (333, 6, 9, 4), (70, 12, 9, 3), (64, 1, 9, 2), (129, 20, 5, 1),
+                                     (1, 4, 9, 2), (33, 3, 12, 1), (90, 30, 9, 2)])
+def test_multilayer_against_oracle(n, D, K, L, family):
+    """No usable multi-layer reference exists: parity is against the oracle.  (1, 4, 9, 2): a single
+    particle; (33, 3, 12, 1): one particle past a 32-tile; (90, 30, 9, 2): the parameters of all layers do not fit
+    in LDS next to the tiles, so the two-lane kernel reads them from global memory.)"""
     H, B = 8, 5.0
     blob, x = make_problem(n, D, K, H, L, seed=n + D)
     kp = kpack(blob, D, K, H, L)
@@ -150,14 +169,15 @@ def test_multilayer_against_oracle(n, D, K, L):
     xb, ldb = nh.inverse(z, None, kp, K, H, B, L, want_logdet=True)
     inside = np.abs(x).max(1) < 4.9
     # autoregressive inversion propagates fp32 error of early dims into later ones (through the
-    # conditioners) and divides by the local slope: the round trip is checked at 3e-3, the direct
-    # comparisons above and below at 1e-4
-    np.testing.assert_allclose(xb.cpu().numpy()[inside], x[inside], atol=3e-3)
+    # conditioners) and divides by the local slope: the round trip is checked at 3e-3 (growing with the
+    # length of the chain beyond 10 dims), the direct comparisons above and below at 1e-4
+    chain = max(1.0, D / 10.0)
+    np.testing.assert_allclose(xb.cpu().numpy()[inside], x[inside], atol=3e-3 * chain)
     xo, _ = CO.inverse(zc, None, blob, K, H, B, L, dtype=np.float64)
     xh = nh.inverse(dev(zc.astype(np.float32)), None, kp, K, H, B, L)
-    np.testing.assert_allclose(xh.cpu().numpy()[inside], xo[inside], atol=3e-3)
+    np.testing.assert_allclose(xh.cpu().numpy()[inside], xo[inside], atol=3e-3 * chain)
     # round trip of L*D chained splines: reconstruction error times |d logdet/dx| accumulates
-    np.testing.assert_allclose((ld + ldb).cpu().numpy()[inside], 0, atol=2e-3 * L)
+    np.testing.assert_allclose((ld + ldb).cpu().numpy()[inside], 0, atol=2e-3 * L * chain)
 
 
 def test_conditional_sampling_with_fused_normalisation():
@@ -367,3 +387,51 @@ def test_large_launch_uses_atomics_and_still_matches_oracle(n):
     np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy(), lc, atol=5e-4, rtol=2e-4)
     err = np.abs(nh.unpack(tb.kparams[0], D, K, H).cpu().numpy() - bc)
     assert np.quantile(err, 0.99) < 2e-3
+
+
+def test_empty_batch_and_domain_error():
+    """n = 0 is a no-op (NFISAM_OK); a non-finite training batch ends the run with NFISAM_ERR_DOMAIN
+    (reference: `ValueError("Input outside domain")` / the discriminant assert, src/flows/utils.py:74-76,133)."""
+    K, H, B, L, D = 9, 8, 5.0, 1, 4
+    blob, x = make_problem(64, D, K, H, L, seed=1)
+    kp = kpack(blob, D, K, H, L)
+    z, ld, _ = nh.forward(torch.zeros(0, D, device=DEV), kp, K, H, B, L)
+    assert z.shape == (0, D) and ld.shape == (0,)
+    xi = nh.inverse(torch.zeros(0, D, device=DEV), None, kp, K, H, B, L)
+    assert xi.shape == (0, D)
+    bad = x.copy()
+    bad[3, 1] = np.nan
+    tb = nh.TrainBatch([dev(bad)], [kp.clone()], K, H, B, L, lr=0.02, max_iters=100, average_window=50)
+    with pytest.raises(RuntimeError, match="domain"):
+        tb.run(use_graph=True)
+    st = tb.state()
+    assert st["domain_err"] == 1 and st["stop"] == 1 and st["step"] == 1      # stopped at the first bad iteration
+
+
+def test_posterior_walk_single_clique_and_wide_root():
+    """Edge cases of the pipelined walk: a tree of one clique (no prefetch stage at all) and a root whose parameter
+    range exceeds what one wave keeps in flight (8 float4 per lane): the remainder is loaded synchronously."""
+    K, H, B, L, n = 9, 8, 5.0, 1, 77
+    rng = np.random.RandomState(3)
+    for D, n_obs in ((16, 0), (5, 2)):
+        blob, _ = make_problem(8, D, K, H, L, seed=D)
+        kp = kpack(blob, D, K, H, L)
+        mean = dev(rng.randn(D)); std = dev(0.5 + rng.rand(D))
+        circ = torch.from_numpy((rng.rand(D) < 0.3).astype(np.uint8)).to(DEV)
+        obs = rng.randn(n_obs)
+        F = D - n_obs
+        cols = list(rng.permutation(F))
+        leaf = dict(kparams=kp, mean=mean, std=std, circular=circ, D_model=D, obs=obs, sep_cols=[], front_cols=cols)
+        # the second tree puts a small clique in front of the wide one, so that the wide one arrives through the prefetch path
+        small_blob, _ = make_problem(8, 2, K, H, L, seed=99)
+        small = dict(kparams=kpack(small_blob, 2, K, H, L), mean=dev(np.zeros(2)), std=dev(np.ones(2)),
+                     circular=torch.zeros(2, dtype=torch.uint8, device=DEV), D_model=2, obs=np.zeros(0), sep_cols=[],
+                     front_cols=[F, F + 1])
+        for entries, total, zrow in (([leaf], F, 0), ([small, leaf], F + 2, 2)):
+            Zt = torch.from_numpy(rng.randn(total, n).astype(np.float32)).to(DEV)
+            S = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
+            given = dev(np.tile(obs, (n, 1))) if n_obs else None
+            ref = nh.inverse(Zt[zrow:zrow + F].t().contiguous(), given, kp, K, H, B, L, mean=mean, std=std, circular=circ,
+                             model_D=D)
+            err = np.abs(S[:, cols].cpu().numpy() - ref.cpu().numpy())
+            assert np.quantile(err, 0.99) < 2e-5 and err.max() < 1e-3, (D, len(entries), err.max())

@@ -136,6 +136,14 @@ int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, co
                               int max_D, int K, int H, float B, int L, int n, const float* Zt, float* St,
                               nfisam_stream_t stream);
 
+/* Training-batch normalisation on the device (NFiSAM.normalize_training_samples, src/slam/NFiSAM.py:515-548):
+ * per column c of x[n,D]: Euclidean -> mean / population std; circular[c] != 0 -> mean = direction of the mean
+ * resultant (scipy.stats.circmean(., high=pi, low=-pi)), deviations wrapped to [-pi, pi), std of the wrapped
+ * deviations; std clipped at 1e-5.  x_out[n,D] = (wrapped) deviation / std, mean[D], std[D].  Sums in double.
+ * `circular` may be NULL (all Euclidean); x_out may alias x.                                             */
+int nfisam_normalize_columns(const float* x, int n, int D, const uint8_t* circular, float* x_out, float* mean,
+                             float* std, nfisam_stream_t stream);
+
 /* ---- training -------------------------------------------------------------------------- */
 /* Vector-Jacobian product of the L-layer flow (what torch autograd computes for
  * `loss.backward()` in slam/NFiSAM.py:474): kgrad[L*kparam_count] += d<gz,z>/dtheta + d<gl,logdet>/dtheta,

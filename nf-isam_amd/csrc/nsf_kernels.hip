@@ -1476,6 +1476,70 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk2_kernel(WalkArgs a) {
 }
 
 // =============================================================================================
+// training-batch normalisation (reference: NFiSAM.normalize_training_samples,
+// src/slam/NFiSAM.py:515-548): per column, Euclidean -> (x - mean) / std; circular -> mu = direction of the
+// mean resultant (scipy.stats.circmean(., high=pi, low=-pi)), wrap(x - mu) / std(wrapped); population std
+// (ddof = 0), clipped at 1e-5.  One block per column; sums in double (the reference works in float64).
+// =============================================================================================
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();                  // sh may still be read from the previous reduction
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(256) nsf_normalize_kernel(const float* __restrict__ x, int n, int D,
+                                                            const uint8_t* __restrict__ circ, float* __restrict__ xn,
+                                                            float* __restrict__ mean, float* __restrict__ stdv) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    const bool circular = circ != nullptr && circ[c] != 0;
+    const double inv_n = 1.0 / (double)n;
+    double mu;
+    if (circular) {
+        double ss = 0.0, cs = 0.0;
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            const double v = (double)x[(size_t)r * D + c];
+            ss += sin(v); cs += cos(v);
+        }
+        ss = block_sum(ss, sh);
+        cs = block_sum(cs, sh);
+        mu = atan2(ss, cs);
+        if (mu >= 3.141592653589793238463) mu -= 6.283185307179586476925;      // [-pi, pi) as theta_to_pipi
+    } else {
+        double s = 0.0;
+        for (int r = threadIdx.x; r < n; r += blockDim.x) s += (double)x[(size_t)r * D + c];
+        mu = block_sum(s, sh) * inv_n;
+    }
+    const double two_pi = 6.283185307179586476925, pi = 3.141592653589793238463;
+    // second pass: (wrapped) deviations, their mean and variance (the wrapped deviations of an angle column are
+    // not centred exactly, and numpy's std subtracts their mean)
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        double d = (double)x[(size_t)r * D + c] - mu;
+        if (circular) { d = fmod(d + pi, two_pi); if (d < 0.0) d += two_pi; d -= pi; }
+        s1 += d; s2 += d * d;
+    }
+    s1 = block_sum(s1, sh) * inv_n;
+    s2 = block_sum(s2, sh) * inv_n;
+    double var = s2 - s1 * s1;
+    if (var < 0.0) var = 0.0;
+    double sd = sqrt(var);
+    if (sd < 1e-5) sd = 1e-5;
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        double d = (double)x[(size_t)r * D + c] - mu;
+        if (circular) { d = fmod(d + pi, two_pi); if (d < 0.0) d += two_pi; d -= pi; }
+        xn[(size_t)r * D + c] = (float)(d / sd);
+    }
+    if (threadIdx.x == 0) { mean[c] = (float)mu; stdv[c] = (float)sd; }
+}
+
+// =============================================================================================
 // elementwise spline with per-element logits in memory (flows.utils.unconstrained_RQS / RQS,
 // src/flows/utils.py:25-164).  Runtime K: the logits are streamed twice (softmax statistics, then
 // cumulative knots + bin selection) so no per-lane arrays are needed.  HBM/latency-bound helper of
@@ -1670,6 +1734,15 @@ extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_
                                (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, Zt, St);
         }
     });
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+extern "C" int nfisam_normalize_columns(const float* x, int n, int D, const uint8_t* circular, float* x_out,
+                                        float* mean, float* stdv, nfisam_stream_t stream) {
+    if (n < 1 || D < 1 || x == nullptr || x_out == nullptr || mean == nullptr || stdv == nullptr) return NFISAM_ERR_ARG;
+    hipLaunchKernelGGL(nsf_normalize_kernel, dim3(D), dim3(256), 0, (hipStream_t)stream, x, n, D, circular, x_out, mean,
+                       stdv);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
 }

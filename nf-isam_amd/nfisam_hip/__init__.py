@@ -23,6 +23,7 @@ EXPORTS = [
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient",
+    "nfisam_normalize_columns",
 ]
 
 
@@ -405,6 +406,21 @@ def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt
                                            int(H), C.c_float(B), int(L), int(n), _ptr(Zt), _ptr(St), _stream()),
            "nfisam_nsf_posterior_walk")
     return St.t().contiguous()
+
+
+def normalize_columns(x, circular=None):
+    """NFiSAM.normalize_training_samples on the device: x [n, D] float32 (cuda) -> (x_normalised, mean[D], std[D])."""
+    x = _dev(x, "x")
+    n, D = x.shape
+    circ = None
+    if circular is not None:
+        circ = torch.as_tensor(np.asarray(circular, dtype=np.uint8)).to(x.device)
+    out = torch.empty_like(x)
+    mean = torch.empty(D, dtype=torch.float32, device=x.device)
+    std = torch.empty(D, dtype=torch.float32, device=x.device)
+    _check(lib().nfisam_normalize_columns(_ptr(x), int(n), int(D), _ptr(circ) if circ is not None else None, _ptr(out),
+                                          _ptr(mean), _ptr(std), _stream()), "nfisam_normalize_columns")
+    return out, mean, std
 
 
 POST_DTYPE = np.dtype([("kparams", np.uint64), ("mean", np.uint64), ("std", np.uint64), ("circular", np.uint64),

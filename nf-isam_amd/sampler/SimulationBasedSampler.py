@@ -14,6 +14,7 @@ from typing import List
 import numpy as np
 
 from factors.utils import unpack_prior_binary_nh_da_factors
+from sampler.DeviceSimulation import HostSimulationBackend
 
 
 class SimulationBasedSampler:
@@ -21,13 +22,17 @@ class SimulationBasedSampler:
         self.factors = factors
         self.vars = vars
 
-    def sample(self, num_samples: int):
+    def sample(self, num_samples: int, backend=None):
+        """-> (batch [n, D], variable ordering incl. observation variables, true observations).  `backend` draws the
+        columns: the factors' numpy methods by default, `sampler.DeviceSimulation.TorchSimulationBackend` keeps
+        them on the GPU (the batch is then a device tensor)."""
+        be = backend if backend is not None else HostSimulationBackend
         priors, binaries, null_hypo, assoc = unpack_prior_binary_nh_da_factors(self.factors)
         if null_hypo:
             raise NotImplementedError("null-hypothesis factors are not rebuilt (SURVEY.md §8 f-2)")
         drawn = {}
         for f in priors:                              # assumes priors do not overlap
-            s = f.sample(num_samples)
+            s = be.prior(f, num_samples)
             col = 0
             for v in f.vars:
                 drawn[v] = s[:, col:col + v.dim]
@@ -36,7 +41,7 @@ class SimulationBasedSampler:
 
         def observe(f):
             true_obs.append(np.asarray(f.observation, dtype=np.float64).ravel())
-            obs_cols.append(f.sample(var1=drawn[f.var1], var2=drawn[f.var2]))
+            obs_cols.append(be.binary(f, var1=drawn[f.var1], var2=drawn[f.var2]))
             obs_vars.append(f.observation_var)
 
         queue = list(binaries)
@@ -61,8 +66,8 @@ class SimulationBasedSampler:
                             deferred.extend(queue)
                             queue = []
                     continue
-                drawn[dst] = f.sample(var1=drawn[f.var1], var2=None) if have1 else f.sample(var1=None,
-                                                                                          var2=drawn[f.var2])
+                drawn[dst] = be.binary(f, var1=drawn[f.var1], var2=None) if have1 else be.binary(f, var1=None,
+                                                                                                var2=drawn[f.var2])
                 stalled = 0
             else:
                 queue.append(f)
@@ -75,12 +80,12 @@ class SimulationBasedSampler:
         for f in assoc:
             if all(v in drawn for v in f.vars):
                 true_obs.append(np.asarray(f.observation, dtype=np.float64).ravel())
-                obs_cols.append(f.sample_observations({v: drawn[v] for v in f.vars}))
+                obs_cols.append(be.assoc_observations(f, drawn))
                 obs_vars.append(f.observation_var)
             else:
                 missing = [v for v in f.vars if v not in drawn]
                 if missing == [f.observer_var]:
-                    drawn[f.observer_var] = f.sample_observer(drawn)
+                    drawn[f.observer_var] = be.assoc_observer(f, drawn)
                 else:
                     raise ValueError("Some variables of the data association have not been sampled: " +
                                      " ".join(str(v.name) for v in missing))
@@ -92,6 +97,6 @@ class SimulationBasedSampler:
                 raise ValueError("Some variables have not been sampled: " + " ".join(missing) +
                                  ". Consider using a different variable elimination ordering.")
         cols = obs_cols + [drawn[v] for v in self.vars]
-        local_samples = np.hstack(cols) if cols else np.empty((num_samples, 0))
+        local_samples = be.hstack(cols, num_samples)
         unused_obs = np.concatenate(true_obs) if true_obs else np.array([])
         return local_samples, obs_vars + list(self.vars), unused_obs

@@ -276,7 +276,8 @@ class FactorGraphSolver:
                 timer.append(time.time() - t0)
             self._clique_true_obs[clique] = true_obs
             if self._args.store_clique_samples:
-                self._clique_samples[clique] = local_samples
+                self._clique_samples[clique] = local_samples if isinstance(local_samples, np.ndarray) \
+                    else local_samples.cpu().numpy()
             model = self.fit_clique_density_model(clique=clique, samples=local_samples,
                                                   var_ordering=sample_var_ordering, timer=timer)
             self._clique_density_model[clique] = model
@@ -296,8 +297,20 @@ class FactorGraphSolver:
         variable_pattern = self._working_bayes_tree.clique_variable_pattern(clique)
         if method == "direct":
             sampler = SimulationBasedSampler(factors=graph.factors, vars=variable_pattern)
+            backend = self._simulation_backend()
+            if backend is not None:
+                from sampler.DeviceSimulation import DeviceSimulationUnsupported
+                try:
+                    return sampler.sample(num_samples, backend=backend)
+                except DeviceSimulationUnsupported:
+                    pass                       # a factor type without a device sampler: simulate this clique on the host
             return sampler.sample(num_samples)
         raise ValueError("Unknown sampling method (nested-sampling local samplers are not rebuilt).")
+
+    def _simulation_backend(self):
+        """Draw backend of the clique training-batch simulator: None = the factors' host (numpy) samplers.
+        Density back ends that can consume device batches override this."""
+        return None
 
     def sample_posterior(self, timer: List[float] = None, *args, **kwargs) -> Dict[Variable, np.ndarray]:
         """Root -> leaves: every clique samples its frontal variables conditioned on its true

@@ -48,7 +48,7 @@ class NFiSAMArgs(SolverArgs):
                  flow_iterations: int = 10, num_knots: int = 12, cuda_training: bool = False,
                  adaptive_flow_setup: bool = False, hidden_dim: int = 8, average_window=50, loss_delta_tol=1e-2,
                  training_set_frac=1.0, validation_interval=10, slower_stop_rate=2.0, data_parallel=False,
-                 training_loss_dir=None, *args, **kwargs):
+                 training_loss_dir=None, device_simulation: bool = False, *args, **kwargs):
         super().__init__(elimination_method=elimination_method, posterior_sample_num=posterior_sample_num,
                          local_sample_num=local_sample_num, store_clique_samples=store_clique_samples,
                          local_sampling_method=local_sampling_method, *args, **kwargs)
@@ -67,6 +67,10 @@ class NFiSAMArgs(SolverArgs):
         self.slower_stop_rate = slower_stop_rate
         self.data_parallel = data_parallel
         self.training_loss_dir = training_loss_dir
+        # not in the reference: simulate / normalise the clique training batches on the GPU
+        # instead of with the host (numpy, float64) simulator.  Off by default: at n = 2000 the ~100 small device
+        # ops per clique cost the host as much as numpy does (Plaza1: 12.1-12.6 s either way)
+        self.device_simulation = device_simulation
         self.tl_cnt = 0
 
 
@@ -151,6 +155,17 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
         # the reference draws all D latent columns and slices (NFiSAM.py:136); only the needed ones are drawn here
         z = torch.randn(n_samples, conditional_dim, device=device, dtype=torch.float32)
         return self.inverse_given_separator(z, x_s).cpu().numpy()
+
+    def conditional_sample_on_device(self, conditional_dim, obs_row=None, sample_number=None) -> "torch.Tensor":
+        """`conditional_sample_given_observation` with ONE observation row tiled on the device and the samples
+        left there (the child -> parent message of the on-device batch simulator)."""
+        f0, L, device = self._flow_cfg()
+        z = torch.randn(int(sample_number), conditional_dim, device=device, dtype=torch.float32)
+        x_s = None
+        if obs_row is not None and len(obs_row) > 0:
+            x_s = torch.as_tensor(np.asarray(obs_row, dtype=np.float32)).to(device).reshape(1, -1) \
+                .expand(int(sample_number), -1).contiguous()
+        return self.inverse_given_separator(z, x_s)
 
     def inverse_given_separator(self, z, x_s=None):
         """z: latent samples [n, c]; x_s: UN-normalised given columns [n, Ds] (numpy or tensor).
@@ -243,6 +258,12 @@ class FlowsPriorFactor(CliqueSeparatorFactor):
         return self._flow_model.conditional_sample_given_observation(conditional_dim=self.dim,
                                                                      obs_samples=obs_samples)
 
+    def sample_on_device(self, num_samples: int) -> "torch.Tensor":
+        """`sample` without leaving the GPU (sampler.DeviceSimulation)."""
+        return self._flow_model.conditional_sample_on_device(conditional_dim=self.dim,
+                                                             obs_row=self._true_obs if self._obs_dim else None,
+                                                             sample_number=num_samples)
+
     def unif_to_sample(self, u) -> np.ndarray:
         """Nested-sampling prior transform: uniform [1,D] -> sample [D] (reference: NFiSAM.py:290-303)."""
         import scipy.stats
@@ -268,6 +289,15 @@ class NFiSAM(FactorGraphSolver):
     def __init__(self, args: NFiSAMArgs = None):
         super().__init__(args=args if args is not None else NFiSAMArgs())
 
+    def _simulation_backend(self):
+        if not getattr(self._args, "device_simulation", False) or not torch.cuda.is_available():
+            return None
+        be = self.__dict__.get("_sim_backend")
+        if be is None:
+            from sampler.DeviceSimulation import TorchSimulationBackend
+            be = self._sim_backend = TorchSimulationBackend(_device())
+        return be
+
     # ---- the hot loop ---------------------------------------------------------------------------
     def fit_clique_density_model(self, clique, samples: np.ndarray, var_ordering: List, timer: List, *args,
                                  **kwargs) -> NormalizingFlowModelWithSeparator:
@@ -287,15 +317,26 @@ class NFiSAM(FactorGraphSolver):
             # observation columns precede the variables and are Euclidean
             circular_dim_list = [False] * (aug_clique_dim - len(circular_dim_list)) + circular_dim_list
 
-        # train/test split on a shuffled COPY (the reference shuffles the caller's array in place)
-        samples = np.array(samples, dtype=np.float64, copy=True)
-        train_size = min(int(samples.shape[0] * a.training_set_frac), samples.shape[0])
-        np.random.shuffle(samples)
-        train_samples, test_samples = samples[:train_size], samples[train_size:]
-        training_data, means, stds = self.normalize_training_samples(train_samples, circular_dim_list, a.flow_type)
-        testing_data = None
-        if len(test_samples) > 0:
-            testing_data, _, _ = self.normalize_training_samples(test_samples, circular_dim_list, a.flow_type)
+        on_device = isinstance(samples, torch.Tensor) and samples.is_cuda
+        if on_device and a.training_set_frac < 1.0:
+            samples, on_device = samples.cpu().numpy(), False       # the hold-out split is done on the host
+        if on_device:
+            # batch simulated on the GPU (sampler.DeviceSimulation): normalise it there too (f-3).  With
+            # training_set_frac = 1 the reference's shuffle only permutes the rows of a full-batch mean.
+            training_data, means, stds = _nh.normalize_columns(samples.to(torch.float32).contiguous(),
+                                                               circular_dim_list)
+            testing_data = None
+        else:
+            # train/test split on a shuffled COPY (the reference shuffles the caller's array in place)
+            samples = np.array(samples, dtype=np.float64, copy=True)
+            train_size = min(int(samples.shape[0] * a.training_set_frac), samples.shape[0])
+            np.random.shuffle(samples)
+            train_samples, test_samples = samples[:train_size], samples[train_size:]
+            training_data, means, stds = self.normalize_training_samples(train_samples, circular_dim_list,
+                                                                         a.flow_type)
+            testing_data = None
+            if len(test_samples) > 0:
+                testing_data, _, _ = self.normalize_training_samples(test_samples, circular_dim_list, a.flow_type)
 
         # Parameters are initialised directly on the device in the reference's order (one op per layer) and
         # trained as kernel-layout blobs; the nn.Module tree of each NSF_AR is only built on demand.

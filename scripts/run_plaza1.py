@@ -19,7 +19,8 @@ nodes, truth, factors = graph_file_parser(os.path.join(ROOT, "tests", "data", da
 steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(os.environ.get("STEP", "5")))
 args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000")), local_sample_num=2000,
                   learning_rate=.01, hidden_dim=8, cuda_training=True, elimination_method="pose_first",
-                  training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50)
+                  training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50,
+                  device_simulation=os.environ.get("DEVSIM", "1") != "0")
 solver = NFiSAM(args)
 rows = []
 t_all = time.time()

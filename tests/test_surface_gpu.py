@@ -217,3 +217,63 @@ def test_fit_with_validation_split_and_multilayer():
     assert xs.shape == (64, 6) and np.all(np.isfinite(xs))
     with pytest.raises(NotImplementedError):
         NFiSAM(NFiSAMArgs(flow_type="NSF_AR_CS")).fit_clique_density_model(clique, samples, [L0, X0], None)
+
+
+def test_device_normalisation_matches_reference_golden():
+    """nfisam_normalize_columns (f-3) against the vectors produced by the reference's
+    NFiSAM.normalize_training_samples (tests/golden/make_golden.py), float32 input."""
+    import nfisam_hip as nh
+    g = dict(np.load(os.path.join(GOLDEN, "normalize.npz")))
+    x = torch.from_numpy(g["samples"].astype(np.float32)).to(DEV)
+    xn, mu, sd = nh.normalize_columns(x, g["circular"])
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mean"], atol=2e-6, rtol=2e-6)
+    np.testing.assert_allclose(sd.cpu().numpy(), g["std"], atol=2e-6, rtol=2e-6)
+    # column 5 of the fixture is constant up to 1e-7 (std clipped at 1e-5): dividing the float32 rounding of the
+    # INPUT by 1e-5 makes it incomparable; every other column agrees to 2e-5
+    live = g["std"] > 1e-4
+    np.testing.assert_allclose(xn.cpu().numpy()[:, live], g["train_norm"][:, live], atol=2e-5)
+    assert np.abs(xn.cpu().numpy()[:, ~live]).max() < 0.1
+    # all-Euclidean call, constant column -> std clipped at 1e-5, in-place allowed
+    y = torch.cat([x[:, :2], torch.full((x.shape[0], 1), 3.0, device=DEV)], 1).contiguous()
+    yn, m2, s2 = nh.normalize_columns(y)
+    assert abs(float(s2[2]) - 1e-5) < 1e-9 and float(yn[:, 2].abs().max()) == 0.0 and abs(float(m2[2]) - 3.0) < 1e-6
+
+
+def test_device_batch_simulator_matches_host_simulator_in_distribution():
+    """sampler.DeviceSimulation (f-2) draws the same joint distribution as the factors' numpy samplers: a clique with
+    an SE(2) prior, two odometry steps, range factors to two landmarks (one creates the landmark on a ring, the later
+    ones become simulated-observation columns) and a 2-way ambiguous association."""
+    from factors.Factors import (AmbiguousDataAssociationFactor, SE2R2RangeGaussianLikelihoodFactor,
+                                 SE2RelativeGaussianLikelihoodFactor, UnarySE2ApproximateGaussianPriorFactor)
+    from sampler.DeviceSimulation import TorchSimulationBackend
+    from sampler.SimulationBasedSampler import SimulationBasedSampler
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    X = [SE2Variable("X%d" % i) for i in range(3)]
+    L0, L1 = R2Variable("L0", VariableType.Landmark), R2Variable("L1", VariableType.Landmark)
+    odom_cov = np.diag([0.2, 0.04, 0.02]) ** 2
+    fs = [UnarySE2ApproximateGaussianPriorFactor(X[0], np.array([1.0, -2.0, 0.3]), np.diag([0.3, 0.2, 0.05]) ** 2),
+          SE2RelativeGaussianLikelihoodFactor(X[0], X[1], np.array([5.0, 0.5, 0.4]), odom_cov),
+          SE2RelativeGaussianLikelihoodFactor(X[1], X[2], np.array([5.0, -0.5, -0.2]), odom_cov),
+          SE2R2RangeGaussianLikelihoodFactor(X[0], L0, 12.0, 0.5),
+          SE2R2RangeGaussianLikelihoodFactor(X[1], L1, 9.0, 0.5),
+          SE2R2RangeGaussianLikelihoodFactor(X[2], L0, 11.0, 0.5),
+          AmbiguousDataAssociationFactor(X[2], [L0, L1], np.array([0.5, 0.5]), SE2R2RangeGaussianLikelihoodFactor, 10.0,
+                                         0.5)]
+    order = [L0, L1] + X
+    n = 6000
+    np.random.seed(0); torch.manual_seed(0)
+    host, hv, hobs = SimulationBasedSampler(fs, order).sample(n)
+    dev_s, dv, dobs = SimulationBasedSampler(fs, order).sample(n, backend=TorchSimulationBackend(DEV))
+    assert dev_s.is_cuda and dev_s.dtype == torch.float32 and tuple(dev_s.shape) == host.shape
+    assert [str(v.name) for v in hv] == [str(v.name) for v in dv]
+    np.testing.assert_array_equal(hobs, dobs)
+    d = dev_s.cpu().numpy().astype(np.float64)
+    # moments column by column (angles: compare resultant vectors), then a joint two-sample statistic
+    for c in range(host.shape[1]):
+        sd = host[:, c].std()
+        assert abs(host[:, c].mean() - d[:, c].mean()) < 0.08 * sd + 5e-3, (c, host[:, c].mean(), d[:, c].mean())
+        assert abs(d[:, c].std() / sd - 1.0) < 0.06, (c, sd, d[:, c].std())
+    scale = host.std(0)
+    a, b = host[:1500] / scale, d[:1500] / scale
+    floor = mmd_rbf(host[:1500] / scale, host[1500:3000] / scale, np.sqrt(host.shape[1]))
+    assert mmd_rbf(a, b, np.sqrt(host.shape[1])) < max(0.03, 3 * floor)

@@ -96,6 +96,7 @@ struct TrainArgs {
     int slab;                       // != 0: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
     int tile;                       // host only: particles per tile (kernel family)
     int iter_idx;                   // iteration index inside the chunk (state->step advances once per chunk)
+    int g_tiles;                    // 1: LDS holds the two dL/dx tiles (L > 1 or gx requested)
 };
 
 template <int K, int H, typename WP>
@@ -167,11 +168,11 @@ constexpr int XS = 66;            // LDS row stride (floats) of every [feature][
 // iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
 // bookkeeping kernel that closes a chunk of iterations consumes and clears them.
 constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
-// staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operand up to row PoP+15
+// staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operands rows PoP..PoP+H-1 / 2H..3H-1
 template <int K, int H>
 struct StgRows {
     static constexpr int PoP = Layout<K, H>::PoP;
-    static constexpr int a = 16 * ((PoP + 15) / 16), b = PoP + 16, c = 3 * H + 16;
+    static constexpr int a = 16 * ((PoP + 15) / 16), b = PoP + H, c = 3 * H;   // bias rows come from the shared `ones` row
     static constexpr int value = (a > b ? (a > c ? a : c) : (b > c ? b : c));
     static constexpr int split = PoP + 16 + 3 * H;      // nsf_train2_kernel: gth | h2 | pad to +16 | ga2 | ga1 | h1
 };
@@ -245,9 +246,10 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
     float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only), 16-byte aligned rows
     float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS] layer inputs, dimension-major
+    const int gt = a.g_tiles ? DT : 0;   // dL/dx tiles exist only when a layer input gradient is needed
     float* g0 = xs + L * DT;          // [D][XS]
-    float* g1 = g0 + DT;              // [D][XS]
-    float* ones = g1 + DT;            // [XS] constant 1 (bias column of the gradient GEMMs)
+    float* g1 = g0 + gt;              // [D][XS]
+    float* ones = g1 + gt;            // [XS] constant 1 (bias column of the gradient GEMMs)
     float* stg = ones + XS + w * (StgRows<K, H>::value * XS);   // wave-private staging tile (MF only)
 
     // ---- prologue: ALL global loads first (particle tile + parameter rows), one wait, then LDS ----
@@ -426,10 +428,10 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     for (int o = 0; o < PoP; ++o) stg[o * XS + lane] = gth[o];
 #pragma unroll
                     for (int k = 0; k < H; ++k) stg[(PoP + k) * XS + lane] = h2[k];
-                    stg[(PoP + H) * XS + lane] = 1.0f;
                     wave_lds_sync();
                     const float* pa = stg + r16 * XS + kq;             // A tiles: gth rows 16t + r16 (>= Po: unused outputs)
-                    const float* pb = stg + (PoP + r16) * XS + kq;     // B: [h2 | 1] rows (>= 9: unused outputs)
+                    // B: [h2 | 1]; the bias column and the unused columns beyond it read the constant-one row
+                    const float* pb = ((r16 < H) ? (stg + (PoP + r16) * XS) : ones) + kq;
                     f32x4 cacc[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -468,10 +470,9 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                         stg[(H + j) * XS + lane] = ga1[j];
                         stg[(2 * H + j) * XS + lane] = h1[j];
                     }
-                    stg[(3 * H) * XS + lane] = 1.0f;
                     wave_lds_sync();
                     const float* pa = stg + r16 * XS + kq;                   // A: rows 0..7 ga2, 8..15 ga1
-                    const float* pb1 = stg + (2 * H + r16) * XS + kq;        // B1: [h1 | 1]
+                    const float* pb1 = ((r16 < H) ? (stg + (2 * H + r16) * XS) : ones) + kq;   // B1: [h1 | 1]
                     f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
                     float areg[TILE / 4];
 #pragma unroll
@@ -645,9 +646,10 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
     const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
     float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only)
     float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS2] layer inputs, dimension-major
+    const int gt = a.g_tiles ? DT : 0;   // dL/dx tiles exist only when a layer input gradient is needed
     float* g0 = xs + L * DT;          // [D][XS2]
-    float* g1 = g0 + DT;              // [D][XS2]
-    float* ones = g1 + DT;            // [XS2]
+    float* g1 = g0 + gt;              // [D][XS2]
+    float* ones = g1 + gt;            // [XS2]
     float* stg = ones + XS2 + w * (StgRows<K, H>::split * XS2);   // wave-private staging tile
 
     // ---- prologue: all global loads first (particle tile + parameter rows), one wait, then LDS ----
@@ -1828,8 +1830,9 @@ static int launch_train2(const TrainArgs& a_in, int n_cliques, int max_n, int ma
     // (measured: single-wave blocks beat 2-4 dims per block by 1-5 % here, although they dispatch more slowly)
     if (independent_dims && tiles * max_D <= 2048) { W = 1; groups = max_D; }
     else if (independent_dims && tiles * W <= 4096) groups = (max_D + W - 1) / W;
+    a.g_tiles = independent_dims ? 0 : 1;
     NSF_DISPATCH(K, H, {
-        const size_t tile_floats = (((size_t)a.L + 2) * max_D + 1 + (size_t)W * StgRows<KK, HH>::split) * XS2;
+        const size_t tile_floats = (((size_t)a.L + 2 * a.g_tiles) * max_D + 1 + (size_t)W * StgRows<KK, HH>::split) * XS2;
         const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
         size_t wfloats = (size_t)a.L * stride;
         if (groups > 1) {
@@ -1864,8 +1867,18 @@ static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max
     int W = pick_waves(max_D), groups = 1;
     if (independent_dims && tiles * max_D <= 1024) { W = 1; groups = max_D; }
     else if (independent_dims && tiles * W <= 2048) groups = (max_D + W - 1) / W;
+    else if (independent_dims && tiles >= 1024) {
+        // throughput regime (several blocks per CU): resident waves per SIMD are limited by the 10.6 KB staging
+        // tile of every wave, not by registers (128 VGPRs): 4 waves per block -> 3 blocks = 12 waves per CU instead
+        // of one block of 8 waves (measured on 64 cliques n=2000 D=15: 226 -> 169 us per iteration)
+        W = 4;
+        const char* e = getenv("NFISAM_BIG_W");
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) W = atoi(e);
+        if (W > max_D) W = max_D;
+    }
+    a.g_tiles = independent_dims ? 0 : 1;
     NSF_DISPATCH(K, H, {
-        const size_t tile_floats = (((size_t)a.L + 2) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
+        const size_t tile_floats = (((size_t)a.L + 2 * a.g_tiles) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
         const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
         // parameter floats one block must hold: all layers, or its own dims' blocks when grouped
         size_t wfloats = (size_t)a.L * stride;

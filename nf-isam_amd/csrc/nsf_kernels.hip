@@ -442,24 +442,34 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                         for (int t = 0; t < NT; ++t) cacc[t] = mfma4(pa[t * 16 * XS + s4], b, cacc[t]);
                     }
                     // C layout: col = lane&15 (= c), rows 4*(lane>>4)+r (= o within the tile)
-                    wave_lds_sync();
-                    if (r16 <= H) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
-                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
-                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
-                            }
-                    }
-                    wave_lds_sync();
-                    constexpr int TOT = (H + 1) * PoP;
                     float* Gw = Gb + LY::oW2(i);
-#pragma unroll
-                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                        const int f = c * 64 + lane;
-                        if (f < TOT) gsink(&Gw[f], stg[f], slab);
-                    }
                     wave_lds_sync();
+                    if (slab) {
+                        // per-tile slab: every entry written once, four consecutive outputs per lane = one 16-byte store
+                        if (r16 <= H) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+                        }
+                    } else {
+                        // atomics: transpose through LDS to the flat order (64 consecutive addresses per wave instruction)
+                        if (r16 <= H) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
+                                    float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                    d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                                }
+                        }
+                        wave_lds_sync();
+                        constexpr int TOT = (H + 1) * PoP;
+#pragma unroll
+                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                            const int f = c * 64 + lane;
+                            if (f < TOT) atomicAdd(&Gw[f], stg[f]);
+                        }
+                        wave_lds_sync();
+                    }
                 }
                 STAMP(7);
                 // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========

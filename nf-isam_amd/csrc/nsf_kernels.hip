@@ -1876,15 +1876,16 @@ static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max
     const bool independent_dims = (a.L == 1 && a.gx == nullptr);
     int W = pick_waves(max_D), groups = 1;
     if (independent_dims && tiles * max_D <= 1024) { W = 1; groups = max_D; }
-    else if (independent_dims && tiles * W <= 2048) groups = (max_D + W - 1) / W;
-    else if (independent_dims && tiles >= 1024) {
-        // throughput regime (several blocks per CU): resident waves per SIMD are limited by the 10.6 KB staging
-        // tile of every wave, not by registers (128 VGPRs): 4 waves per block -> 3 blocks = 12 waves per CU instead
-        // of one block of 8 waves (measured on 64 cliques n=2000 D=15: 226 -> 169 us per iteration)
+    else if (independent_dims) {
+        // Beyond one wave per SIMD the resident waves per CU are limited by the 10.6 KB staging tile of every wave,
+        // not by registers (128 VGPRs): 4 waves per block -> 3 blocks = 12 waves per CU instead of one block of 8
+        // (64 cliques n=2000 D=15: 226 -> 169 us per iteration).  Up to 256 tiles every wave still gets a single
+        // unit (dims spread over grid.z); larger launches let a wave loop over its dims and amortise the tile load.
         W = 4;
         const char* e = getenv("NFISAM_BIG_W");
         if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) W = atoi(e);
         if (W > max_D) W = max_D;
+        if (tiles <= 256) groups = (max_D + W - 1) / W;
     }
     a.g_tiles = independent_dims ? 0 : 1;
     NSF_DISPATCH(K, H, {

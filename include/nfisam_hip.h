@@ -144,6 +144,36 @@ int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, co
 int nfisam_normalize_columns(const float* x, int n, int D, const uint8_t* circular, float* x_out, float* mean,
                              float* std, nfisam_stream_t stream);
 
+/* ---- clique training-batch simulator (f-2) -------------------------------------------------------
+ * One op of the ancestral-simulation schedule of a clique (sampler/SimulationBasedSampler.plan; reference:
+ * src/sampler/SimulationBasedSampler.py:14-133).  Columns index the [n, D_total] batch; an SE(2) variable takes 3
+ * consecutive columns (x y theta), an R2 variable 2.  p: SE(2) ops = pose / measurement (3) then the lower Cholesky
+ * factor of the tangent-space noise covariance (l00 l10 l11 l20 l21 l22).                                     */
+#define NFISAM_SIM_MAX_OPS 40
+#define NFISAM_SIM_COPY       1   /* c.. <- k columns b.. of the row-major device array `src` with row stride a       */
+#define NFISAM_SIM_PRIOR_SE2  2   /* c <- p[0:3] * Exp(eps)                       (Factors.py:725-743)                */
+#define NFISAM_SIM_REL_FWD    3   /* c <- col a * (p[0:3] * Exp(eps))             (Factors.py:1196-1317)              */
+#define NFISAM_SIM_REL_BWD    4   /* c <- col a * (p[0:3] * Exp(eps))^-1                                              */
+#define NFISAM_SIM_REL_OBS    5   /* c <- (col a)^-1 (col b) * Exp(eps)           simulated odometry measurement      */
+#define NFISAM_SIM_RING       6   /* c(xy) <- a(xy) + (p[0] + p[1] z)(cos phi, sin phi), phi ~ U(-pi, pi)  (:2575-2649) */
+#define NFISAM_SIM_RANGE_OBS  7   /* c <- |b(xy) - a(xy)| + p[0] z                simulated range measurement         */
+#define NFISAM_SIM_ADA_OBS    8   /* c <- range from a(xy) to ONE of the k candidates cand[], cumulative weights
+                                     p[0:k], noise p[4] z                          (Factors.py:3146-3157)             */
+typedef struct nfisam_sim_op {
+    int32_t code;
+    int32_t a, b, c;
+    int32_t cand[4];
+    int32_t k;
+    float p[9];
+    uint64_t src;
+} nfisam_sim_op;
+
+/* Simulate the n joint samples of a clique: every thread interprets `ops` (HOST array, copied into the launch) for its
+ * own sample with a counter-based generator keyed by `seed`; x_out[n, D_out] row-major receives the first D_out
+ * columns (D_total - D_out scratch columns may hold variables that are not part of the batch).                */
+int nfisam_simulate_clique(const nfisam_sim_op* ops, int n_ops, int n, int D_out, int D_total, uint64_t seed,
+                           float* x_out, nfisam_stream_t stream);
+
 /* ---- training -------------------------------------------------------------------------- */
 /* Vector-Jacobian product of the L-layer flow (what torch autograd computes for
  * `loss.backward()` in slam/NFiSAM.py:474): kgrad[L*kparam_count] += d<gz,z>/dtheta + d<gl,logdet>/dtheta,

@@ -23,7 +23,7 @@ EXPORTS = [
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient",
-    "nfisam_normalize_columns",
+    "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
 
@@ -406,6 +406,26 @@ def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt
                                            int(H), C.c_float(B), int(L), int(n), _ptr(Zt), _ptr(St), _stream()),
            "nfisam_nsf_posterior_walk")
     return St.t().contiguous()
+
+
+class SimOp(C.Structure):
+    """`nfisam_sim_op` (include/nfisam_hip.h)."""
+    _fields_ = [("code", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("cand", C.c_int32 * 4),
+                ("k", C.c_int32), ("p", C.c_float * 9), ("src", C.c_uint64)]
+
+
+SIM_MAX_OPS = 40
+SIM_COPY, SIM_PRIOR_SE2, SIM_REL_FWD, SIM_REL_BWD, SIM_REL_OBS, SIM_RING, SIM_RANGE_OBS, SIM_ADA_OBS = range(1, 9)
+assert C.sizeof(SimOp) == 80
+
+
+def simulate_clique(ops, n, D_out, D_total, seed, device):
+    """Run a compiled simulation schedule (list of SimOp) -> device tensor [n, D_out] float32."""
+    arr = (SimOp * len(ops))(*ops)
+    out = torch.empty(int(n), int(D_out), dtype=torch.float32, device=device)
+    _check(lib().nfisam_simulate_clique(arr, len(ops), int(n), int(D_out), int(D_total), C.c_uint64(int(seed)), _ptr(out),
+                                        _stream()), "nfisam_simulate_clique")
+    return out
 
 
 def normalize_columns(x, circular=None):

@@ -48,7 +48,7 @@ class NFiSAMArgs(SolverArgs):
                  flow_iterations: int = 10, num_knots: int = 12, cuda_training: bool = False,
                  adaptive_flow_setup: bool = False, hidden_dim: int = 8, average_window=50, loss_delta_tol=1e-2,
                  training_set_frac=1.0, validation_interval=10, slower_stop_rate=2.0, data_parallel=False,
-                 training_loss_dir=None, device_simulation: bool = False, *args, **kwargs):
+                 training_loss_dir=None, device_simulation=True, *args, **kwargs):
         super().__init__(elimination_method=elimination_method, posterior_sample_num=posterior_sample_num,
                          local_sample_num=local_sample_num, store_clique_samples=store_clique_samples,
                          local_sampling_method=local_sampling_method, *args, **kwargs)
@@ -67,9 +67,10 @@ class NFiSAMArgs(SolverArgs):
         self.slower_stop_rate = slower_stop_rate
         self.data_parallel = data_parallel
         self.training_loss_dir = training_loss_dir
-        # not in the reference: simulate / normalise the clique training batches on the GPU
-        # instead of with the host (numpy, float64) simulator.  Off by default: at n = 2000 the ~100 small device
-        # ops per clique cost the host as much as numpy does (Plaza1: 12.1-12.6 s either way)
+        # not in the reference: simulate and normalise the clique training batches on the GPU.
+        # True: one fused kernel per clique (csrc/clique_sim.hip); "torch": batched torch ops; False: the factors'
+        # host (numpy, float64) samplers.  Cliques with a factor type the device simulator does not know fall back
+        # to the host.  Plaza1: the fused simulator takes ~1.3 s off the 4-5 s spent outside training.
         self.device_simulation = device_simulation
         self.tl_cnt = 0
 
@@ -294,8 +295,9 @@ class NFiSAM(FactorGraphSolver):
             return None
         be = self.__dict__.get("_sim_backend")
         if be is None:
-            from sampler.DeviceSimulation import TorchSimulationBackend
-            be = self._sim_backend = TorchSimulationBackend(_device())
+            from sampler.DeviceSimulation import FusedSimulationBackend, TorchSimulationBackend
+            fused = str(getattr(self._args, "device_simulation", "")).lower() != "torch"
+            be = self._sim_backend = (FusedSimulationBackend if fused else TorchSimulationBackend)(_device())
         return be
 
     # ---- the hot loop ---------------------------------------------------------------------------

@@ -39,10 +39,12 @@ def xy(order, arr):
     return np.hstack([cols[v] for v in sorted(order)]), cols
 
 
-@pytest.mark.parametrize("device_simulation", [False, True], ids=["host-simulator", "device-simulator"])
+@pytest.mark.parametrize("device_simulation", [False, True, "torch"],
+                         ids=["host-simulator", "fused-device-simulator", "torch-device-simulator"])
 def test_small_range_problem_incremental_posteriors(tmp_path, device_simulation):
-    """device-simulator: the clique training batches are simulated and normalised on the GPU
-    (sampler.DeviceSimulation + nfisam_normalize_columns) instead of by the factors' numpy samplers."""
+    """device simulators: the clique training batches are simulated (one fused kernel per clique, or batched torch
+    ops) and normalised on the GPU (sampler.DeviceSimulation + nfisam_normalize_columns) instead of by the factors'
+    numpy samplers."""
     from slam.NFiSAM import NFiSAM_empirial_study
     from utils.Statistics import MMDb
     g = np.load(os.path.join(GOLDEN, "small_range_case1.npz"))

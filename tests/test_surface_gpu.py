@@ -239,13 +239,15 @@ def test_device_normalisation_matches_reference_golden():
     assert abs(float(s2[2]) - 1e-5) < 1e-9 and float(yn[:, 2].abs().max()) == 0.0 and abs(float(m2[2]) - 3.0) < 1e-6
 
 
-def test_device_batch_simulator_matches_host_simulator_in_distribution():
-    """sampler.DeviceSimulation (f-2) draws the same joint distribution as the factors' numpy samplers: a clique with
+@pytest.mark.parametrize("backend_name", ["FusedSimulationBackend", "TorchSimulationBackend"])
+def test_device_batch_simulator_matches_host_simulator_in_distribution(backend_name):
+    """sampler.DeviceSimulation (f-2: one fused kernel per clique, or batched torch ops) draws the same joint
+    distribution as the factors' numpy samplers: a clique with
     an SE(2) prior, two odometry steps, range factors to two landmarks (one creates the landmark on a ring, the later
     ones become simulated-observation columns) and a 2-way ambiguous association."""
     from factors.Factors import (AmbiguousDataAssociationFactor, SE2R2RangeGaussianLikelihoodFactor,
                                  SE2RelativeGaussianLikelihoodFactor, UnarySE2ApproximateGaussianPriorFactor)
-    from sampler.DeviceSimulation import TorchSimulationBackend
+    import sampler.DeviceSimulation as DS
     from sampler.SimulationBasedSampler import SimulationBasedSampler
     from slam.Variables import R2Variable, SE2Variable, VariableType
     X = [SE2Variable("X%d" % i) for i in range(3)]
@@ -263,7 +265,7 @@ def test_device_batch_simulator_matches_host_simulator_in_distribution():
     n = 6000
     np.random.seed(0); torch.manual_seed(0)
     host, hv, hobs = SimulationBasedSampler(fs, order).sample(n)
-    dev_s, dv, dobs = SimulationBasedSampler(fs, order).sample(n, backend=TorchSimulationBackend(DEV))
+    dev_s, dv, dobs = SimulationBasedSampler(fs, order).sample(n, backend=getattr(DS, backend_name)(DEV))
     assert dev_s.is_cuda and dev_s.dtype == torch.float32 and tuple(dev_s.shape) == host.shape
     assert [str(v.name) for v in hv] == [str(v.name) for v in dv]
     np.testing.assert_array_equal(hobs, dobs)
@@ -273,6 +275,9 @@ def test_device_batch_simulator_matches_host_simulator_in_distribution():
         sd = host[:, c].std()
         assert abs(host[:, c].mean() - d[:, c].mean()) < 0.08 * sd + 5e-3, (c, host[:, c].mean(), d[:, c].mean())
         assert abs(d[:, c].std() / sd - 1.0) < 0.06, (c, sd, d[:, c].std())
+    # (the numpy sampler assigns mixture components to contiguous row blocks: shuffle before taking subsets)
+    perm = np.random.RandomState(1).permutation(n)
+    host, d = host[perm], d[perm]
     scale = host.std(0)
     a, b = host[:1500] / scale, d[:1500] / scale
     floor = mmd_rbf(host[:1500] / scale, host[1500:3000] / scale, np.sqrt(host.shape[1]))

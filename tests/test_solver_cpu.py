@@ -298,3 +298,65 @@ def test_ambiguous_data_association_factor():
     samples, order, obs = SimulationBasedSampler(fs, pattern).sample(300)
     assert samples.shape == (300, 1 + 8 + 6) and [v.name for v in order][0].startswith("O")
     np.testing.assert_allclose(obs, f.observation)
+
+
+def test_simulation_plan_and_fused_op_table(monkeypatch):
+    """The clique simulation schedule (SimulationBasedSampler.plan) and its compilation into `nfisam_sim_op`s
+    (sampler.DeviceSimulation.FusedSimulationBackend) without a GPU: the kernel launch is replaced by a recorder."""
+    import torch
+    import nfisam_hip as nh
+    from factors.Factors import AmbiguousDataAssociationFactor, UnarySE2ApproximateGaussianPriorFactor
+    from sampler.DeviceSimulation import DeviceSimulationUnsupported, FusedSimulationBackend
+    X = [SE2Variable("X%d" % i) for i in range(3)]
+    L0, L1 = R2Variable("L0", VariableType.Landmark), R2Variable("L1", VariableType.Landmark)
+    cov = np.diag([0.2, 0.04, 0.02]) ** 2
+    fs = [UnarySE2ApproximateGaussianPriorFactor(X[0], np.array([1.0, -2.0, 0.3]), np.diag([0.3, 0.2, 0.05]) ** 2),
+          SE2RelativeGaussianLikelihoodFactor(X[0], X[1], np.array([5.0, 0.5, 0.4]), cov),
+          SE2RelativeGaussianLikelihoodFactor(X[1], X[2], np.array([5.0, -0.5, -0.2]), cov),
+          SE2R2RangeGaussianLikelihoodFactor(X[0], L0, 12.0, 0.5),
+          SE2R2RangeGaussianLikelihoodFactor(X[1], L1, 9.0, 0.5),
+          SE2R2RangeGaussianLikelihoodFactor(X[2], L0, 11.0, 0.5),
+          AmbiguousDataAssociationFactor(X[2], [L0, L1], np.array([0.25, 0.75]), SE2R2RangeGaussianLikelihoodFactor, 10.0,
+                                         0.5)]
+    order = [L0, L1] + X
+    sampler = SimulationBasedSampler(fs, order)
+    steps = sampler.plan()
+    assert [s[0] for s in steps] == ["prior", "draw", "draw", "draw", "draw", "observe", "assoc_obs"]
+    assert [str(s[2].name) for s in steps if s[0] == "draw"] == ["X1", "X2", "L0", "L1"]
+    # the host execution of the same plan keeps the documented layout [obs | variables in pattern order]
+    np.random.seed(0)
+    batch, vs, true_obs = sampler.sample(50)
+    assert batch.shape == (50, 2 + 2 + 2 + 9) and [str(v.name) for v in vs[2:]] == ["L0", "L1", "X0", "X1", "X2"]
+    np.testing.assert_allclose(true_obs, [11.0, 10.0])
+
+    captured = {}
+
+    def fake_launch(ops, n, D_out, D_total, seed, device):
+        captured.update(ops=list(ops), n=n, D_out=D_out, D_total=D_total, seed=seed)
+        return torch.zeros(n, D_out)
+    monkeypatch.setattr(nh, "simulate_clique", fake_launch)
+    x, vs2, obs2 = sampler.sample(50, backend=FusedSimulationBackend("cpu"))
+    assert tuple(x.shape) == (50, 15) and [str(v.name) for v in vs2] == [str(v.name) for v in vs]
+    np.testing.assert_allclose(obs2, true_obs)
+    ops = captured["ops"]
+    assert captured["D_out"] == captured["D_total"] == 15 and 0 <= captured["seed"] < 2 ** 62
+    assert [o.code for o in ops] == [nh.SIM_PRIOR_SE2, nh.SIM_REL_FWD, nh.SIM_REL_FWD, nh.SIM_RING, nh.SIM_RING,
+                                     nh.SIM_RANGE_OBS, nh.SIM_ADA_OBS]
+    # columns: obs 0,1 | L0 2-3 | L1 4-5 | X0 6-8 | X1 9-11 | X2 12-14
+    assert (ops[0].c, ops[1].a, ops[1].c, ops[2].a, ops[2].c) == (6, 6, 9, 9, 12)
+    assert (ops[3].a, ops[3].c, ops[4].a, ops[4].c) == (6, 2, 9, 4)
+    assert (ops[5].a, ops[5].b, ops[5].c) == (12, 2, 0)
+    ada = ops[6]
+    assert (ada.a, ada.c, ada.k, list(ada.cand)[:2]) == (12, 1, 2, [2, 4])
+    np.testing.assert_allclose(list(ada.p)[:5], [0.25, 1.0, 1.0, 1.0, 0.5], rtol=1e-6)
+    np.testing.assert_allclose(list(ops[1].p)[:3], [5.0, 0.5, 0.4], rtol=1e-6)
+    np.testing.assert_allclose(list(ops[1].p)[3:], [0.2, 0, 0.04, 0, 0, 0.02], atol=1e-7)
+    np.testing.assert_allclose(list(ops[3].p)[:2], [12.0, 0.5])
+
+    # a factor type without a device sampler makes the backend decline (the solver then simulates on the host)
+    class Odd(SE2RelativeGaussianLikelihoodFactor):
+        pass
+    odd = Odd(X[0], X[1], np.array([1.0, 0, 0]), cov)
+    odd._correlated_Rt = False
+    with pytest.raises(DeviceSimulationUnsupported):
+        SimulationBasedSampler([fs[0], odd], [X[0], X[1]]).sample(10, backend=FusedSimulationBackend("cpu"))

@@ -1403,12 +1403,40 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk2_kernel(WalkArgs a) {
         const bool more = (c + 1 < a.n_cliques);
         // ---- 1. given columns: true observations, then the separator samples written by the ancestors.  The
         //         even lane of a pair is the one that wrote them (program order makes them visible to it).
-        for (int k = 0; k < Ds; ++k) {
-            float v = 0.0f;
-            if (k < n_obs) v = ax[3 * dmax + k];
-            else if (hf == 0) v = a.St[(size_t)cl[k - n_obs] * n + pp];
-            const float d = v - ax[k];
-            if (hf == 0) xs[k * XS2 + p] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+        // All loads are issued before any is consumed (one memory round trip instead of one per column): lanes 0..31
+        // take the wave's 32 samples of column k, lanes 32..63 those of column k + 1 (128 contiguous bytes each).
+        // The values were stored by this wave: agent-scope loads read them back from L2.
+        {
+            const int half = lane >> 5, pl = lane & 31;
+            const int gq = blockIdx.x * TILE2 + pl;
+            const size_t pq = (gq < n) ? (size_t)gq : 0;
+            constexpr int KMAX = 16;                       // columns in flight per lane: covers Ds <= 32
+            float v[KMAX];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const int k = 2 * j + half;
+                v[j] = 0.0f;
+                if (k < Ds) {
+                    if (k < n_obs) v[j] = ax[3 * dmax + k];
+                    else v[j] = __hip_atomic_load(&a.St[(size_t)cl[k - n_obs] * n + pq], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const int k = 2 * j + half;
+                if (k < Ds) {
+                    const float d = v[j] - ax[k];
+                    xs[k * XS2 + pl] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+                }
+            }
+            for (int k = 2 * KMAX + half; k < Ds; k += 2) {          // very wide separators: the rest, one by one
+                float vv = (k < n_obs) ? ax[3 * dmax + k]
+                                       : __hip_atomic_load(&a.St[(size_t)cl[k - n_obs] * n + pq], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                const float d = vv - ax[k];
+                xs[k * XS2 + pl] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+            }
         }
         wave_lds_sync();
         // ---- 2. next clique: everything that does not depend on this one goes in flight now ----------

@@ -186,10 +186,13 @@ class BayesTree(object):
         return "BayesTree{" + ", ".join(str(c) for c in self.clique_ordering()) + "}"
 
     # ---- incremental update support -----------------------------------------------------------
-    def get_affected_vars_and_partial_bayes_trees(self, vars: Set[Variable]) -> Tuple[Set[Variable], List["BayesTree"]]:
+    def get_affected_vars_and_partial_bayes_trees(self, vars: Set[Variable], detach: bool = False
+                                                  ) -> Tuple[Set[Variable], List["BayesTree"]]:
         """Cliques holding `vars` as frontal variables and all their ancestors are affected; every
-        maximal unaffected subtree hanging off an affected clique is returned as a detached tree
-        (deep copy).  -> (frontal variables of affected cliques, detached sub trees)."""
+        maximal unaffected subtree hanging off an affected clique is returned as a detached tree: a deep copy
+        (as in the reference), or -- `detach=True`, for a caller that discards this tree afterwards -- the very
+        same nodes cut off from their parent (no O(tree) copy per update).
+        -> (frontal variables of affected cliques, detached sub trees)."""
         frontal_of = {}
         for c in self.clique_ordering():
             for v in c.frontal:
@@ -204,9 +207,14 @@ class BayesTree(object):
         for c in self.clique_ordering():
             if not any(c is a for a in affected):
                 continue
-            for child in c.children:
+            for child in list(c.children):
                 if not any(child is a for a in affected):
-                    sub_trees.append(BayesTree(root_clique=_deep_copy_subtree(child)))
+                    if detach:
+                        c.children = [x for x in c.children if x is not child]
+                        child.parent = None
+                        sub_trees.append(BayesTree(root_clique=child))
+                    else:
+                        sub_trees.append(BayesTree(root_clique=_deep_copy_subtree(child)))
         affected_vars = set().union(*[c.frontal for c in affected]) if affected else set()
         return affected_vars, sub_trees
 

@@ -163,8 +163,9 @@ class FactorGraphSolver:
         old_nodes = set(self.physical_vars)
         touched = set().union(*[set(f.vars) for f in self._new_factors]) if self._new_factors else set()
         if self._physical_bayes_tree:
+            # the old physical tree is replaced below: its unaffected subtrees are moved, not copied
             affected_nodes, sub_trees = self._physical_bayes_tree.get_affected_vars_and_partial_bayes_trees(
-                vars=old_nodes & touched)
+                vars=old_nodes & touched, detach=True)
             self._working_graph = self._physical_graph.get_sub_factor_graph_with_prior(
                 variables=affected_nodes, sub_trees=sub_trees, clique_prior_dict=self._implicit_factors)
         else:

@@ -110,6 +110,31 @@ __device__ __forceinline__ void load_row(const float* row, float (&w)[N]) {
     }
 }
 
+// The first U of the N floats of a row; the tail group is fetched with a narrower load, so that no loaded register
+// is dead: a partly dead 16-byte load lets the register allocator overlap its destination with the next load's,
+// and that write-after-write pair forces a full s_waitcnt lgkmcnt(0) between the two loads.
+template <int N, int U>
+__device__ __forceinline__ void load_row_used(const float* row, float (&w)[N]) {
+    static_assert(U <= N && U > 0, "used prefix");
+#pragma unroll
+    for (int j = 0; j + 4 <= U; j += 4) {
+        const wf4 v = *(const wf4*)(row + j);
+        w[j] = v.x; w[j + 1] = v.y; w[j + 2] = v.z; w[j + 3] = v.w;
+    }
+    constexpr int R = U & 3, J = U - R;
+    if constexpr (R == 1) {
+        w[J] = row[J];
+    } else if constexpr (R == 2) {
+        const float2 v = *(const float2*)(row + J);
+        w[J] = v.x; w[J + 1] = v.y;
+    } else if constexpr (R == 3) {
+        const float2 v = *(const float2*)(row + J);
+        w[J] = v.x; w[J + 1] = v.y; w[J + 2] = row[J + 2];
+    }
+#pragma unroll
+    for (int j = U; j < N; ++j) w[j] = 0.0f;
+}
+
 // ---- conditioner ----------------------------------------------------------------------------
 // xs: LDS, dimension-major with row stride `xstride`: xs[k * xstride + lane] = x_k of this lane's particle.
 // WP = weight pointer type: `cfloat*` (scalar-cache path, SGPR operands) or `const float*` into an

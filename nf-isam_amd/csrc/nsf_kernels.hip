@@ -597,7 +597,7 @@ __device__ __forceinline__ void load_theta2(const float* lp, int i, const float*
                                             float (&h2o)[H / 2], float (&th)[hp_of(K)]) {
     using LY = Layout<K, H>;
     if (i == 0) {
-        load_row<LY::HP>(lp + LY::HP * hf, th);
+        load_row_used<LY::HP, K + LY::ND0>(lp + LY::HP * hf, th);
     } else {
         const float* blk = lp + LY::off(i);
         cond_hidden2<K, H>(blk, i, xin, p, hf, h1m, h1o, h2m, h2o);
@@ -793,8 +793,8 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < HH; ++kk) {
                     float wr[HP], wo[HP];
-                    load_row<HP>(W2 + (mo + kk) * PoP, wr);
-                    load_row<HP>(W2 + (oo + kk) * PoP, wo);
+                    load_row_used<HP, UO>(W2 + (mo + kk) * PoP, wr);
+                    load_row_used<HP, UO>(W2 + (oo + kk) * PoP, wo);
                     float am = 0.0f, ao = 0.0f;
 #pragma unroll
                     for (int o = 0; o < UO; ++o) {

@@ -80,21 +80,22 @@ __device__ __forceinline__ void cond_theta2(const float* blk, int i, int hf, con
     using LY = Layout<K, H>;
     constexpr int HH = H / 2, HP = LY::HP;
     const int mo = HH * hf, oo = HH - mo;
+    constexpr int UO = K + LY::ND0;                           // used outputs per half (the rest is padding)
     const float* W2 = blk + LY::oW2(i) + HP * hf;
-    load_row<HP>(blk + LY::ob2(i) + HP * hf, th);
+    load_row_used<HP, UO>(blk + LY::ob2(i) + HP * hf, th);
 #pragma unroll
     for (int kk = 0; kk < HH; ++kk) {
         float wr[HP];
-        load_row<HP>(W2 + (mo + kk) * LY::PoP, wr);
+        load_row_used<HP, UO>(W2 + (mo + kk) * LY::PoP, wr);
 #pragma unroll
-        for (int o = 0; o < HP; ++o) th[o] = __builtin_fmaf(wr[o], h2m[kk], th[o]);
+        for (int o = 0; o < UO; ++o) th[o] = __builtin_fmaf(wr[o], h2m[kk], th[o]);
     }
 #pragma unroll
     for (int kk = 0; kk < HH; ++kk) {
         float wr[HP];
-        load_row<HP>(W2 + (oo + kk) * LY::PoP, wr);
+        load_row_used<HP, UO>(W2 + (oo + kk) * LY::PoP, wr);
 #pragma unroll
-        for (int o = 0; o < HP; ++o) th[o] = __builtin_fmaf(wr[o], h2o[kk], th[o]);
+        for (int o = 0; o < UO; ++o) th[o] = __builtin_fmaf(wr[o], h2o[kk], th[o]);
     }
 }
 

@@ -303,7 +303,7 @@ def main():
                                  "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU). Algorithmic HBM bytes: 98 KB (x) + "
                                  "110 KB parameters per launch."},
         }
-        if args.no_update_bench:
+        if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only
             out["wall_clock_per_incremental_update"] = None
         else:
             try:
@@ -316,13 +316,14 @@ def main():
                 out["roofline"]["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
             except Exception:   # noqa: BLE001
                 pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(xs_np[0], blobs_np[0])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     tb.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -301,7 +301,10 @@ def main():
                                  "workload (189 MFLOP per launch = 1.2 us at peak; 128 tiles x 6 waves on 128 of "
                                  "256 CUs, 7 dependent unit passes per wave); priced against the fp32 peak "
                                  "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU). Algorithmic HBM bytes: 98 KB (x) + "
-                                 "110 KB parameters per launch."},
+                                 "110 KB parameters per launch; `traffic` (measured, profiles/) is larger because "
+                                 "every 32-particle tile writes its own 27 KB copy of the gradient with plain stores "
+                                 "(3.5 MB per launch, read once by the Adam kernel) instead of float atomics - no "
+                                 "re-reads, 130 GB/s, far below the HBM bound."},
         }
         if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only
             out["wall_clock_per_incremental_update"] = None

@@ -159,6 +159,8 @@ int nfisam_normalize_columns(const float* x, int n, int D, const uint8_t* circul
 #define NFISAM_SIM_RANGE_OBS  7   /* c <- |b(xy) - a(xy)| + p[0] z                simulated range measurement         */
 #define NFISAM_SIM_ADA_OBS    8   /* c <- range from a(xy) to ONE of the k candidates cand[], cumulative weights
                                      p[0:k], noise p[4] z                          (Factors.py:3146-3157)             */
+#define NFISAM_SIM_NH_RING    9   /* RING whose noise is p[1] with probability p[3], else p[2]   (BinaryFactorWithNullHypo,   */
+#define NFISAM_SIM_NH_OBS    10   /* RANGE_OBS whose noise is p[0] with probability p[2], else p[1]    Factors.py:3300-3462)  */
 typedef struct nfisam_sim_op {
     int32_t code;
     int32_t a, b, c;

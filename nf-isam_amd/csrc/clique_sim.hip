@@ -147,6 +147,21 @@ __global__ void __launch_bounds__(SIM_BLOCK) nsf_clique_sim_kernel(SimArgs a) {
             col(op.c) = sqrtf(dx * dx + dy * dy) + op.p[4] * r.z0;
             break;
         }
+        case NFISAM_SIM_NH_RING: {                // ring whose radius noise is the regular or the inflated ("null") sigma
+            const Rand r = draw(a.seed, sample, o);
+            const float sig = (r.u3 < op.p[3]) ? op.p[1] : op.p[2];
+            const float rad = op.p[0] + sig * r.z0;
+            const float phi = (2.0f * r.u2 - 1.0f) * 3.141592653589793f;
+            col(op.c) = col(op.a) + rad * cosf(phi);
+            col(op.c + 1) = col(op.a + 1) + rad * sinf(phi);
+            break;
+        }
+        case NFISAM_SIM_NH_OBS: {                 // simulated range with the regular or the inflated sigma
+            const Rand r = draw(a.seed, sample, o);
+            const float dx = col(op.b) - col(op.a), dy = col(op.b + 1) - col(op.a + 1);
+            col(op.c) = sqrtf(dx * dx + dy * dy) + ((r.u2 < op.p[2]) ? op.p[0] : op.p[1]) * r.z0;
+            break;
+        }
         default: break;
         }
     }
@@ -169,9 +184,9 @@ extern "C" int nfisam_simulate_clique(const nfisam_sim_op* ops, int n_ops, int n
         return NFISAM_ERR_ARG;
     for (int o = 0; o < n_ops; ++o) {
         const nfisam_sim_op& op = ops[o];
-        const int w = (op.code == NFISAM_SIM_COPY) ? op.k : ((op.code == NFISAM_SIM_RING) ? 2 :
-                      ((op.code == NFISAM_SIM_RANGE_OBS || op.code == NFISAM_SIM_ADA_OBS) ? 1 : 3));
-        if (op.code < NFISAM_SIM_COPY || op.code > NFISAM_SIM_ADA_OBS || op.c < 0 || op.c + w > D_total) return NFISAM_ERR_ARG;
+        const int w = (op.code == NFISAM_SIM_COPY) ? op.k : ((op.code == NFISAM_SIM_RING || op.code == NFISAM_SIM_NH_RING) ? 2 :
+                      ((op.code == NFISAM_SIM_RANGE_OBS || op.code == NFISAM_SIM_ADA_OBS || op.code == NFISAM_SIM_NH_OBS) ? 1 : 3));
+        if (op.code < NFISAM_SIM_COPY || op.code > NFISAM_SIM_NH_OBS || op.c < 0 || op.c + w > D_total) return NFISAM_ERR_ARG;
         if (op.code == NFISAM_SIM_COPY && (op.src == 0 || op.k < 1)) return NFISAM_ERR_ARG;
         if (op.code == NFISAM_SIM_ADA_OBS && (op.k < 1 || op.k > 4)) return NFISAM_ERR_ARG;
     }

@@ -415,7 +415,8 @@ class SimOp(C.Structure):
 
 
 SIM_MAX_OPS = 40
-SIM_COPY, SIM_PRIOR_SE2, SIM_REL_FWD, SIM_REL_BWD, SIM_REL_OBS, SIM_RING, SIM_RANGE_OBS, SIM_ADA_OBS = range(1, 9)
+SIM_COPY, SIM_PRIOR_SE2, SIM_REL_FWD, SIM_REL_BWD, SIM_REL_OBS, SIM_RING, SIM_RANGE_OBS, SIM_ADA_OBS, SIM_NH_RING, \
+    SIM_NH_OBS = range(1, 11)
 assert C.sizeof(SimOp) == 80
 
 

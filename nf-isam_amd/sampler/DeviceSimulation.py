@@ -22,8 +22,9 @@ from typing import Dict, List
 import numpy as np
 import torch
 
-from factors.Factors import (AmbiguousDataAssociationFactor, SE2R2RangeGaussianLikelihoodFactor,
-                             SE2RelativeGaussianLikelihoodFactor, UnarySE2ApproximateGaussianPriorFactor)
+from factors.Factors import (AmbiguousDataAssociationFactor, BinaryFactorWithNullHypo,
+                             SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor,
+                             UnarySE2ApproximateGaussianPriorFactor)
 
 
 class DeviceSimulationUnsupported(NotImplementedError):
@@ -116,6 +117,17 @@ class TorchSimulationBackend(object):
             d = var2[:, i2] - var1[:, i1]
             n = d.shape[0]
             return (torch.sqrt((d * d).sum(1)) + f._sigma * torch.randn(n, device=self.device)).reshape(n, 1)
+        if isinstance(f, BinaryFactorWithNullHypo):
+            ref = var1 if var1 is not None else var2
+            n = ref.shape[0]
+            out = None
+            for (lo, hi), c in zip(self._split(f, n), f.components):
+                if hi > lo:
+                    part = self.binary(c, var1=None if var1 is None else var1[lo:hi], var2=None if var2 is None else var2[lo:hi])
+                    if out is None:
+                        out = torch.zeros(n, part.shape[1], device=self.device)
+                    out[lo:hi] = part
+            return out
         raise DeviceSimulationUnsupported(type(f).__name__)
 
     # ---- k-way association factors -------------------------------------------------------------------
@@ -165,6 +177,11 @@ class FusedSimulationBackend(object):
 
     def __init__(self, device):
         self.device = torch.device(device)
+
+    @staticmethod
+    def _nh_range(f):
+        return isinstance(f, BinaryFactorWithNullHypo) and len(f.components) == 2 and \
+            all(isinstance(c, SE2R2RangeGaussianLikelihoodFactor) for c in f.components)
 
     @staticmethod
     def _chol6(f):
@@ -222,6 +239,10 @@ class FusedSimulationBackend(object):
                          p=list(f.observation) + self._chol6(f))
                 elif isinstance(f, SE2R2RangeGaussianLikelihoodFactor) and dst.dim == 2:
                     emit(nh.SIM_RING, a=column(src), c=column(dst), p=[float(f._observation[0]), f._sigma])
+                elif self._nh_range(f) and dst.dim == 2:
+                    c0, c1 = f.components
+                    emit(nh.SIM_NH_RING, a=column(src), c=column(dst),
+                         p=[float(np.ravel(f.observation)[0]), c0._sigma, c1._sigma, float(f.weights[0])])
                 else:
                     raise DeviceSimulationUnsupported(type(f).__name__)
             elif kind == "observe":
@@ -231,6 +252,10 @@ class FusedSimulationBackend(object):
                     emit(nh.SIM_REL_OBS, a=column(f.var1), b=column(f.var2), c=ocol, p=[0, 0, 0] + self._chol6(f))
                 elif isinstance(f, SE2R2RangeGaussianLikelihoodFactor):
                     emit(nh.SIM_RANGE_OBS, a=column(f.var1), b=column(f.var2), c=ocol, p=[f._sigma])
+                elif self._nh_range(f):
+                    c0, c1 = f.components
+                    emit(nh.SIM_NH_OBS, a=column(f.var1), b=column(f.var2), c=ocol,
+                         p=[c0._sigma, c1._sigma, float(f.weights[0])])
                 else:
                     raise DeviceSimulationUnsupported(type(f).__name__)
                 ocol += f.observation_var.dim

@@ -27,20 +27,22 @@ class SimulationBasedSampler:
             ("prior", f)            draw all variables of a prior factor
             ("draw", f, dst)        draw variable `dst` of binary factor f from its other (already drawn) end
             ("observe", f)          simulated measurement of a binary factor whose two ends are drawn
+                                    (binary factors include the two-hypothesis BinaryFactorWithNullHypo)
             ("assoc_obs", f)        simulated measurement of a k-way association factor
             ("assoc_observer", f)   draw the observer of an association factor from its candidates
         (reference: src/sampler/SimulationBasedSampler.py:14-133)."""
         priors, binaries, null_hypo, assoc = unpack_prior_binary_nh_da_factors(self.factors)
-        if null_hypo:
-            raise NotImplementedError("null-hypothesis factors are not rebuilt (SURVEY.md §8 f-2)")
         steps, have = [], set()
         for f in priors:                              # assumes priors do not overlap
             steps.append(("prior", f))
             have.update(f.vars)
         queue = list(binaries)
+        pending_nh = list(null_hypo)       # possibly-outlier factors are scheduled once the plain binaries are used up
         deferred = []          # factors that could only be simulated "small -> large" (landmark -> pose)
         stalled = 0
-        while queue:
+        while queue or pending_nh:
+            if not queue:
+                queue, pending_nh = pending_nh, []
             f = queue.pop(0)
             have1, have2 = f.var1 in have, f.var2 in have
             if have1 and have2:

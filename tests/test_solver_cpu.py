@@ -360,3 +360,37 @@ def test_simulation_plan_and_fused_op_table(monkeypatch):
     odd._correlated_Rt = False
     with pytest.raises(DeviceSimulationUnsupported):
         SimulationBasedSampler([fs[0], odd], [X[0], X[1]]).sample(10, backend=FusedSimulationBackend("cpu"))
+
+
+def test_null_hypothesis_factor_and_its_place_in_the_schedule():
+    """BinaryFactorWithNullHypo (reference: src/factors/Factors.py:3300-3462): a range measurement that is an outlier
+    with probability w1 (same measurement, sigma inflated by null_sigma_scale); text round trip, mixture statistics, and
+    the sampler schedules such factors after all plain binary factors (src/sampler/SimulationBasedSampler.py:38-45)."""
+    from factors.Factors import BinaryFactorWithNullHypo, UnarySE2ApproximateGaussianPriorFactor
+    X0, X1 = SE2Variable("X0"), SE2Variable("X1")
+    L0 = R2Variable("L0", VariableType.Landmark)
+    nhf = BinaryFactorWithNullHypo(X0, L0, np.array([0.8, 0.2]), SE2R2RangeGaussianLikelihoodFactor, 10.0, 0.5,
+                                   null_sigma_scale=8.0)
+    again = Factor.construct_from_text(str(nhf), [X0, X1, L0])
+    assert isinstance(again, BinaryFactorWithNullHypo) and str(again) == str(nhf) and again.null_sigma_scale == 8.0
+    np.random.seed(0)
+    x = np.zeros((40000, 3))
+    lm = nhf.sample(var1=x)
+    r = np.hypot(lm[:, 0], lm[:, 1])
+    assert abs(r.mean() - 10.0) < 0.05 and abs(r.std() - np.sqrt(0.8 * 0.25 + 0.2 * 16.0)) < 0.05
+    obs = nhf.sample(var1=x, var2=np.tile([10.0, 0.0], (40000, 1)))
+    assert obs.shape == (40000, 1) and abs(obs.std() - np.sqrt(0.8 * 0.25 + 0.2 * 16.0)) < 0.05
+    # kurtosis of a two-scale mixture is far from Gaussian
+    z = (obs[:, 0] - obs.mean()) / obs.std()
+    assert (z ** 4).mean() > 6.0
+    prior = UnarySE2ApproximateGaussianPriorFactor(X0, np.zeros(3), np.diag([0.1, 0.1, 0.01]))
+    odo = SE2RelativeGaussianLikelihoodFactor(X0, X1, np.array([5.0, 0, 0]), np.diag([0.04, 0.01, 0.001]))
+    rng_f = SE2R2RangeGaussianLikelihoodFactor(X1, L0, 7.0, 0.5)
+    steps = SimulationBasedSampler([prior, nhf, odo, rng_f], [L0, X0, X1]).plan()
+    # plain binaries first: odometry draws X1, the plain range draws L0 from X1; the null-hypothesis factor then has
+    # both ends sampled and becomes a simulated measurement
+    assert [(s[0], type(s[1]).__name__) for s in steps] == [
+        ("prior", "UnarySE2ApproximateGaussianPriorFactor"), ("draw", "SE2RelativeGaussianLikelihoodFactor"),
+        ("draw", "SE2R2RangeGaussianLikelihoodFactor"), ("observe", "BinaryFactorWithNullHypo")]
+    batch, vs, true_obs = SimulationBasedSampler([prior, nhf, odo, rng_f], [L0, X0, X1]).sample(200)
+    assert batch.shape == (200, 1 + 2 + 3 + 3) and np.allclose(true_obs, [10.0])

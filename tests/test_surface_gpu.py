@@ -244,9 +244,10 @@ def test_device_batch_simulator_matches_host_simulator_in_distribution(backend_n
     """sampler.DeviceSimulation (f-2: one fused kernel per clique, or batched torch ops) draws the same joint
     distribution as the factors' numpy samplers: a clique with
     an SE(2) prior, two odometry steps, range factors to two landmarks (one creates the landmark on a ring, the later
-    ones become simulated-observation columns) and a 2-way ambiguous association."""
-    from factors.Factors import (AmbiguousDataAssociationFactor, SE2R2RangeGaussianLikelihoodFactor,
-                                 SE2RelativeGaussianLikelihoodFactor, UnarySE2ApproximateGaussianPriorFactor)
+    ones become simulated-observation columns), a 2-way ambiguous association and a possibly-outlier range."""
+    from factors.Factors import (AmbiguousDataAssociationFactor, BinaryFactorWithNullHypo,
+                                 SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor,
+                                 UnarySE2ApproximateGaussianPriorFactor)
     import sampler.DeviceSimulation as DS
     from sampler.SimulationBasedSampler import SimulationBasedSampler
     from slam.Variables import R2Variable, SE2Variable, VariableType
@@ -260,7 +261,9 @@ def test_device_batch_simulator_matches_host_simulator_in_distribution(backend_n
           SE2R2RangeGaussianLikelihoodFactor(X[1], L1, 9.0, 0.5),
           SE2R2RangeGaussianLikelihoodFactor(X[2], L0, 11.0, 0.5),
           AmbiguousDataAssociationFactor(X[2], [L0, L1], np.array([0.5, 0.5]), SE2R2RangeGaussianLikelihoodFactor, 10.0,
-                                         0.5)]
+                                         0.5),
+          BinaryFactorWithNullHypo(X[1], L0, np.array([0.7, 0.3]), SE2R2RangeGaussianLikelihoodFactor, 11.5, 0.5,
+                                   null_sigma_scale=6.0)]
     order = [L0, L1] + X
     n = 6000
     np.random.seed(0); torch.manual_seed(0)

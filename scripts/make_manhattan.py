@@ -8,13 +8,15 @@ src/manhattan_world_with_range/Simulator.py:117-190,253-316; the shipped instanc
     column, one vertex per step; pose heading = direction of travel (turn in place, then drive one cell);
   * odometry: relative pose perturbed on the manifold with cov diag((20*[s, s/5, s/10])^2), s = 0.01;
     prior on X0 with cov diag(1e-4, 1e-6, 1e-8);
-  * every pose measures the range (sigma 2 m) to ONE random beacon.  With probability p_ada (0.4), if that beacon
-    is already in the graph and at least two beacons are, the measurement becomes an
-    AmbiguousDataAssociationFactor over the true beacon and up to max_ada-1 other known ones (uniform weights);
-    otherwise a plain range factor (which introduces the beacon if it is new).
+  * every pose measures the range (sigma 2 m) to ONE random beacon.  With probability p_outlier (0 in the shipped
+    cases) the measurement is an outlier: shifted by outlier_scale * sigma and wrapped in a BinaryFactorWithNullHypo
+    (weights .5/.5, null sigma scale = outlier_scale = 5).  Else with probability p_ada (0.4), if that beacon is
+    already in the graph and at least two beacons are, it becomes an AmbiguousDataAssociationFactor over the true
+    beacon and up to max_ada-1 other known ones (uniform weights); otherwise a plain range factor (which introduces
+    the beacon if it is new).
 With the default robot area (3,3)-(15,14) the walk has 46 - 1 + 156 = 201 poses ("200 poses").
 
-usage: make_manhattan.py out.fg [seed] [x0 y0 x1 y1]
+usage: make_manhattan.py out.fg [seed] [x0 y0 x1 y1]      (P_OUTLIER=<prob> in the environment adds outliers)
 """
 import os
 import sys
@@ -23,7 +25,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd"))
-from factors.Factors import (AmbiguousDataAssociationFactor, SE2R2RangeGaussianLikelihoodFactor,   # noqa: E402
+from factors.Factors import (AmbiguousDataAssociationFactor, BinaryFactorWithNullHypo,   # noqa: E402
+                             SE2R2RangeGaussianLikelihoodFactor,
                              SE2RelativeGaussianLikelihoodFactor, UnarySE2ApproximateGaussianPriorFactor)
 from geometry.TwoDimension import se2_compose, se2_exp, se2_inverse   # noqa: E402
 from slam.FactorGraphSimulator import factor_graph_to_string   # noqa: E402
@@ -45,7 +48,8 @@ def boundary_then_lawnmower(x0, y0, x1, y1):
     return edge + lawn
 
 
-def generate(seed=0, area=(3, 3, 15, 14), n_beacons=4, range_std=2.0, odom_scale=0.01, p_ada=0.4, max_ada=3):
+def generate(seed=0, area=(3, 3, 15, 14), n_beacons=4, range_std=2.0, odom_scale=0.01, p_ada=0.4, max_ada=3,
+             p_outlier=0.0, outlier_scale=5.0):
     rng = np.random.RandomState(seed)
     verts = [(i, j) for i in range(2, 18) for j in range(2, 18)]
     beacons = [verts[k] for k in rng.choice(len(verts), size=n_beacons, replace=False)]
@@ -60,7 +64,14 @@ def generate(seed=0, area=(3, 3, 15, 14), n_beacons=4, range_std=2.0, odom_scale
         name = "L%d" % rng.randint(n_beacons)
         r = float(np.linalg.norm(beacon_xy[name] - pose[:2])) + range_std * rng.randn()
         var = R2Variable(name, variable_type=VariableType.Landmark)
-        if rng.rand() < p_ada and var in known and len(known) > 1:
+        odd = rng.rand()
+        if odd < p_outlier:
+            if var not in known:
+                known.append(var)
+                truth[var] = beacon_xy[name]
+            factors.append(BinaryFactorWithNullHypo(pose_var, var, np.array([.5, .5]), SE2R2RangeGaussianLikelihoodFactor,
+                                                    r + outlier_scale * range_std, range_std, null_sigma_scale=outlier_scale))
+        elif odd < p_outlier + p_ada and var in known and len(known) > 1:
             others = [v for v in known if v != var]
             rng.shuffle(others)
             observed = [var] + others[:max_ada - 1]
@@ -96,7 +107,7 @@ if __name__ == "__main__":
     out = sys.argv[1]
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     area = tuple(int(v) for v in sys.argv[3:7]) if len(sys.argv) >= 7 else (3, 3, 15, 14)
-    vs, tr, fs = generate(seed=seed, area=area)
+    vs, tr, fs = generate(seed=seed, area=area, p_outlier=float(os.environ.get("P_OUTLIER", "0")))
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     with open(out, "w") as fh:
         fh.write(factor_graph_to_string(vs, fs, tr))

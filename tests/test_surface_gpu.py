@@ -285,3 +285,48 @@ def test_device_batch_simulator_matches_host_simulator_in_distribution(backend_n
     a, b = host[:1500] / scale, d[:1500] / scale
     floor = mmd_rbf(host[:1500] / scale, host[1500:3000] / scale, np.sqrt(host.shape[1]))
     assert mmd_rbf(a, b, np.sqrt(host.shape[1])) < max(0.03, 3 * floor)
+
+
+def test_fused_simulator_ops_are_exact_without_noise():
+    """With (almost) no noise the simulation is deterministic apart from ring bearings: every SE(2) op of the fused kernel
+    (prior, odometry forward and backward, odometry as a measurement, simulated range) must reproduce the host
+    factors' numpy algebra."""
+    from factors.Factors import (SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor,
+                                 UnarySE2ApproximateGaussianPriorFactor)
+    from sampler.DeviceSimulation import FusedSimulationBackend
+    from sampler.SimulationBasedSampler import SimulationBasedSampler
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    X = [SE2Variable("X%d" % i) for i in range(4)]
+    L0 = R2Variable("L0", VariableType.Landmark)
+    tiny = np.diag([1e-18, 1e-18, 1e-18])
+    fs = [UnarySE2ApproximateGaussianPriorFactor(X[1], np.array([3.0, -1.0, 2.8]), tiny),
+          SE2RelativeGaussianLikelihoodFactor(X[1], X[2], np.array([4.0, 0.7, 1.1]), tiny),      # forward: X2 from X1
+          SE2RelativeGaussianLikelihoodFactor(X[0], X[1], np.array([2.0, -0.5, -2.9]), tiny),    # backward: X0 from X1
+          SE2RelativeGaussianLikelihoodFactor(X[2], X[3], np.array([1.0, 1.0, 3.0]), tiny),
+          SE2RelativeGaussianLikelihoodFactor(X[0], X[3], np.array([0.0, 0.0, 0.0]), tiny),      # both ends drawn: measurement
+          SE2R2RangeGaussianLikelihoodFactor(X[2], L0, 6.0, 1e-9),                               # ring (random bearing)
+          SE2R2RangeGaussianLikelihoodFactor(X[0], L0, 5.0, 1e-9)]                               # simulated range
+    order = [L0] + X
+    n = 300
+    np.random.seed(1)
+    host, hv, _ = SimulationBasedSampler(fs, order).sample(n)
+    devb, dv, _ = SimulationBasedSampler(fs, order).sample(n, backend=FusedSimulationBackend(DEV))
+    d = devb.cpu().numpy().astype(np.float64)
+    assert [str(v.name) for v in hv] == [str(v.name) for v in dv] and host.shape == d.shape == (n, 4 + 2 + 12)
+    names = [str(v.name) for v in hv]
+    # columns: [odometry measurement (3) | range measurement (1) | L0 (2) | X0..X3 (3 each)]
+    pose_cols = slice(6, 18)
+    ang = [8, 11, 14, 17]
+    lin = [c for c in range(6, 18) if c not in ang]
+    np.testing.assert_allclose(d[:, lin], host[:, lin], atol=2e-5)
+    dth = np.abs((d[:, ang] - host[:, ang] + np.pi) % (2 * np.pi) - np.pi)
+    assert dth.max() < 2e-6
+    # the odometry measurement between X0 and X3 (deterministic), angle compared modulo 2 pi
+    np.testing.assert_allclose(d[:, 0:2], host[:, 0:2], atol=5e-5)
+    assert np.abs((d[:, 2] - host[:, 2] + np.pi) % (2 * np.pi) - np.pi).max() < 5e-6
+    # the landmark sits on the ring of radius 6 around X2 (bearing random), and the simulated range is its distance to X0
+    x2, x0 = d[:, 12:14], d[:, 6:8]
+    np.testing.assert_allclose(np.linalg.norm(d[:, 4:6] - x2, axis=1), 6.0, atol=1e-4)
+    np.testing.assert_allclose(d[:, 3], np.linalg.norm(d[:, 4:6] - x0, axis=1), atol=1e-4)
+    phi = np.arctan2(d[:, 5] - x2[:, 1], d[:, 4] - x2[:, 0])
+    assert phi.min() < -2.5 and phi.max() > 2.5 and abs(np.mean(np.cos(phi))) < 0.2

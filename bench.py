@@ -313,6 +313,15 @@ def main():
                 out["wall_clock_per_incremental_update"] = incremental_update_wallclock()
             except Exception as e:   # noqa: BLE001  (must never break the contract line)
                 out["wall_clock_per_incremental_update"] = {"error": str(e)[:200]}
+        vj = os.path.join(ROOT, "profiles", "r01_valu_issue_utilisation.json")
+        if os.path.exists(vj):   # the binding roofline of this path is VALU issue: counters from separate --pmc passes
+            try:
+                v = json.load(open(vj))
+                out["roofline"]["valu_issue_utilisation"] = {"single_clique_C2": v["single_clique_C2"]["utilisation"],
+                                                             "batch_64_cliques": v["batch_64_cliques_n2000_D15"]["utilisation"],
+                                                             "source": "profiles/r01_valu_issue_utilisation.json"}
+            except Exception:   # noqa: BLE001
+                pass
         tj = os.path.join(ROOT, "profiles", "r01_train_kernel_traffic.json")
         if os.path.exists(tj):   # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/README.md)
             try:

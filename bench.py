@@ -58,6 +58,35 @@ def c2_clique(n, seed):
     return s, circular
 
 
+def ring_clique(n, n_lmk, n_pose, n_obs, rng):
+    """Synthetic clique of the range-only SLAM family (configs C3 / Plaza shape): columns
+    [obs (n_obs) | landmarks xy (n_lmk) | poses x y theta (n_pose)]; every pose is a prior pose pushed through odometry
+    noise, landmark j sits on a ring around pose 0, observation k is a noisy range pose(k % n_pose) -> landmark
+    (k % n_lmk).  D = n_obs + 2 n_lmk + 3 n_pose."""
+    poses = []
+    base = np.zeros((n, 3))
+    for p in range(n_pose):
+        v = rng.randn(n, 3) * np.array([0.2, 0.04, 0.02]) + np.array([20.0 * p, 0.0, 0.0])
+        poses.append(base + v)
+    lm = []
+    for j in range(n_lmk):
+        r = 42.4 + 10.0 * j + 2.0 * rng.randn(n)
+        phi = rng.uniform(-np.pi, np.pi, n)
+        lm.append(np.stack([poses[0][:, 0] + r * np.cos(phi), poses[0][:, 1] + r * np.sin(phi)], 1))
+    obs = [np.hypot(lm[k % n_lmk][:, 0] - poses[k % n_pose][:, 0], lm[k % n_lmk][:, 1] - poses[k % n_pose][:, 1]) +
+           2.0 * rng.randn(n) for k in range(n_obs)]
+    s = np.concatenate([np.stack(obs, 1)] + lm + poses, 1)
+    circ = [False] * (n_obs + 2 * n_lmk) + [False, False, True] * n_pose
+    return s, circ
+
+
+# (n_lmk, n_pose, n_obs) of BASELINE config[2] "C3": 8 cliques, D = 6 8 8 10 10 12 12 12, n = 2000 each
+C3_SHAPES = [(1, 1, 1), (2, 1, 1), (2, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2)]
+# Plaza1 / Manhattan clique shapes (D = 15, 16, 17)
+PLAZA_SHAPE = (3, 2, 3)
+SHAPE_OF_D = {15: (3, 2, 3), 16: (2, 3, 3), 17: (3, 3, 2)}
+
+
 def normalize(samples, circular):
     """NFiSAM.normalize_training_samples (src/slam/NFiSAM.py:515-548), host side, not timed."""
     from scipy.stats import circmean

@@ -1206,6 +1206,11 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
     const int F = D - Ds;
     float* xs = smem;                 // [D][TILE]  row being reconstructed
     float* zs = xs + D * TILE;        // [F][TILE]  latent of the current layer
+    // L > 1 with given columns: ych[l] = the given columns as layer l sees them (pushed through the marginal flow of
+    // layers 0..l-1; the flow is autoregressive, so they depend on the given columns only).  The reference conditions
+    // every layer on the raw columns (src/slam/NFiSAM.py:151-152), which inverts no composition.
+    const bool chain = (L > 1 && Ds > 0);
+    float* ych = chain ? (zs + F * TILE) : xs;      // [L][Ds][TILE]
     // given columns: normalise (NFiSAM.py:96-106)
     for (int e = lane; e < Ds * TILE; e += TILE) {
         const int p = e / Ds, k = e - p * Ds;
@@ -1215,7 +1220,7 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
             const float d = v - mean[k];
             v = ((circ != nullptr && circ[k]) ? wrap_pi(d) : d) / stdv[k];
         }
-        xs[k * TILE + p] = v;
+        ych[k * TILE + p] = v;
     }
     for (int e = lane; e < F * TILE; e += TILE) {
         const int p = e / F, k = e - p * F;
@@ -1225,9 +1230,25 @@ __global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict
     __syncthreads();
     cfloat* kp = (cfloat*)kparams;
     const int Pk = layer_stride > 0 ? layer_stride : LY::count(D);
+    if (chain) {
+        for (int l = 0; l + 1 < L; ++l) {
+            cfloat* lp = kp + (size_t)l * Pk;
+            const float* yin = ych + (size_t)l * Ds * TILE;
+            float* yout = ych + (size_t)(l + 1) * Ds * TILE;
+            for (int i = 0; i < Ds; ++i) {
+                float h1[H], h2[H], th[PoP];
+                load_theta<K, H, cfloat*>(lp, i, yin, TILE, lane, h1, h2, th);
+                Spline<K> S;
+                float yi, lad;
+                spline_eval<K, PoP, false>(yin[i * TILE + lane], th, B, S, yi, lad);
+                yout[i * TILE + lane] = yi;
+            }
+        }
+    }
     float ld = 0.0f;
     for (int l = L - 1; l >= 0; --l) {
         cfloat* lp = kp + (size_t)l * Pk;
+        if (chain) for (int i = 0; i < Ds; ++i) xs[i * TILE + lane] = ych[((size_t)l * Ds + i) * TILE + lane];
         for (int i = Ds; i < D; ++i) {
             float h1[H], h2[H], th[PoP];
             load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
@@ -1268,7 +1289,7 @@ template <int K, int H>
 __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_post_clique* __restrict__ table,
                                                                 int n_cliques, const int32_t* __restrict__ cols,
                                                                 const float* __restrict__ obs, float B, int L, int n,
-                                                                const float* __restrict__ Zt, float* __restrict__ St) {
+                                                                int dmax, const float* __restrict__ Zt, float* __restrict__ St) {
     using LY = Layout<K, H>;
     constexpr int PoP = LY::PoP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1277,6 +1298,7 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_pos
     const bool valid = p < n;
     const size_t pp = valid ? (size_t)p : 0;
     float* xs = smem;                       // [Dmax][TILE]
+    float* ych = xs + (size_t)dmax * TILE;  // [L][Dmax][TILE] given columns per layer (L > 1 only, see nsf_inverse_kernel)
     int zoff = 0;                           // latent rows are consumed in walk order
     for (int c = 0; c < n_cliques; ++c) {
         const nfisam_post_clique q = table[c];
@@ -1284,16 +1306,34 @@ __global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_pos
         const float* mean = q.mean;
         const float* stdv = q.std;
         const uint8_t* circ = q.circular;
+        const bool chain = (L > 1 && Ds > 0);
+        float* y0 = chain ? ych : xs;
         // given columns: true observations (same for every sample) then the separator samples
         for (int k = 0; k < Ds; ++k) {
             float v = (k < n_obs) ? obs[q.obs_off + k] : St[(size_t)cols[q.sep_off + (k - n_obs)] * n + pp];
             const float d = v - mean[k];
-            xs[k * TILE + lane] = (circ[k] ? wrap_pi(d) : d) / stdv[k];
+            y0[k * TILE + lane] = (circ[k] ? wrap_pi(d) : d) / stdv[k];
         }
         cfloat* kp = (cfloat*)q.kparams;
         const int Pk = LY::count(q.D_model);
+        if (chain) {
+            for (int l = 0; l + 1 < L; ++l) {
+                cfloat* lp = kp + (size_t)l * Pk;
+                const float* yin = ych + (size_t)l * dmax * TILE;
+                float* yout = ych + (size_t)(l + 1) * dmax * TILE;
+                for (int i = 0; i < Ds; ++i) {
+                    float h1[H], h2[H], th[PoP];
+                    load_theta<K, H, cfloat*>(lp, i, yin, TILE, lane, h1, h2, th);
+                    Spline<K> S;
+                    float yi, lad;
+                    spline_eval<K, PoP, false>(yin[i * TILE + lane], th, B, S, yi, lad);
+                    yout[i * TILE + lane] = yi;
+                }
+            }
+        }
         for (int l = L - 1; l >= 0; --l) {
             cfloat* lp = kp + (size_t)l * Pk;
+            if (chain) for (int i = 0; i < Ds; ++i) xs[i * TILE + lane] = ych[((size_t)l * dmax + i) * TILE + lane];
             for (int i = Ds; i < D; ++i) {
                 float h1[H], h2[H], th[PoP];
                 load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
@@ -1732,7 +1772,7 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
         !(B > 0) || (Ds > 0 && x_sep == nullptr) || (mean != nullptr && stdv == nullptr))
         return NFISAM_ERR_ARG;
     if (n == 0) return NFISAM_OK;
-    const size_t lds = ((size_t)D + (D - Ds)) * TILE * sizeof(float);
+    const size_t lds = ((size_t)D + (D - Ds) + ((L > 1 && Ds > 0) ? (size_t)L * Ds : 0)) * TILE * sizeof(float);
     NSF_DISPATCH(K, H, {
         int rc = set_lds(nsf_inverse_kernel<KK, HH>, lds);
         if (rc) return rc;
@@ -1758,7 +1798,7 @@ extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_
         const size_t lds2 = (2 * wmax + 8 * (size_t)max_D + 2 * (size_t)max_D + (size_t)3 * max_D * XS2) * sizeof(float);
         const char* walk_env = getenv("NFISAM_WALK");          // "plain" forces the one-lane walk (tests, A/B)
         const bool force_plain = (walk_env != nullptr && strcmp(walk_env, "plain") == 0);
-        if (lds2 <= 150 * 1024 && max_D <= 64 && !force_plain) {
+        if (L == 1 && lds2 <= 150 * 1024 && max_D <= 64 && !force_plain) {
             int rc = set_lds(nsf_posterior_walk2_kernel<KK, HH>, lds2);
             if (rc) return rc;
             WalkArgs wa;
@@ -1767,11 +1807,11 @@ extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_
             hipLaunchKernelGGL((nsf_posterior_walk2_kernel<KK, HH>), dim3((n + TILE2 - 1) / TILE2), dim3(64), lds2,
                                (hipStream_t)stream, wa);
         } else {
-            const size_t lds = (size_t)max_D * TILE * sizeof(float);
+            const size_t lds = (size_t)max_D * TILE * sizeof(float) * (L > 1 ? (size_t)(L + 1) : 1);
             int rc = set_lds(nsf_posterior_walk_kernel<KK, HH>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL((nsf_posterior_walk_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds,
-                               (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, Zt, St);
+                               (hipStream_t)stream, table, n_cliques, cols, obs, B, L, n, max_D, Zt, St);
         }
     });
     HIP_TRY(hipGetLastError());

@@ -316,21 +316,35 @@ int FN(nsf_oracle_backward)(const R* x, const R* blob, int n, int D, int K, int 
 }
 
 /* ---- inverse: z[n,D-Ds] (+ x_sep[n,Ds] or NULL) -> x_free[n,D-Ds], logdet[n] (optional).
- * For L>1 every layer is conditioned on the same x_sep (src/slam/NFiSAM.py:151-152). */
+ * L == 1 is the reference (src/flows/flows.py:115-137, src/slam/NFiSAM.py:140-155).  For L > 1 the reference
+ * conditions every layer on the same raw x_sep (NFiSAM.py:151-152), which inverts nothing (its multi-layer
+ * forward is scrambled as well).  Here the given columns are pushed through the marginal flow
+ * of layers 0..l-1 first (the flow is autoregressive, so the first Ds columns of every layer's input depend on
+ * x_sep only), and layer l is conditioned on them: forward(concat(x_sep, inverse(z, x_sep))) returns z. */
 int FN(nsf_oracle_inverse)(const R* z, const R* x_sep, const R* blob, int n, int D, int Ds, int K,
                            int H, R B, int L, R* x_out, R* logdet) {
-    if (K > MAXK || H > MAXH || D > MAXD || Ds < 0 || Ds >= D) return 1;
+    if (K > MAXK || H > MAXH || D > MAXD || Ds < 0 || Ds >= D || L < 1 || L > 16) return 1;
     size_t P = FN(nsf_oracle_param_count)(D, K, H);
     int F = D - Ds;
 #pragma omp parallel for schedule(static)
     for (int p = 0; p < n; ++p) {
-        R row[MAXD], cur[MAXD], h1[MAXH], h2[MAXH], theta[3 * MAXK];
+        R ys[16][MAXD], row[MAXD], cur[MAXD], h1[MAXH], h2[MAXH], theta[3 * MAXK];
         FN(Spl) S;
-        for (int i = 0; i < Ds; ++i) row[i] = x_sep[(size_t)p * Ds + i];
+        for (int i = 0; i < Ds; ++i) ys[0][i] = x_sep[(size_t)p * Ds + i];
+        for (int l = 0; l + 1 < L; ++l) {           /* given columns as seen by layer l + 1 */
+            const R* lb = blob + (size_t)l * P;
+            for (int i = 0; i < Ds; ++i) {
+                const R* th = lb;
+                if (i > 0) { FN(cond_fwd)(ys[l], i, lb + FN(dim_off)(i, K, H), K, H, h1, h2, theta); th = theta; }
+                FN(spline_eval)(ys[l][i], th, K, B, 0, &S);
+                ys[l + 1][i] = S.out;
+            }
+        }
         for (int i = 0; i < F; ++i) cur[i] = z[(size_t)p * F + i];
         R ld = 0;
         for (int l = L - 1; l >= 0; --l) {
             const R* lb = blob + (size_t)l * P;
+            for (int i = 0; i < Ds; ++i) row[i] = ys[l][i];
             for (int i = Ds; i < D; ++i) {
                 const R* th = lb;
                 if (i > 0) { FN(cond_fwd)(row, i, lb + FN(dim_off)(i, K, H), K, H, h1, h2, theta); th = theta; }

@@ -236,13 +236,24 @@ def inverse(z, blob, K, H, B, L=1):
 
 
 def inverse_given_separator(z, x_sep, blob, K, H, B, L=1):
-    """Normalised-space conditional inverse.  For L>1 every layer is conditioned on the same
-    x_sep, exactly as NormalizingFlowModelWithSeparator.inverse_given_separator does
-    (src/slam/NFiSAM.py:151-152)."""
+    """Normalised-space conditional inverse.  L == 1: NormalizingFlowModelWithSeparator.inverse_given_separator
+    (src/slam/NFiSAM.py:140-155).  For L > 1 the reference conditions every layer on the same raw x_sep
+    (NFiSAM.py:151-152), which is not the inverse of any composition; here layer l is conditioned on the given
+    columns pushed through the marginal flow of layers 0..l-1, so that forward(cat(x_sep, result)) returns z."""
     Ds = 0 if x_sep is None else x_sep.shape[1]
     D = Ds + z.shape[1]
-    for lb in reversed(split_layers(blob, D, K, H, L)):
-        z, _ = layer_inverse(z, lb, K, H, B, x_sep=x_sep, D=D)
+    layers = split_layers(blob, D, K, H, L)
+    seps = [x_sep]
+    for lb in layers[:-1]:
+        if x_sep is None:
+            seps.append(None)
+            continue
+        init, nets = unpack(lb, D, K, H)
+        theta = conditioner(seps[-1], init, nets, upto=Ds)
+        zs, _ = rqs(seps[-1], theta, K, B, inverse=False)
+        seps.append(zs)
+    for lb, xs in zip(reversed(layers), reversed(seps)):
+        z, _ = layer_inverse(z, lb, K, H, B, x_sep=xs, D=D)
     return z
 
 

@@ -13,25 +13,7 @@ K, H, B, L = 9, 8, 5.0, 1
 dev = torch.device("cuda:0")
 
 
-def ring_clique(n, n_lmk, n_pose, n_obs, rng):
-    """columns [obs (n_obs) | landmarks xy (n_lmk) | poses x y theta (n_pose)]: every pose is a prior pose pushed through
-    odometry noise, landmark j sits on a ring around pose 0, observation k is a noisy range pose(k % n_pose) -> landmark
-    (k % n_lmk)."""
-    poses = []
-    base = np.zeros((n, 3))
-    for p in range(n_pose):
-        v = rng.randn(n, 3) * np.array([0.2, 0.04, 0.02]) + np.array([20.0 * p, 0.0, 0.0])
-        poses.append(base + v)
-    lm = []
-    for j in range(n_lmk):
-        r = 42.4 + 10.0 * j + 2.0 * rng.randn(n)
-        phi = rng.uniform(-np.pi, np.pi, n)
-        lm.append(np.stack([poses[0][:, 0] + r * np.cos(phi), poses[0][:, 1] + r * np.sin(phi)], 1))
-    obs = [np.hypot(lm[k % n_lmk][:, 0] - poses[k % n_pose][:, 0], lm[k % n_lmk][:, 1] - poses[k % n_pose][:, 1]) +
-           2.0 * rng.randn(n) for k in range(n_obs)]
-    s = np.concatenate([np.stack(obs, 1)] + lm + poses, 1)
-    circ = [False] * (n_obs + 2 * n_lmk) + [False, False, True] * n_pose
-    return s, circ
+ring_clique = BM.ring_clique
 
 
 def train_batch(shapes, n, iters, seed0):
@@ -59,7 +41,7 @@ def train_batch(shapes, n, iters, seed0):
 
 
 if __name__ == "__main__":
-    c3 = [(1, 1, 1), (2, 1, 1), (2, 1, 1), (1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2)]   # D = 6 8 8 10 10 12 12 12
+    c3 = BM.C3_SHAPES   # D = 6 8 8 10 10 12 12 12
     only = sys.argv[1] if len(sys.argv) > 1 else ""          # "c3" | "scaling" | "" (both)
     out = {}
     if only in ("", "c3"):

@@ -287,61 +287,121 @@ def test_argument_errors_are_loud():
         nh.inverse(x, x, kp, 9, 8, 5.0)       # D would be 6: wrong blob size
 
 
-def test_posterior_tree_walk_equals_per_clique_conditional_sampling():
-    """nfisam_nsf_posterior_walk == a chain of nfisam_nsf_inverse calls with the same latent draws
-    (FactorGraphSolver.sample_posterior semantics, src/slam/FactorGraphSolver.py:497-550).  Latent rows are
-    consumed in walk order (clique c's j-th frontal column takes row sum_{c'<c} n_frontal(c') + j); the
-    destination columns are permuted here so that the two orders differ.  Both kernels (pipelined two-lane
-    walk, plain walk) are checked."""
+def _walk_tree_problem(L, K, H, rng):
+    """Three cliques: root {v0,v1} -> child {v2 | v1} -> leaf {v3 | v2, part of v0}; sample-matrix columns permuted."""
+    total = 9
+    specs = [dict(n_obs=0, sep=[], front=[4, 5, 6, 7, 8]),                 # root: joint of v0, v1
+             dict(n_obs=2, sep=[7, 8], front=[1, 2, 3]),                   # obs(2) | v1 -> v2
+             dict(n_obs=1, sep=[1, 2, 3, 4, 5], front=[0])]                # obs(1) | v2, part of v0 -> v3
+    entries, host = [], []
+    for sp in specs:
+        D = sp["n_obs"] + len(sp["sep"]) + len(sp["front"]) + (1 if sp is specs[1] else 0)   # one model is larger than used
+        blob, _ = make_problem(8, D, K, H, L, seed=int(rng.randint(1000)))
+        mean = (rng.randn(D) * 2).astype(np.float32); std = (0.5 + rng.rand(D)).astype(np.float32)
+        circ_np = (rng.rand(D) < 0.3)
+        obs = rng.randn(sp["n_obs"])
+        entries.append(dict(kparams=kpack(blob, D, K, H, L), mean=dev(mean), std=dev(std),
+                            circular=torch.from_numpy(circ_np.astype(np.uint8)).to(DEV), D_model=D, obs=obs,
+                            sep_cols=sp["sep"], front_cols=sp["front"]))
+        host.append((blob, mean, std, circ_np, D, obs))
+    return total, specs, entries, host
+
+
+def _oracle_walk(specs, host, Zt, n, total, K, H, B, L):
+    """FactorGraphSolver.sample_posterior (src/slam/FactorGraphSolver.py:497-550) with the float64 oracle: per clique
+    normalise the given columns, conditional inverse (truncated flow = first Ds+F dims of the model), un-normalise."""
+    ref = np.zeros((n, total))
+    zrow = 0
+    for sp, (blob, mean, std, circ, D, obs) in zip(specs, host):
+        Ds, F = sp["n_obs"] + len(sp["sep"]), len(sp["front"])
+        given = np.concatenate([np.tile(obs, (n, 1)), ref[:, sp["sep"]]], 1) if Ds else None
+        xs_n = None
+        if Ds:
+            xs_n = O.normalize_samples(given.astype(np.float32), mean, std, circ, 0).astype(np.float64)
+        # the first Ds+F dims of a D-dim autoregressive flow are its (Ds+F)-dim marginal flow: truncate the blob
+        Dt = Ds + F
+        Pt, P = O.param_count(Dt, K, H), O.param_count(D, K, H)
+        tb = np.concatenate([blob[l * P:l * P + Pt] for l in range(L)])
+        z = Zt[zrow:zrow + F, :].T
+        zrow += F
+        xf, _ = CO.inverse(z, xs_n, tb, K, H, B, L, dtype=np.float64)
+        ref[:, sp["front"]] = O.unnormalize_samples(xf.astype(np.float32), mean, std, circ, Ds)
+    return ref
+
+
+@pytest.mark.parametrize("L", [1, 2])
+def test_posterior_tree_walk_matches_float64_oracle_chain(L):
+    """nfisam_nsf_posterior_walk against the ORACLE: a chain of float64 `CO.inverse` calls with the same latent draws
+    (FactorGraphSolver.sample_posterior semantics, src/slam/FactorGraphSolver.py:497-550).  Latent rows are consumed
+    in walk order; the destination columns are permuted so that the two orders differ.  Both kernels (pipelined
+    two-lane walk for L = 1, plain walk) and the per-clique `nfisam_nsf_inverse` path are checked."""
     K, H, B, n = 9, 8, 5.0, 300
-    for L in (1, 2):
-        rng = np.random.RandomState(10 + L)
-        # sample matrix columns: v0 (3) v1 (2) v2 (3) v3 (1); tree: root {v0,v1} -> child {v2 | v1} -> leaf {v3 | v2, v0[0:2]...}
-        total = 9
-        specs = [dict(n_obs=0, sep=[], front=[4, 5, 6, 7, 8]),                 # root: joint of v0, v1
-                 dict(n_obs=2, sep=[7, 8], front=[1, 2, 3]),                   # obs(2) | v1 -> v2
-                 dict(n_obs=1, sep=[1, 2, 3, 4, 5], front=[0])]                # obs(1) | v2, part of v0 -> v3
-        entries, models = [], []
-        for sp in specs:
-            D = sp["n_obs"] + len(sp["sep"]) + len(sp["front"]) + (1 if sp is specs[1] else 0)   # one model is larger than used
-            blob, _ = make_problem(8, D, K, H, L, seed=int(rng.randint(1000)))
-            kp = kpack(blob, D, K, H, L)
-            mean = dev(rng.randn(D) * 2); std = dev(0.5 + rng.rand(D))
-            circ_np = (rng.rand(D) < 0.3)
-            circ = torch.from_numpy(circ_np.astype(np.uint8)).to(DEV)
-            obs = rng.randn(sp["n_obs"])
-            entries.append(dict(kparams=kp, mean=mean, std=std, circular=circ, D_model=D, obs=obs, sep_cols=sp["sep"],
-                                front_cols=sp["front"]))
-            models.append((kp, mean, std, circ, D, obs))
-        Zt = torch.from_numpy(rng.randn(total, n).astype(np.float32)).to(DEV)
-        S = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
-        assert S.shape == (n, total)
-        ref = torch.zeros(n, total, device=DEV)
-        zrow = 0
-        for sp, (kp, mean, std, circ, D, obs) in zip(specs, models):
-            given = []
-            if sp["n_obs"]:
-                given.append(dev(np.tile(obs, (n, 1))))
-            if sp["sep"]:
-                given.append(ref[:, sp["sep"]])
-            xs = torch.cat(given, 1).contiguous() if given else None
-            z = Zt[zrow:zrow + len(sp["front"]), :].t().contiguous()
-            zrow += len(sp["front"])
-            out = nh.inverse(z, xs, kp, K, H, B, L, mean=mean, std=std, circular=circ, model_D=D)
-            ref[:, sp["front"]] = out
-        # a child conditions on its parent's samples: rounding differences of the two code paths are amplified
-        # by the conditioners' slopes along the chain, so the tail is checked at 1e-3 and the bulk at 2e-5
-        def close(a, b):
-            err = np.abs(a.cpu().numpy() - b.cpu().numpy())
-            assert np.quantile(err, 0.99) < 2e-5 and err.max() < 1e-3, (np.quantile(err, 0.99), err.max())
-        close(S, ref)
-        os.environ["NFISAM_WALK"] = "plain"
-        try:
-            S1 = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
-        finally:
-            del os.environ["NFISAM_WALK"]
-        close(S1, ref)
+    rng = np.random.RandomState(10 + L)
+    total, specs, entries, host = _walk_tree_problem(L, K, H, rng)
+    Zt_np = rng.randn(total, n).astype(np.float32)
+    Zt = torch.from_numpy(Zt_np).to(DEV)
+    ref = _oracle_walk(specs, host, Zt_np.astype(np.float64), n, total, K, H, B, L)
+    circ_cols = np.zeros(total, dtype=bool)
+    for sp, (_, _, _, circ, D, _) in zip(specs, host):
+        Ds = sp["n_obs"] + len(sp["sep"])
+        circ_cols[sp["front"]] = circ[Ds:Ds + len(sp["front"])]
+
+    def close(a):
+        # a child conditions on its parent's samples: fp32 rounding is amplified by the conditioners' slopes along
+        # the chain (autoregressive inversion), so the bulk is checked at 2e-4 and the tail at 5e-3
+        d = a - ref
+        d[:, circ_cols] = (d[:, circ_cols] + np.pi) % (2 * np.pi) - np.pi
+        err = np.abs(d)
+        assert np.quantile(err, 0.99) < 2e-4 * L and err.max() < 5e-3 * L, (np.quantile(err, 0.99), err.max())
+
+    S = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
+    assert S.shape == (n, total)
+    close(S.cpu().numpy().astype(np.float64))
+    os.environ["NFISAM_WALK"] = "plain"
+    try:
+        S1 = nh.posterior_walk(entries, total, n, K, H, B, L, DEV, Zt=Zt)
+    finally:
+        del os.environ["NFISAM_WALK"]
+    close(S1.cpu().numpy().astype(np.float64))
+    if L == 1:
         assert not torch.equal(S1, S)      # two different kernels (rounding differs somewhere)
+    # the per-clique path (one nfisam_nsf_inverse call per clique, what FlowsPriorFactor.sample uses)
+    per = torch.zeros(n, total, device=DEV)
+    zrow = 0
+    for sp, e in zip(specs, entries):
+        given = []
+        if sp["n_obs"]:
+            given.append(dev(np.tile(e["obs"], (n, 1))))
+        if sp["sep"]:
+            given.append(per[:, sp["sep"]])
+        xs = torch.cat(given, 1).contiguous() if given else None
+        z = Zt[zrow:zrow + len(sp["front"]), :].t().contiguous()
+        zrow += len(sp["front"])
+        per[:, sp["front"]] = nh.inverse(z, xs, e["kparams"], K, H, B, L, mean=e["mean"], std=e["std"],
+                                         circular=e["circular"], model_D=e["D_model"])
+    close(per.cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.parametrize("L,Ds", [(2, 3), (3, 1), (2, 0)])
+def test_multilayer_conditional_inverse_round_trips(L, Ds):
+    """L > 1 with given columns: layer l is conditioned on the given columns pushed through layers 0..l-1 (DESIGN.md
+    §3.3; the reference's literal loop, src/slam/NFiSAM.py:151-152, inverts no composition).  Property:
+    forward(cat(x_s, inverse_given_separator(z_f, x_s))) == (., z_f); and equality with the float64 oracle."""
+    n, D, K, H, B = 257, 7, 9, 8, 5.0
+    blob, x = make_problem(n, D, K, H, L, seed=70 + L, spread=1.0)
+    kp = kpack(blob, D, K, H, L)
+    rng = np.random.RandomState(L)
+    zf = rng.randn(n, D - Ds).astype(np.float32)
+    xs = x[:, :Ds].copy() if Ds else None
+    xf = nh.inverse(dev(zf), dev(xs) if Ds else None, kp, K, H, B, L)
+    full = torch.cat([dev(xs), xf], 1).contiguous() if Ds else xf
+    z, _, _ = nh.forward(full, kp, K, H, B, L)
+    inside = (full.abs().max(1).values < 4.9).cpu().numpy()
+    err = np.abs(z.cpu().numpy()[:, Ds:] - zf)[inside]
+    assert inside.sum() > n // 2 and np.quantile(err, 0.99) < 1e-3 and err.max() < 2e-2, (np.quantile(err, 0.99), err.max())
+    xo, _ = CO.inverse(zf, xs, blob, K, H, B, L, dtype=np.float64)
+    e2 = np.abs(xf.cpu().numpy() - xo)[inside]
+    assert np.quantile(e2, 0.99) < 3e-4 * L and e2.max() < 1e-2, (np.quantile(e2, 0.99), e2.max())
 
 
 def test_training_is_bitwise_reproducible_for_small_single_layer_launches():

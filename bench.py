@@ -4,25 +4,35 @@
 Metric (BASELINE.json): flow-training samples/sec/GPU := n x iterations / wall time of the
 training loop, timed where the reference times it (src/slam/NFiSAM.py:435,451-492).
 
-Workload at N=1 = BASELINE config[1] ("C2"): one clique, n=4096 particles,
-D=6 columns [range-obs | landmark xy | pose x y theta] drawn from the clique's own generative
-model (ring-shaped posterior), normalised as NFiSAM.normalize_training_samples does, L=4 stacked
-NSF_AR layers, K=9 bins, H=8, B=5, Adam lr=0.02, fixed number of iterations (no early stop).
-A "step" is ONE full-batch training iteration (forward + analytic backward + gradient reduction
-+ Adam).  With N>1 every rank trains its own independent clique of the same shape (weak scaling,
-no data-path collective: independent cliques never exchange data).
+Headline workload at N=1 = BASELINE config[2] ("C3"), the largest single-GPU configuration:
+8 independent cliques of the range-only SLAM family, D = 6 8 8 10 10 12 12 12 columns
+[range obs | landmarks xy | poses x y theta], n = 2000 particles each, drawn from the cliques' own generative
+model, normalised as NFiSAM.normalize_training_samples does, one NSF_AR layer (flow_number = 1, the
+reference's default), K = 9 bins, H = 8, B = 5, Adam lr = 0.01, fixed number of iterations (no early stop),
+trained as ONE batched launch sequence (grid.y = clique).  A "step" is ONE full-batch training iteration of
+all 8 cliques (forward + analytic backward + gradient reduction + Adam).  With N > 1 every rank trains its
+own 8 cliques (weak scaling, no data-path collective: independent cliques never exchange data).
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
-  roofline     : dominant kernel (nsf_train2_kernel) algorithmic FLOP / its average launch
+Launch: `python bench.py --gpus N --steps K --warmup W`.  Under torchrun (WORLD_SIZE set) this process is one
+rank; without it and N > 1 the script starts N child ranks itself BEFORE touching the GPU and relays rank 0's
+line.
+
+Prints ONE JSON line on rank 0 (driver contract), including
+  roofline     : dominant kernel (the gradient kernel of the C3 batch) algorithmic FLOP / its average launch
                  duration, measured live with HIP events, against the fp32 peak of gfx950
-                 (157.3 TFLOP/s = f32 MFMA peak = f32 packed-VALU peak).
+                 (157.3 TFLOP/s = f32 MFMA peak = f32 packed-VALU peak); the binding resource is VALU issue.
+  regimes      : the same live measurement for the other regimes of the path: C2 (BASELINE config[1]: one
+                 clique, 4 stacked layers), one Plaza1-shaped clique (n = 2000, D = 15: the latency regime of the
+                 real datasets) and a batch of 64 such cliques (the throughput regime / scaling shape).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
-                 the reference) timed on the host cores on a bounded sample of the same workload.
+                 the reference) timed on the host cores on a bounded sample of the same workload, next to the
+                 TRUE reference's figures measured in the build container (profiles/r02_cpu_reference_vs_port.json).
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -33,9 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd"))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
-K, H, B, L = 9, 8, 5.0, 4
-N_PART, D = 4096, 6
-LR = 0.02
+K, H, B = 9, 8, 5.0
+LR = 0.01
 
 
 def c2_clique(n, seed):
@@ -126,42 +135,156 @@ def init_blob_np(D, K, H, L, seed):
     return np.concatenate(parts).astype(np.float32)
 
 
-def cpu_baseline(x, blob, budget_s=12.0):
-    """Oracle timed on the host cores: bounded sample of the SAME workload (same batch, same model).
-    The path is ~20k tiny eager ops per iteration, so more threads than ~8 only add overhead
-    (the reference measured 5.2e4 samples/s on 8 threads for this shape): the
-    thread count is capped at 8 and stated in `cores`."""
+# ---- workloads ---------------------------------------------------------------------------------------------
+def c3_problem(seed0):
+    """-> list of (x normalised [2000, D], reference-order blob)."""
+    out = []
+    for c, sh in enumerate(C3_SHAPES):
+        s, circ = ring_clique(2000, *sh, np.random.RandomState(seed0 + c))
+        x, _, _ = normalize(s, circ)
+        out.append((x, init_blob_np(x.shape[1], K, H, 1, seed0 + c)))
+    return out
+
+
+def regime_problem(name, seed0):
+    """-> (list of (x, blob), L)"""
+    if name == "C2_single_clique_n4096_D6_L4":
+        s, circ = c2_clique(4096, seed0)
+        x, _, _ = normalize(s, circ)
+        return [(x, init_blob_np(6, K, H, 4, seed0))], 4
+    if name == "plaza_clique_n2000_D15":
+        s, circ = ring_clique(2000, *PLAZA_SHAPE, np.random.RandomState(seed0))
+        x, _, _ = normalize(s, circ)
+        return [(x, init_blob_np(15, K, H, 1, seed0))], 1
+    if name == "batch64_n2000_D15":
+        out = []
+        for c in range(64):
+            s, circ = ring_clique(2000, *PLAZA_SHAPE, np.random.RandomState(seed0 + c))
+            x, _, _ = normalize(s, circ)
+            out.append((x, init_blob_np(15, K, H, 1, seed0 + c)))
+        return out, 1
+    raise KeyError(name)
+
+
+class Workload:
+    """Device-resident clique batch + the two timed things: whole iterations, and the gradient kernel alone."""
+
+    def __init__(self, problem, L, dev):
+        import torch
+        import nfisam_hip as nh
+        self.torch, self.nh, self.L, self.dev = torch, nh, L, dev
+        self.xs = [torch.from_numpy(x).to(dev) for x, _ in problem]
+        self.kp0 = [nh.pack(torch.from_numpy(b).to(dev), x.shape[1], K, H, L) for x, b in problem]
+        self.n_samples = sum(int(x.shape[0]) for x, _ in problem)
+        self.flop_per_launch = sum(flops_per_sample_iter(x.shape[1], K, H, L) * x.shape[0] for x, _ in problem)
+
+    def batch(self, iters):
+        """`iters` fixed iterations: the window early-stop rule is armed with a tolerance of 0 (never fires) and a window
+        of `iters`, so that the hipGraph chunk length divides `iters` and every iteration is a graph replay."""
+        return self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, H, B, self.L, lr=LR, max_iters=iters,
+                                  average_window=iters, loss_delta_tol=0.0, early_stop=True)
+
+    def time_iterations(self, iters, warmup, barrier):
+        torch = self.torch
+        tbw = self.batch(max(warmup, 1))
+        tbw.run(use_graph=True)
+        tbw.close()
+        tb = self.batch(iters)
+        tb.prepare(use_graph=True)               # one-time graph capture, outside the timed region
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        done = tb.run(use_graph=True)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        assert all(i == iters for i in done), done
+        il = [t.cpu().numpy() for t in tb.iter_loss]
+        for v in il:
+            assert np.all(np.isfinite(v)) and v[iters - 1] < v[0], (v[0], v[iters - 1])
+        tb.close()
+        return dt, ev0.elapsed_time(ev1), float(np.mean([v[0] for v in il])), float(np.mean([v[iters - 1] for v in il]))
+
+    def time_gradient_kernel(self, reps=200):
+        """Average duration of the gradient kernel exactly as a training iteration launches it: `reps` launches captured
+        in a graph (no host launch gaps), HIP events on the stream they run on; includes one ~1.5 us kernel boundary."""
+        torch = self.torch
+        tbk = self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, H, B, self.L, lr=LR, max_iters=10 ** 6,
+                                 early_stop=False)
+        for _ in range(20):
+            tbk.gradient_only()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                tbk.gradient_only()
+        graph.replay()
+        torch.cuda.synchronize()
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        graph.replay()
+        k1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * k0.elapsed_time(k1) / reps
+        tbk.close()
+        return us
+
+    def record(self, iters, warmup, barrier):
+        dt, gpu_ms, l0, l1 = self.time_iterations(iters, warmup, barrier)
+        kus = self.time_gradient_kernel()
+        ach = self.flop_per_launch / (kus * 1e-6) / 1e12
+        return dict(cliques=len(self.xs), D=[int(x.shape[1]) for x in self.xs] if len(self.xs) <= 8 else int(self.xs[0].shape[1]),
+                    particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, iterations=iters,
+                    us_per_iteration=1e6 * dt / iters, gpu_us_per_iteration_events=1e3 * gpu_ms / iters,
+                    samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus,
+                    flop_per_launch=self.flop_per_launch, achieved_tflops=ach, frac_of_fp32_peak=ach / FP32_PEAK_TFLOPS,
+                    first_loss=l0, final_loss=l1), dt
+
+
+def cpu_baseline(problem, budget_s=12.0):
+    """Oracle timed on the host cores: bounded sample of the SAME workload (the eight C3 cliques, one after the other --
+    the reference trains cliques sequentially).  The path is ~4k tiny eager ops per iteration, so more threads than ~8
+    only add overhead: the thread count is capped at 8 and stated in `cores`."""
     import torch
     from oracle import nsf_torch as O
     cores = min(os.cpu_count() or 1, 8)
     torch.set_num_threads(cores)
-    xt = torch.from_numpy(x)
-    b0 = torch.from_numpy(blob)
-    t0 = time.perf_counter()
-    O.train(xt, b0, K, H, B, L, lr=LR, max_iters=1, early_stop=False)        # warm-up + estimate
-    per = time.perf_counter() - t0
-    iters = int(max(2, min(100, budget_s / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    O.train(xt, b0, K, H, B, L, lr=LR, max_iters=iters, early_stop=False)
-    dt = time.perf_counter() - t0
-    out = {"value": x.shape[0] * iters / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": "%d full-batch Adam iterations of the same clique (n=%d, D=%d, L=%d, K=%d) with the "
-                     "PyTorch-eager CPU restatement of the reference path (oracle/nsf_torch.py), %d threads"
-                     % (iters, x.shape[0], x.shape[1], L, K, cores),
-           "ms_per_step": 1e3 * dt / iters}
-    try:   # also the plain-C port (OpenMP over particles), for information
-        os.environ["OMP_NUM_THREADS"] = str(min(os.cpu_count() or 1, 16))
-        from oracle import c_oracle as CO
-        CO.train(x, blob, K, H, B, L, lr=LR, max_iters=1, early_stop=False, dtype=np.float32)
-        it2 = 10
+    t_total, n_total = 0.0, 0
+    per_clique = budget_s / len(problem)
+    iters_used = []
+    for x, blob in problem:
+        xt, b0 = torch.from_numpy(x), torch.from_numpy(blob)
+        O.train(xt, b0, K, H, B, 1, lr=LR, max_iters=1, early_stop=False)        # warm-up (first call pages torch in)
         t0 = time.perf_counter()
-        CO.train(x, blob, K, H, B, L, lr=LR, max_iters=it2, early_stop=False, dtype=np.float32)
-        dt2 = time.perf_counter() - t0
-        out["c_port_value"] = x.shape[0] * it2 / dt2
-        out["c_port_threads"] = int(os.environ["OMP_NUM_THREADS"])
-    except Exception as e:   # noqa: BLE001
-        out["c_port_value"] = None
-        out["c_port_error"] = str(e)[:100]
+        O.train(xt, b0, K, H, B, 1, lr=LR, max_iters=2, early_stop=False)        # estimate
+        per = (time.perf_counter() - t0) / 2
+        iters = int(max(2, min(60, per_clique / max(per, 1e-6))))
+        t0 = time.perf_counter()
+        O.train(xt, b0, K, H, B, 1, lr=LR, max_iters=iters, early_stop=False)
+        t_total += time.perf_counter() - t0
+        n_total += x.shape[0] * iters
+        iters_used.append(iters)
+    out = {"value": n_total / t_total, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": "%s full-batch Adam iterations of the 8 C3 cliques (n=2000, D=6..12, L=1, K=9), one clique after the "
+                     "other, with the PyTorch-eager CPU restatement of the reference path (oracle/nsf_torch.py), %d threads"
+                     % ("/".join(str(i) for i in iters_used), cores)}
+    ref = os.path.join(ROOT, "profiles", "r02_cpu_reference_vs_port.json")
+    if os.path.exists(ref):   # the TRUE reference cannot travel to the GPU box: its figures were taken in the build container
+        try:
+            r = json.load(open(ref))
+            out["reference_measured"] = {
+                "where": "build container (%s, %d threads, torch %s), scripts/cpu_reference_vs_port.py" %
+                         (r["cpu"], r["threads"], r["torch"]),
+                "c3_reference_samples_per_s": r["c3_batch"]["reference_samples_per_s"],
+                "c3_port_samples_per_s": r["c3_batch"]["port_samples_per_s"],
+                "port_over_reference": r["c3_batch"]["port_over_reference"],
+                "note": "the port is ~1.5x FASTER than the reference it stands for (it batches the D spline evaluations "
+                        "of a layer like the reference but skips the reference's per-dim torch.split/.clone/.cuda() "
+                        "scratch tensors), so speed-ups quoted against `value` understate the speed-up over the reference",
+            }
+        except Exception as e:   # noqa: BLE001
+            out["reference_measured"] = {"error": str(e)[:100]}
     return out
 
 
@@ -206,107 +329,90 @@ def incremental_update_wallclock():
             "note": "reference column = example/.../case1/run1/step_timing (authors' GPU, same arguments)"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU) BEFORE this
+    process touches the GPU, relay rank 0's JSON line, exit with the worst child code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--cliques", type=int, default=1, help="independent cliques per GPU (default: config C2 = 1)")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--regime-steps", type=int, default=200, help="iterations timed per secondary regime")
+    ap.add_argument("--no-regimes", action="store_true", help="headline workload only (rocprofv3 runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-update-bench", action="store_true",
                     help="skip the end-to-end incremental-update timing (used for rocprofv3 runs so that the kernel "
-                         "statistics contain the C2 workload only)")
+                         "statistics contain the headline workload only)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))            # nothing above has touched the GPU
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
-    import nfisam_hip as nh
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one GPU (smoke test of the launch path on a
+    # 1-GPU box -- RCCL refuses two ranks on one device)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    # ---- synthetic workload, resident in HBM before the timed region -----------------------
-    nc = args.cliques
-    xs_np, blobs_np = [], []
-    for c in range(nc):
-        s, circ = c2_clique(N_PART, seed=1000 * rank + c)
-        xn, _, _ = normalize(s, circ)
-        xs_np.append(xn)
-        blobs_np.append(init_blob_np(D, K, H, L, seed=7 + 1000 * rank + c))
-    xs = [torch.from_numpy(x).to(dev) for x in xs_np]
-    kp0 = [nh.pack(torch.from_numpy(b).to(dev), D, K, H, L) for b in blobs_np]
-    use_graph = not args.no_graph
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
 
-    # warm-up: W untimed iterations (also instantiates kernels / graphs)
-    tbw = nh.TrainBatch(xs, [p.clone() for p in kp0], K, H, B, L, lr=LR, max_iters=max(args.warmup, 1),
-                        early_stop=False)
-    tbw.run(use_graph=use_graph)
-    tbw.close()
-    # timed: exactly K iterations
-    tb = nh.TrainBatch(xs, [p.clone() for p in kp0], K, H, B, L, lr=LR, max_iters=args.steps, early_stop=False)
-    tb.prepare(use_graph=use_graph)          # one-time graph capture, outside the timed region
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    iters = tb.run(use_graph=use_graph)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    assert all(i == args.steps for i in iters), iters
-    il = tb.iter_loss[0].cpu().numpy()
-    assert np.all(np.isfinite(il)) and il[-1] < il[0], (il[0], il[-1])
-    gpu_ms = ev0.elapsed_time(ev1)
-
+    # ---- headline: C3, resident in HBM before the timed region ---------------------------------
+    problem = c3_problem(seed0=100 + 1000 * rank)
+    wl = Workload(problem, 1, dev)
+    head, dt = wl.record(args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- dominant kernel: average launch duration, HIP events on the launch stream ---------
-    reps = 200
-    tbk = nh.TrainBatch(xs[:1], [kp0[0].clone()], K, H, B, L, lr=LR, max_iters=10 ** 6, early_stop=False)
-
-    def train_kernel_once():   # the gradient kernel exactly as the timed region launches it (per-tile slabs)
-        tbk.gradient_only()
-    for _ in range(20):
-        train_kernel_once()
-    torch.cuda.synchronize()
-    # `reps` launches of the same kernel captured in a graph (no host launch gaps between them), timed
-    # with HIP events on the stream they run on: per-launch duration + one ~1.5 us kernel boundary.
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for _ in range(reps):
-            train_kernel_once()
-    graph.replay()
-    torch.cuda.synchronize()
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
-    graph.replay()
-    k1.record()
-    torch.cuda.synchronize()
-    kern_us = 1e3 * k0.elapsed_time(k1) / reps
-
-    fl = flops_per_sample_iter(D, K, H, L)
-    launch_flops = fl * N_PART
-    achieved = launch_flops / (kern_us * 1e-6) / 1e12
+    regimes = {}
+    if rank == 0 and world == 1 and not args.no_regimes:
+        for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15"):
+            prob, L = regime_problem(name, seed0=7)
+            regimes[name], _ = Workload(prob, L, dev).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
 
     if rank == 0:
-        total = world * nc * N_PART * args.steps
+        total = world * wl.n_samples * args.steps
+        ach = head["achieved_tflops"]
         out = {
             "metric": "flow-training samples/sec/GPU + wall-clock per incremental update",
             "value": total / dt,
@@ -315,26 +421,34 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 single-clique 6-D ring posterior [obs|landmark xy|pose xyθ], n=4096, "
-                                   "NSF_AR x4 layers, K=9, H=8, B=5, Adam lr=0.02, fixed iterations",
-                       "cliques_per_gpu": nc, "particles": N_PART, "D": D, "layers": L, "K": K, "H": H,
-                       "hipgraph": use_graph, "parallelism": "independent cliques per GPU (no collective)"},
-            "per_gpu_value": nc * N_PART * args.steps / dt,
-            "gpu_ms_per_step_events": gpu_ms / args.steps,
-            "final_loss": float(il[-1]), "first_loss": float(il[0]),
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "nsf_train2_kernel<9,8,true>", "kernel_us": kern_us,
-                         "flop_per_launch": launch_flops,
-                         "note": "fp32 VALU/transcendental-issue-bound kernel, latency-bound on this single-clique "
-                                 "workload (189 MFLOP per launch = 1.2 us at peak; 128 tiles x 6 waves on 128 of "
-                                 "256 CUs, 7 dependent unit passes per wave); priced against the fp32 peak "
-                                 "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU). Algorithmic HBM bytes: 98 KB (x) + "
-                                 "110 KB parameters per launch; `traffic` (measured, profiles/) is larger because "
-                                 "every 32-particle tile writes its own 27 KB copy of the gradient with plain stores "
-                                 "(3.5 MB per launch, read once by the Adam kernel) instead of float atomics - no "
-                                 "re-reads, 130 GB/s, far below the HBM bound."},
+            "config": {"workload": "C3 (BASELINE config[2]): 8 independent cliques of the range-only SLAM family per GPU, "
+                                   "D = 6 8 8 10 10 12 12 12, n = 2000 each, NSF_AR x1 layer, K=9, H=8, B=5, Adam lr=0.01, "
+                                   "fixed iterations, one batched launch sequence",
+                       "cliques_per_gpu": len(problem), "particles": 2000, "D": head["D"], "layers": 1, "K": K, "H": H,
+                       "hipgraph": True, "parallelism": "independent cliques per GPU (no collective)"},
+            "per_gpu_value": wl.n_samples * args.steps / dt,
+            "gpu_ms_per_step_events": head["gpu_us_per_iteration_events"] / 1e3,
+            "final_loss": head["final_loss"], "first_loss": head["first_loss"],
+            "roofline": {"bound": "valu_issue", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "nsf_train1_kernel<9,8,3>", "kernel_us": head["gradient_kernel_us"],
+                         "flop_per_launch": head["flop_per_launch"],
+                         "note": "fp32 VALU/transcendental-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, neither HBM nor "
+                                 "MFMA binds; MFMA carries only the weight-gradient GEMMs), priced against the fp32 peak "
+                                 "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  333 MFLOP per launch = 2.1 us at peak: the "
+                                 "C3 launch is 2560 waves of ONE (dim, 64-particle tile) unit each, i.e. one dependent "
+                                 "instruction stream of ~2k VALU + 64 MFMA instructions per wave at 2.5 waves per SIMD - "
+                                 "latency-bound by construction; `regimes.batch64_n2000_D15` is the throughput regime.  "
+                                 "Algorithmic HBM bytes per launch: 608 KB (x) + 112 KB (parameters); `traffic` is null "
+                                 "because it is not measured in this run (PMC passes: profiles/, see `traffic_profiled`)."},
+            "regimes": regimes,
         }
+        tj = os.path.join(ROOT, "profiles", "r02_train_kernel_traffic.json")
+        if os.path.exists(tj):   # HBM bytes per launch from separate rocprofv3 --pmc passes of an EARLIER run of this workload
+            try:
+                out["roofline"]["traffic_profiled"] = dict(json.load(open(tj)), source="profiles/r02_train_kernel_traffic.json")
+            except Exception:   # noqa: BLE001
+                pass
         if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only
             out["wall_clock_per_incremental_update"] = None
         else:
@@ -342,27 +456,11 @@ def main():
                 out["wall_clock_per_incremental_update"] = incremental_update_wallclock()
             except Exception as e:   # noqa: BLE001  (must never break the contract line)
                 out["wall_clock_per_incremental_update"] = {"error": str(e)[:200]}
-        vj = os.path.join(ROOT, "profiles", "r01_valu_issue_utilisation.json")
-        if os.path.exists(vj):   # the binding roofline of this path is VALU issue: counters from separate --pmc passes
-            try:
-                v = json.load(open(vj))
-                out["roofline"]["valu_issue_utilisation"] = {"single_clique_C2": v["single_clique_C2"]["utilisation"],
-                                                             "batch_64_cliques": v["batch_64_cliques_n2000_D15"]["utilisation"],
-                                                             "source": "profiles/r01_valu_issue_utilisation.json"}
-            except Exception:   # noqa: BLE001
-                pass
-        tj = os.path.join(ROOT, "profiles", "r01_train_kernel_traffic.json")
-        if os.path.exists(tj):   # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/README.md)
-            try:
-                out["roofline"]["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
-            except Exception:   # noqa: BLE001
-                pass
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(xs_np[0], blobs_np[0])
+            out["cpu_baseline"] = cpu_baseline(problem)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    tb.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

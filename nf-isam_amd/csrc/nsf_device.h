@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace nsf {
 
@@ -135,6 +136,28 @@ __device__ __forceinline__ void load_row_used(const float* row, float (&w)[N]) {
     for (int j = U; j < N; ++j) w[j] = 0.0f;
 }
 
+// Scalar-path weight rows live in SGPRs (102 per wave).  Left alone, hipcc hoists the s_loads of every later row of a
+// fully unrolled loop above the FMAs of the current rows and then SPILLS the loaded weights to VGPR lanes
+// (v_writelane / v_readlane: two extra VALU instructions per weight, ~1000 per unit).  A scheduling fence after every
+// group of rows keeps at most ~64 weight SGPRs in flight; the fence emits no instruction.
+template <typename WP>
+__device__ __forceinline__ void row_group_fence() {
+    if constexpr (std::is_same<WP, cfloat*>::value) __builtin_amdgcn_sched_barrier(0);
+}
+
+// The backward pass re-reads W2 / W1 that the forward pass of the same unit has read.  Scalar-path loads are
+// invariant loads, so hipcc would CSE the two and keep ~330 weight SGPRs alive from the forward conditioner across the
+// whole spline to the backward conditioner -- i.e. spill every weight to a VGPR lane (v_writelane) and fetch it back
+// (v_readlane) in front of every FMA: two extra VALU instructions per weight.  Passing the pointer through an empty
+// asm hides the equality; the re-load hits the scalar cache.
+__device__ __forceinline__ cfloat* reload_ptr(cfloat* p) {
+    const uint64_t v = (uint64_t)p;                     // wave-uniform by construction: make that explicit for the "s" constraint
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (cfloat*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+__device__ __forceinline__ const float* reload_ptr(const float* p) { return p; }
+
 // ---- conditioner ----------------------------------------------------------------------------
 // xs: LDS, dimension-major with row stride `xstride`: xs[k * xstride + lane] = x_k of this lane's particle.
 // WP = weight pointer type: `cfloat*` (scalar-cache path, SGPR operands) or `const float*` into an
@@ -162,6 +185,7 @@ __device__ __forceinline__ void cond_hidden(WP blk, int i, const float* xs, int 
 #pragma unroll
             for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wq[u][j], xk[u], a[j]);
         }
+        row_group_fence<WP>();
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h1[j] = ftanh(a[j]);
@@ -172,6 +196,7 @@ __device__ __forceinline__ void cond_hidden(WP blk, int i, const float* xs, int 
         load_row<H>(W1 + k * H, wr);
 #pragma unroll
         for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], h1[k], a[j]);
+        if ((k & 7) == 7) row_group_fence<WP>();
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h2[j] = ftanh(a[j]);
@@ -189,6 +214,7 @@ __device__ __forceinline__ void cond_theta(WP blk, int i, const float (&h2)[H],
         load_row<LY::PoP>(W2 + k * LY::PoP, wr);
 #pragma unroll
         for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(wr[o], h2[k], th[o]);
+        if (k & 1) row_group_fence<WP>();
     }
 }
 

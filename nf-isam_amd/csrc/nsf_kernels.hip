@@ -63,8 +63,24 @@ __device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
 // tiles).  slab = true: this tile owns a private copy of the gradient buffer and every entry is written
 // exactly once per iteration with a plain store; the Adam kernel sums the tiles in a fixed order
 // (no memory-side atomic tail on small launches, bitwise-reproducible training).
+typedef __attribute__((address_space(1))) float gfloat;       // device-memory float (global_ instead of flat_ instructions)
+typedef __attribute__((ext_vector_type(4))) float vf4_t;
+typedef __attribute__((address_space(1))) vf4_t gvf4_t;
 __device__ __forceinline__ void gsink(float* dst, float v, bool slab) {
     if (slab) *dst = v; else atomicAdd(dst, v);
+}
+__device__ __forceinline__ void gsink(gfloat* dst, float v, bool slab) {
+    if (slab) *dst = v; else __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gsink4(gfloat* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
+    if (slab) {
+        *(gvf4_t*)dst = v;
+        return;
+    }
+    gsink(dst + 0, v.x, slab);
+    gsink(dst + 1, v.y, slab);
+    gsink(dst + 2, v.z, slab);
+    gsink(dst + 3, v.w, slab);
 }
 __device__ __forceinline__ void gsink4(float* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
     if (slab) {   // every destination of a 4-group is 16-byte aligned (kernel-layout rows are multiples of 4 floats)
@@ -97,6 +113,9 @@ struct TrainArgs {
     int tile;                       // host only: particles per tile (kernel family)
     int iter_idx;                   // iteration index inside the chunk (state->step advances once per chunk)
     int g_tiles;                    // 1: LDS holds the two dL/dx tiles (L > 1 or gx requested)
+    int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
+    int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
+    int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
 };
 
 template <int K, int H, typename WP>
@@ -168,11 +187,12 @@ constexpr int XS = 66;            // LDS row stride (floats) of every [feature][
 // iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
 // bookkeeping kernel that closes a chunk of iterations consumes and clears them.
 constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
-// staging rows per wave: the gth tiles may read up to row 16*NT-1, the [h|1] operands rows PoP..PoP+H-1 / 2H..3H-1
+// staging rows per wave.  nsf_train_kernel: phase A stages one 16-row tile of gth at a time next to h2 (16 + H rows),
+// phase B ga2 | ga1 | h1 (3H rows); the atomics sink transposes (H+1) x PoP floats through the same rows.
 template <int K, int H>
 struct StgRows {
     static constexpr int PoP = Layout<K, H>::PoP;
-    static constexpr int a = 16 * ((PoP + 15) / 16), b = PoP + H, c = 3 * H;   // bias rows come from the shared `ones` row
+    static constexpr int a = 16 + H, b = 3 * H, c = ((H + 1) * PoP + 65) / 66;   // bias rows come from the shared `ones` row
     static constexpr int value = (a > b ? (a > c ? a : c) : (b > c ? b : c));
     static constexpr int split = PoP + 16 + 3 * H;      // nsf_train2_kernel: gth | h2 | pad to +16 | ga2 | ga1 | h1
 };
@@ -191,8 +211,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int K, int H, bool MF, bool WL>
-__global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
+// OCC = waves per SIMD the register allocation aims at (amdgpu_waves_per_eu): the throughput launches (many cliques
+// per launch, 4-wave blocks, scalar-path weights) want 4 resident waves per SIMD to cover the scalar-load and LDS
+// round trips of a wave's dependent instruction stream; the latency launches (one clique) run one or two waves per
+// SIMD and keep every intermediate in registers.
+template <int K, int H, bool MF, bool WL, int OCC>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, 8))) nsf_train_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
     using WP = typename std::conditional<WL, const float*, cfloat*>::type;
     constexpr int PoP = LY::PoP;
@@ -212,11 +236,12 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int L = a.L;
     const float B = a.B;
     const bool slab = a.slab != 0;
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;      // 64-particle tiles this block sums over (L == 1 only)
     const size_t gstride = (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
     float* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
     if (slab) G += (size_t)blockIdx.x * gstride;
 
-    const int p0 = blockIdx.x * TILE;
+    const int p0 = blockIdx.x * TILE * T;
     if (p0 >= n) return;
     // state words as per-lane loads issued now and consumed only after the prologue's global loads have
     // been issued too: one exposed memory round trip instead of two
@@ -233,8 +258,6 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int dim_lo = blockIdx.z * W;
     const int dim_step = (gridDim.z > 1) ? D : W;       // one pass over [dim_lo + w] when grouped
     if (dim_lo >= D) return;
-    const int gp = p0 + lane;
-    const bool valid = gp < n;
     const int DT = D * XS;
     STAMP_DECL
     STAMP(0);
@@ -245,20 +268,21 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
     const int w_lo = (gridDim.z > 1 && dim_lo > 0) ? LY::off(dim_lo) : 0;
     const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
     float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only), 16-byte aligned rows
-    float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS] layer inputs, dimension-major
+    float* xs = smem + (WL ? a.wl_floats : 0);   // [L or T][D][XS] layer inputs / particle tiles, dimension-major
     const int gt = a.g_tiles ? DT : 0;   // dL/dx tiles exist only when a layer input gradient is needed
-    float* g0 = xs + L * DT;          // [D][XS]
+    float* g0 = xs + (L > T ? L : T) * DT;   // [D][XS]
     float* g1 = g0 + gt;              // [D][XS]
     float* ones = g1 + gt;            // [XS] constant 1 (bias column of the gradient GEMMs)
-    float* stg = ones + XS + w * (StgRows<K, H>::value * XS);   // wave-private staging tile (MF only)
+    float* stg = ones + XS + w * (STG_ROWS * XS);   // wave-private staging tile (MF only)
 
-    // ---- prologue: ALL global loads first (particle tile + parameter rows), one wait, then LDS ----
-    // The tile is 64*D contiguous floats; element e belongs to particle e / D, column e % D (the
+    // ---- prologue: ALL global loads first (particle tiles + parameter rows), one wait, then LDS ----
+    // The T tiles are 64*T*D contiguous floats; element e belongs to particle e / D, column e % D (the
     // quotient by a reciprocal multiply: exact for e < 2^20).  Rows beyond n read as 0.
     {
         constexpr int XB = 16, WB = 4;               // loads in flight per lane: dwords of x, float4 of weights
-        const int nx = D * TILE;
-        const int lim = ((n - p0) < TILE ? (n - p0) : TILE) * D;      // floats of this tile that exist
+        const int nx = D * TILE * T;
+        const int rows = (n - p0) < TILE * T ? (n - p0) : TILE * T;
+        const int lim = rows * D;                                     // floats of these tiles that exist
         const float* xt = x + (size_t)p0 * D;
         const float invD = 1.0f / (float)D;
         const int tot4 = WL ? ((w_hi - w_lo) >> 2) : 0;               // block offsets are multiples of 4 floats
@@ -289,7 +313,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                     int k = e - pq * D;
                     if (k < 0) { k += D; pq -= 1; }
                     if (k >= D) { k -= D; pq += 1; }
-                    xs[k * XS + pq] = xv[u];
+                    xs[(pq >> 6) * DT + k * XS + (pq & 63)] = xv[u];
                 }
             }
             if constexpr (WL) {
@@ -338,227 +362,252 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         const bool need_gx = (l > 0) || (a.gx != nullptr);
         WP lp = kp + (size_t)l * Pk;
         float* Gl = G + (size_t)l * Pk;
-        const float* xin = xs + l * DT;
         if (need_gx) {
             for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
             __syncthreads();
         }
         for (int i = dim_lo + w; i < D; i += dim_step) {
-            float h1[H], h2[H], th[PoP], gth[PoP];
-            STAMP(2);
-            load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
-            STAMP(3);
-            Spline<K> S;
-            float z, lad;
-            spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
-            STAMP(4);
-            float gz, gl;
-            if (a.nll_mode) {
-                gl = -1.0f;
-                gz = last ? z : gcur[i * XS + lane];
-                if (valid) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
-            } else {
-                gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
-                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS + lane];
-            }
-            if (!valid) { gz = 0.0f; gl = 0.0f; }
-            const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
-            if (need_gx) atomicAdd(&gprev[i * XS + lane], gxs);
-            STAMP(5);
-
-            if (i == 0) {   // init_param: plain sum over particles of gth
-                constexpr int N0 = (PoP <= 32) ? 32 : 64;
-                float v[N0];
+            // gradient accumulators of this dim: they persist over the block's T tiles (the MFMAs add into them), so a
+            // block emits ONE gradient copy however many tiles it covers
+            f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
-                const float r = butterfly<N0>(v, lane);
-                if (lane < PoP) gsink(&Gl[lane], r, slab);
-                continue;
-            }
+            for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float r0 = 0.0f;                           // i == 0: init_param gradient of lane < PoP
             WP blk = lp + LY::off(i);
             float* Gb = Gl + LY::off(i);
-            // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights)
-            float gh2[H], ga2[H], ga1[H];
-            {
-                WP W2 = blk + LY::oW2(i);
-#pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    float wr[PoP];
-                    load_row<PoP>(W2 + k * PoP, wr);
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
-                    gh2[k] = acc;
+            for (int tt = 0; tt < T; ++tt) {
+                if (p0 + tt * TILE >= n) break;
+                const float* xin = xs + (T > 1 ? tt : l) * DT;
+                const int gp = p0 + tt * TILE + lane;
+                const bool valid = gp < n;
+                float h1[H], h2[H], th[PoP], gth[PoP];
+                STAMP(2);
+                load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
+                STAMP(3);
+                Spline<K> S;
+                float z, lad;
+                spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
+                STAMP(4);
+                float gz, gl;
+                if (a.nll_mode) {
+                    gl = -1.0f;
+                    gz = last ? z : gcur[i * XS + lane];
+                    if (valid) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+                } else {
+                    gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                    gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS + lane];
                 }
+                if (!valid) { gz = 0.0f; gl = 0.0f; }
+                const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
+                if (need_gx) atomicAdd(&gprev[i * XS + lane], gxs);
+                STAMP(5);
+
+                if (i == 0) {   // init_param: plain sum over particles of gth
+                    constexpr int N0 = (PoP <= 32) ? 32 : 64;
+                    float v[N0];
 #pragma unroll
-                for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
-                WP W1 = blk + LY::oW1(i);
-#pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    float wr[H];
-                    load_row<H>(W1 + k * H, wr);
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
-                    ga1[k] = acc * (1.0f - h1[k] * h1[k]);
+                    for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+                    r0 += butterfly<N0>(v, lane);
+                    continue;
                 }
-                if (need_gx) {
-                    WP W0 = blk;
-                    for (int k = 0; k < i; k += 4) {       // 4 rows in flight (rows >= i alias later weights: unused)
-                        float wq[4][H], acc[4];
+                // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights)
+                float gh2[H], ga2[H], ga1[H];
+                {
+                    WP W2 = reload_ptr(blk + LY::oW2(i));
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) load_row<H>(W0 + (k + u) * H, wq[u]);
+                    for (int k = 0; k < H; ++k) {
+                        float wr[PoP];
+                        load_row<PoP>(W2 + k * PoP, wr);
+                        float acc = 0.0f;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc[u] = 0.0f;
+                        for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
+                        gh2[k] = acc;
+                        if (k & 1) row_group_fence<WP>();
+                    }
 #pragma unroll
-                            for (int j = 0; j < H; ++j) acc[u] = __builtin_fmaf(wq[u][j], ga1[j], acc[u]);
+                    for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
+                    WP W1 = reload_ptr(blk + LY::oW1(i));
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        float wr[H];
+                        load_row<H>(W1 + k * H, wr);
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
+                        ga1[k] = acc * (1.0f - h1[k] * h1[k]);
+                        if ((k & 7) == 7) row_group_fence<WP>();
+                    }
+                    if (need_gx) {
+                        WP W0 = blk;
+                        for (int k = 0; k < i; k += 4) {       // 4 rows in flight (rows >= i alias later weights: unused)
+                            float wq[4][H], acc[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) load_row<H>(W0 + (k + u) * H, wq[u]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc[u] = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < H; ++j) acc[u] = __builtin_fmaf(wq[u][j], ga1[j], acc[u]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (k + u < i) atomicAdd(&gprev[(k + u) * XS + lane], acc[u]);
                         }
+                    }
+                }
+                STAMP(6);
+                if constexpr (MF) {
+                    // ======== phase A: dW2t | db2 = [h2, 1]^T (x) gth, one 16-row tile of gth per staging round ========
+                    // (staging rows 0..15: the gth tile, rows 16..16+H-1: h2 -- 24 rows instead of PoP + H = 40: the
+                    //  staging tile is what limits the resident waves per CU)
+                    {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (k + u < i) atomicAdd(&gprev[(k + u) * XS + lane], acc[u]);
+                        for (int k = 0; k < H; ++k) stg[(16 + k) * XS + lane] = h2[k];
+                        const float* pa = stg + r16 * XS + kq;             // A: gth rows 16t + r16 (>= Po: unused outputs)
+                        // B: [h2 | 1]; the bias column and the unused columns beyond it read the constant-one row
+                        const float* pb = ((r16 < H) ? (stg + (16 + r16) * XS) : ones) + kq;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                            for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
+                            wave_lds_sync();
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) cacc[t] = mfma4(pa[s4], pb[s4], cacc[t]);
+                            wave_lds_sync();
+                        }
+                    }
+                    STAMP(7);
+                    // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========
+                    {
+#pragma unroll
+                        for (int j = 0; j < H; ++j) {
+                            stg[j * XS + lane] = ga2[j];
+                            stg[(H + j) * XS + lane] = ga1[j];
+                            stg[(2 * H + j) * XS + lane] = h1[j];
+                        }
+                        wave_lds_sync();
+                        const float* pa = stg + r16 * XS + kq;                   // A: rows 0..7 ga2, 8..15 ga1
+                        const float* pb1 = ((r16 < H) ? (stg + (2 * H + r16) * XS) : ones) + kq;   // B1: [h1 | 1]
+                        float areg[TILE / 4];
+#pragma unroll
+                        for (int s4 = 0; s4 < TILE; s4 += 4) {
+                            areg[s4 / 4] = pa[s4];
+                            c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
+                        }
+                        // x tiles (16 input columns each); column i is the bias (ones row).  Tile 0 (columns 0..15) keeps
+                        // its accumulator over the block's tiles; further column tiles (D > 16) add into the block's
+                        // own gradient copy: the same lane owns the same entries for every tile, so a plain
+                        // read-add-write is race-free (slab) / a float atomic (shared copy).
+                        {
+                            const float* pb0 = ((r16 < i) ? (xin + r16 * XS) : ones) + kq;
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
+                        }
+                        for (int ct = 1; ct * 16 <= i; ++ct) {
+                            const int cab = ct * 16 + r16;
+                            const float* pb0 = ((cab < i) ? (xin + cab * XS) : ones) + kq;
+                            f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) cx = mfma4(areg[s4 / 4], pb0[s4], cx);
+                            if (kq >= 2 && cab <= i) {
+                                float* dst = &Gb[cab * H + 4 * (kq - 2)];
+                                if (slab && tt > 0) cx += *(const f32x4*)dst;
+                                gsink4(dst, cx, slab);
+                            }
+                        }
+                        wave_lds_sync();
+                    }
+                    STAMP(8);
+                } else {
+                    // ======== butterfly variant (round-1 v1): reduce-scatter over lanes with ds_bpermute (T == 1) ========
+                    {
+                        constexpr int TOT = (H + 1) * PoP;
+                        float* Gw = Gb + LY::oW2(i);
+#pragma unroll
+                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                            float v[64];
+#pragma unroll
+                            for (int t = 0; t < 64; ++t) {
+                                const int f = c * 64 + t;
+                                const int k = f / PoP, o = f % PoP;
+                                v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
+                        }
+                    }
+                    {
+                        constexpr int TOT = (H + 1) * H;
+                        float* Gw = Gb + LY::oW1(i);
+#pragma unroll
+                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                            float v[64];
+#pragma unroll
+                            for (int t = 0; t < 64; ++t) {
+                                const int f = c * 64 + t;
+                                const int k = f / H, j = f % H;
+                                v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
+                        }
+                    }
+                    {
+                        float* Gw = Gb;
+                        constexpr int RPC = 64 / H;
+                        const int tot = (i + 1) * H;
+                        for (int kc = 0; kc <= i; kc += RPC) {
+                            float v[64];
+#pragma unroll
+                            for (int r_ = 0; r_ < RPC; ++r_) {
+                                const int k = kc + r_;
+                                const float xk = (k < i) ? xin[k * XS + lane] : ((k == i) ? 1.0f : 0.0f);
+#pragma unroll
+                                for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (kc * H + lane < tot) gsink(&Gw[kc * H + lane], r, slab);
+                        }
                     }
                 }
             }
-            STAMP(6);
+            // ---- this dim's gradient copy: every entry written once (slab) or added once (atomics) per block ----
+            if (i == 0) {
+                if (lane < PoP) gsink(&Gl[lane], r0, slab);
+                continue;
+            }
             if constexpr (MF) {
-                // ======== phase A: dW2t | db2 = [h2, 1]^T (x) gth   -> flat f = c*PoP + o =========
-                {
+                // C layout of the MFMAs: col = lane&15 (= input column c), rows 4*(lane>>4)+r (= four consecutive outputs)
+                float* Gw = Gb + LY::oW2(i);
+                if (slab) {
+                    if (r16 <= H) {
 #pragma unroll
-                    for (int o = 0; o < PoP; ++o) stg[o * XS + lane] = gth[o];
-#pragma unroll
-                    for (int k = 0; k < H; ++k) stg[(PoP + k) * XS + lane] = h2[k];
-                    wave_lds_sync();
-                    const float* pa = stg + r16 * XS + kq;             // A tiles: gth rows 16t + r16 (>= Po: unused outputs)
-                    // B: [h2 | 1]; the bias column and the unused columns beyond it read the constant-one row
-                    const float* pb = ((r16 < H) ? (stg + (PoP + r16) * XS) : ones) + kq;
-                    f32x4 cacc[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s4 = 0; s4 < TILE; s4 += 4) {
-                        const float b = pb[s4];
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) cacc[t] = mfma4(pa[t * 16 * XS + s4], b, cacc[t]);
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
                     }
-                    // C layout: col = lane&15 (= c), rows 4*(lane>>4)+r (= o within the tile)
-                    float* Gw = Gb + LY::oW2(i);
-                    wave_lds_sync();
-                    if (slab) {
-                        // per-tile slab: every entry written once, four consecutive outputs per lane = one 16-byte store
-                        if (r16 <= H) {
+                } else {
+                    // atomics: transpose through LDS to the flat order (64 consecutive addresses per wave instruction)
+                    if (r16 <= H) {
 #pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
-                        }
-                    } else {
-                        // atomics: transpose through LDS to the flat order (64 consecutive addresses per wave instruction)
-                        if (r16 <= H) {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
-                                    float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
-                                    d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
-                                }
-                        }
-                        wave_lds_sync();
-                        constexpr int TOT = (H + 1) * PoP;
-#pragma unroll
-                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                            const int f = c * 64 + lane;
-                            if (f < TOT) atomicAdd(&Gw[f], stg[f]);
-                        }
-                        wave_lds_sync();
-                    }
-                }
-                STAMP(7);
-                // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========
-                {
-#pragma unroll
-                    for (int j = 0; j < H; ++j) {
-                        stg[j * XS + lane] = ga2[j];
-                        stg[(H + j) * XS + lane] = ga1[j];
-                        stg[(2 * H + j) * XS + lane] = h1[j];
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
+                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                            }
                     }
                     wave_lds_sync();
-                    const float* pa = stg + r16 * XS + kq;                   // A: rows 0..7 ga2, 8..15 ga1
-                    const float* pb1 = ((r16 < H) ? (stg + (2 * H + r16) * XS) : ones) + kq;   // B1: [h1 | 1]
-                    f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
-                    float areg[TILE / 4];
-#pragma unroll
-                    for (int s4 = 0; s4 < TILE; s4 += 4) {
-                        areg[s4 / 4] = pa[s4];
-                        c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
-                    }
-                    // x tiles (16 input columns each); column i is the bias (ones row)
-                    float* Gw0 = Gb;
-                    const int tot0 = (i + 1) * H;
-                    for (int ct = 0; ct * 16 <= i; ++ct) {
-                        const int cab = ct * 16 + r16;
-                        const float* pb0 = ((cab < i) ? (xin + cab * XS) : ones) + kq;
-                        f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int s4 = 0; s4 < TILE; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
-                        // rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = cab*H + j
-                        if (kq >= 2 && cab <= i) gsink4(&Gw0[cab * H + 4 * (kq - 2)], c0, slab);
-                    }
-                    (void)tot0;
-                    // rows 0..7 (kq < 2) are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
-                    if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
-                    wave_lds_sync();
-                }
-                STAMP(8);
-            } else {
-                // ======== butterfly variant (round-1 v1): reduce-scatter over lanes with ds_bpermute ========
-                {
                     constexpr int TOT = (H + 1) * PoP;
-                    float* Gw = Gb + LY::oW2(i);
 #pragma unroll
                     for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                        float v[64];
-#pragma unroll
-                        for (int t = 0; t < 64; ++t) {
-                            const int f = c * 64 + t;
-                            const int k = f / PoP, o = f % PoP;
-                            v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
-                        }
-                        const float r = butterfly<64>(v, lane);
-                        if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
+                        const int f = c * 64 + lane;
+                        if (f < TOT) atomicAdd(&Gw[f], stg[f]);
                     }
+                    wave_lds_sync();
                 }
-                {
-                    constexpr int TOT = (H + 1) * H;
-                    float* Gw = Gb + LY::oW1(i);
-#pragma unroll
-                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                        float v[64];
-#pragma unroll
-                        for (int t = 0; t < 64; ++t) {
-                            const int f = c * 64 + t;
-                            const int k = f / H, j = f % H;
-                            v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
-                        }
-                        const float r = butterfly<64>(v, lane);
-                        if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
-                    }
-                }
-                {
-                    float* Gw = Gb;
-                    constexpr int RPC = 64 / H;
-                    const int tot = (i + 1) * H;
-                    for (int kc = 0; kc <= i; kc += RPC) {
-                        float v[64];
-#pragma unroll
-                        for (int r_ = 0; r_ < RPC; ++r_) {
-                            const int k = kc + r_;
-                            const float xk = (k < i) ? xin[k * XS + lane] : ((k == i) ? 1.0f : 0.0f);
-#pragma unroll
-                            for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
-                        }
-                        const float r = butterfly<64>(v, lane);
-                        if (kc * H + lane < tot) gsink(&Gw[kc * H + lane], r, slab);
-                    }
-                }
+                // c1 rows 0..7 (kq < 2) are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
+                if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+                // c0 rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = c*H + j, input column c = r16
+                if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
             }
         }
         STAMP(12);
@@ -567,7 +616,7 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
         float* tmp = gcur; gcur = gprev; gprev = tmp;
     }
 
-    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input (T == 1)
         for (int e = threadIdx.x; e < D * TILE; e += blockDim.x) {
             const int p = e / D, k = e - p * D;
             const int q = p0 + p;
@@ -583,6 +632,259 @@ __global__ void __launch_bounds__(512) nsf_train_kernel(TrainArgs a) {
                                          : a.loss_sum;
             if (dst != nullptr) atomicAdd(dst, tot);
         }
+    }
+}
+
+// =============================================================================================
+// throughput training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, blocks are dim-major.
+//
+// Why: in nsf_train_kernel the four waves of a block run four different dims and every wave walks through all of
+// its dims, so a CU's resident waves read 12-16 different weight sets through the 16 KB scalar data cache: 58 % of
+// the scalar loads miss (rocprofv3 SQC_DCACHE_HITS / _MISSES, 64-clique batch) and every miss is an exposed
+// ~500-cycle round trip in front of an `s_waitcnt lgkmcnt(0)`.  Here grid = (tile groups, cliques, dims): the W
+// waves of a block run the SAME (clique, dim) on different particle tiles, each wave sweeps T tiles with that one
+// weight set and keeps the weight-gradient MFMA accumulators across them, so a CU holds 3-4 weight sets (< 8 KB),
+// emits one gradient copy per T tiles, and needs no workgroup barrier at all (every LDS byte is wave-private).
+// LDS per wave: the particle tile [D][XS] + a 16-row staging tile (the [h|1] operands of the gradient GEMMs are
+// parked in registers while the staging rows are re-used for the other operand): 8.4 KB at D = 15, so the
+// register allocation (OCC) decides the occupancy, not LDS.
+// =============================================================================================
+template <int K, int H, int OCC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) nsf_train1_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;
+    constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
+    static_assert(H == 8, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
+    // atomics, which count against both memory counters)
+    const nfisam_clique* cp = a.cliques != nullptr ? (a.cliques + blockIdx.y) : nullptr;
+    const gfloat* x = (const gfloat*)(cp ? cp->x : a.single.x);
+    const float* kparams = cp ? cp->kparams : a.single.kparams;
+    gfloat* G = (gfloat*)(cp ? cp->kgrad : a.single.kgrad);
+    nfisam_train_state* st = cp ? cp->state : a.single.state;
+    const int n = cp ? cp->n : a.single.n;
+    const int D = cp ? cp->D : a.single.D;
+    const int i = blockIdx.z;                                 // this block's dim
+    if (i >= D) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+    const int slot = blockIdx.x * W + w;                      // this wave's gradient copy
+    const int p0 = slot * TILE * T;
+    if (p0 >= n) return;
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const size_t gstride = (size_t)LY::count(D);
+    gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
+    if (slab) G += (size_t)slot * gstride;
+    const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
+    float* xt = smem + (size_t)w * ((xrows + 16) * XS);       // [xrows][XS] particle tile, dimension-major
+    float* stg = xt + xrows * XS;                             // [16][XS] staging rows
+    const int r16 = lane & 15, kq = lane >> 4;
+    cfloat* lp = (cfloat*)kparams;
+    cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
+    gfloat* Gb = G + LY::off(i > 0 ? i : 1);
+
+    f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float r0 = 0.0f, lossv = 0.0f;
+
+    // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
+    // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
+    // arithmetic, no column the dim does not need.  Rows beyond n re-read row n-1 (masked out of loss and gradient).
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto load_tile = [&](int pt) {
+        const int pr = (pt + lane < n) ? pt + lane : n - 1;
+        const gfloat* row = x + (size_t)pr * D;
+        for (int c0 = 0; c0 <= i; c0 += 16) {
+            float xr[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = c0 + 4 * q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k <= i) {                                 // wave-uniform
+                    if (k + 3 < D) {
+                        const f32x4u u = *(const __attribute__((address_space(1))) f32x4u*)(row + k);
+                        v = f32x4{u.x, u.y, u.z, u.w};
+                    } else {
+                        v.x = row[k];
+                        if (k + 1 < D) v.y = row[k + 1];
+                        if (k + 2 < D) v.z = row[k + 2];
+                    }
+                }
+                xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+            }
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // wave-uniform; first consumer of the state loads
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+        }
+        return true;
+    };
+
+    for (int tt = 0; tt < T; ++tt) {
+        const int pt = p0 + tt * TILE;
+        if (pt >= n) break;
+        if (!load_tile(pt)) return;
+        wave_lds_sync();
+        const bool valid = pt + lane < n;
+        float h1[H], h2[H], th[PoP], gth[PoP];
+        load_theta<K, H, cfloat*>(lp, i, xt, XS, lane, h1, h2, th);
+        Spline<K> S;
+        float z, lad;
+        spline_eval<K, PoP, false>(xt[i * XS + lane], th, B, S, z, lad);
+        if (valid) lossv += 0.5f * z * z - lad;
+        const float gxs = spline_backward<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
+        (void)gxs;
+        if (i == 0) {   // init_param: plain sum over particles of gth
+            constexpr int N0 = (PoP <= 32) ? 32 : 64;
+            float v[N0];
+#pragma unroll
+            for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+            r0 += butterfly<N0>(v, lane);
+            wave_lds_sync();                                    // the tile is overwritten by the next iteration's loads
+            continue;
+        }
+        // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights) ----
+        float ga2[H], ga1[H];
+        {
+            float gh2[H];
+            cfloat* W2 = reload_ptr(blk + LY::oW2(i));
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                float wr[PoP];
+                load_row<PoP>(W2 + k * PoP, wr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
+                gh2[k] = acc;
+                if (k & 1) row_group_fence<cfloat*>();
+            }
+#pragma unroll
+            for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
+            cfloat* W1 = reload_ptr(blk + LY::oW1(i));
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                float wr[H];
+                load_row<H>(W1 + k * H, wr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
+                ga1[k] = acc * (1.0f - h1[k] * h1[k]);
+                if ((k & 7) == 7) row_group_fence<cfloat*>();
+            }
+        }
+        // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
+        //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
+        const float* pa = stg + r16 * XS + kq;
+        const float* pah = stg + (r16 < H ? r16 : 0) * XS + kq;     // [h | 1] operand: every lane loads, lanes >= H take 1
+        float breg[NS];
+        {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth
+#pragma unroll
+            for (int k = 0; k < H; ++k) stg[k * XS + lane] = h2[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) cacc[t] = mfma4(pa[4 * s4], breg[s4], cacc[t]);
+                wave_lds_sync();
+            }
+        }
+        {   // phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
+#pragma unroll
+            for (int j = 0; j < H; ++j) stg[j * XS + lane] = h1[j];
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                stg[j * XS + lane] = ga2[j];
+                stg[(H + j) * XS + lane] = ga1[j];
+            }
+            wave_lds_sync();
+            float areg[NS];
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) {
+                areg[s4] = pa[4 * s4];
+                c1 = mfma4(areg[s4], breg[s4], c1);
+            }
+            {   // input columns 0..15 (column i = bias)
+                const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; c0 = mfma4(areg[s4], (r16 < i) ? v : 1.0f, c0); }
+            }
+            for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
+                const int cab = ct * 16 + r16;
+                const float* pb0 = xt + (cab < i ? cab : 0) * XS + kq;
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; cx = mfma4(areg[s4], (cab < i) ? v : 1.0f, cx); }
+                if (kq >= 2 && cab <= i) {
+                    gfloat* dst = &Gb[cab * H + 4 * (kq - 2)];
+                    if (slab && tt > 0) cx += *(const gvf4_t*)dst;
+                    gsink4(dst, cx, slab);
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+
+    // ---- the wave's gradient copy of this dim ----
+    if (i == 0) {
+        if (lane < PoP) gsink(&G[lane], r0, slab);
+    } else {
+        gfloat* Gw = Gb + LY::oW2(i);
+        if (slab) {
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+            }
+        } else {
+            // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
+            constexpr int TOT = (H + 1) * PoP;
+            static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) {
+                        float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                        d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                    }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                const int f = c * 64 + lane;
+                if (f < TOT) gsink(&Gw[f], stg[f], false);
+            }
+        }
+        if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+        if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
+    }
+    const float tot = wave_sum(lossv);
+    if (lane == 0) {
+        gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
+                                      : (gfloat*)a.loss_sum;
+        if (dst != nullptr) gsink(dst, tot, false);
     }
 }
 
@@ -965,6 +1267,7 @@ struct AdamArgs {
     int iter_idx;           // iteration index inside the chunk
     int chunk;              // bookkeeping kernel: iterations to close
     int max_n;              // largest n of the batch (number of slabs in every workspace)
+    int few_copies;         // every clique has <= 8 gradient copies: one thread per parameter
 };
 
 __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
@@ -988,7 +1291,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const int pj0 = threadIdx.x & 31, tl0 = threadIdx.x >> 5, jf = blockIdx.x * 32 + pj0;
     const int n_tiles0 = a.slab ? (n + a.slab - 1) / a.slab : 1;
     float pre_g = 0.0f, pre_m = 0.0f, pre_v = 0.0f, pre_t = 0.0f;
-    if (jf < P) {
+    if (jf < P && !a.few_copies) {
 #pragma unroll 8
         for (int tt = tl0; tt < n_tiles0; tt += 8) pre_g += G[(size_t)tt * P + jf];
         if (tl0 == 0) { pre_m = m[jf]; pre_v = v[jf]; pre_t = theta[jf]; }
@@ -1007,6 +1310,26 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const float step_size = a.cfg.lr / bc1;
     const float inv_bc2s = 1.0f / sqrtf(bc2);
     const float inv_n = 1.0f / (float)n;
+    if (a.slab && n_tiles0 <= 8 && a.few_copies) {
+        // few gradient copies (throughput launches: one copy per T tiles): one thread per parameter, the copies summed
+        // in copy order (bitwise-reproducible), every load independent of the others
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
+            float gv[8];
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) gv[tt] = (tt < n_tiles0) ? G[(size_t)tt * P + j] : 0.0f;
+            const float mo = m[j], vo = v[j], to = theta[j];
+            float gs = gv[0];
+#pragma unroll
+            for (int tt = 1; tt < 8; ++tt) gs += gv[tt];
+            const float g = gs * inv_n;
+            const float mj = b1 * mo + (1.0f - b1) * g;
+            const float vj = b2 * vo + (1.0f - b2) * g * g;
+            m[j] = mj;
+            v[j] = vj;
+            theta[j] = to - step_size * mj / (sqrtf(vj) * inv_bc2s + a.cfg.eps);
+        }
+        return;
+    }
     // 256 threads = 32 parameters x 8 tile-lanes: with per-tile gradient slabs every tile-lane sums the
     // tiles tt = tl, tl+8, ... of its parameter (independent loads, issued together), the 8 partial sums
     // are combined through LDS in a fixed order (bitwise-reproducible), lane 0 applies Adam.
@@ -1864,12 +2187,13 @@ static int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: automati
     return v;
 }
 
-template <int KK, int HH, bool MF, bool WL>
+template <int KK, int HH, bool MF, bool WL, int OCC>
 static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, int W, int groups, size_t lds,
                                 hipStream_t s) {
-    int rc = set_lds(nsf_train_kernel<KK, HH, MF, WL>, lds);
+    int rc = set_lds(nsf_train_kernel<KK, HH, MF, WL, OCC>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL>), dim3((max_n + TILE - 1) / TILE, n_cliques, groups),
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL, OCC>), dim3((max_n + TILE * T - 1) / (TILE * T), n_cliques, groups),
                        dim3(64 * W), lds, s, a);
     return NFISAM_OK;
 }
@@ -1886,6 +2210,40 @@ static int train_tile(int n_cliques, int max_n, int max_D) {
     }
     const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
     return waves <= 1280 ? TILE2 : TILE;
+}
+
+// Throughput launches (wide family, L == 1) go to nsf_train1_kernel (dim-major blocks) unless NFISAM_DIM_MAJOR=0
+// (A/B against nsf_train_kernel's tile-major blocks).
+static bool dim_major_enabled() {
+    const char* e = getenv("NFISAM_DIM_MAJOR");
+    return !(e != nullptr && e[0] == '0');
+}
+static bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int tile) {
+    const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+    return tile == TILE && L == 1 && use_mfma_grad() && dim_major_enabled() && tiles * max_D > 1024;
+}
+
+// 64-particle tiles summed into one gradient copy (one wave's sweep in nsf_train1_kernel, one block's in
+// nsf_train_kernel).  More tiles per copy = fewer copies for the Adam kernel to read back, fewer prologues and
+// better scalar-cache reuse of the weights, as long as the launch still has ~1.5x the waves the chip holds at four
+// waves per SIMD (4096).  The decision depends on the launch shape only, so the gradient, Adam and bookkeeping
+// launches of an iteration agree on the number of gradient copies.
+static int tiles_per_block(int n_cliques, int max_n, int max_D, int L, int tile) {
+    if (tile != TILE || L != 1 || !use_mfma_grad()) return 1;
+    const long tiles_c = (max_n + TILE - 1) / TILE, tiles = tiles_c * n_cliques;
+    if (tiles * max_D <= 1024) return 1;
+    const char* e = getenv("NFISAM_TILES_PER_BLOCK");
+    int T = 1;
+    if (is_dim_major(n_cliques, max_n, max_D, L, tile)) {
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
+        while (T < 8 && (long)n_cliques * ((tiles_c + 2 * T - 1) / (2 * T)) * max_D >= 6144) T *= 2;
+        return T;
+    }
+    if (tiles <= 256) return 1;                  // nsf_train_kernel spreads the dims over grid.z there: one tile per block
+    if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
+    const int W = max_D < 4 ? max_D : 4;
+    while (T < 4 && tiles * W / (2 * T) >= 4096) T *= 2;
+    return T;
 }
 
 template <int KK, int HH, bool WL>
@@ -1942,22 +2300,53 @@ static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max
     // (latency-bound) every (tile, dim) unit becomes its own single-wave block, so that every wave has
     // a SIMD to itself; with thousands of waves in flight tiles keep their dims together instead.
     const bool independent_dims = (a.L == 1 && a.gx == nullptr);
-    int W = pick_waves(max_D), groups = 1;
+    if (independent_dims && a.nll_mode && a.gz == nullptr && H == 8 && is_dim_major(n_cliques, max_n, max_D, a.L, TILE)) {
+        // throughput regime: one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
+        int W = 4;
+        const char* e = getenv("NFISAM_BIG_W");
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) W = atoi(e);
+        const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+        a.tiles_per_block = T;
+        a.xrows = max_D;
+        a.n_copies = (max_n + TILE * T - 1) / (TILE * T);
+        const int gx = (a.n_copies + W - 1) / W;
+        const size_t lds = (size_t)W * (size_t)(max_D + 16) * XS * sizeof(float);
+        int occ = 3;           // 149 VGPRs, no scratch; the 128-register build (4 waves per SIMD) spills 40 VGPRs and measures 5 % slower
+        const char* oe = getenv("NFISAM_OCC");
+        if (oe != nullptr) occ = atoi(oe);
+        NSF_DISPATCH(K, H, {
+            int rc;
+            if (occ >= 4) {
+                rc = set_lds(nsf_train1_kernel<KK, 8, 4>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 4>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+            } else {
+                rc = set_lds(nsf_train1_kernel<KK, 8, 3>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 3>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+            }
+        });
+        HIP_TRY(hipGetLastError());
+        return NFISAM_OK;
+    }
+    int W = pick_waves(max_D), groups = 1, T = 1;
     if (independent_dims && tiles * max_D <= 1024) { W = 1; groups = max_D; }
     else if (independent_dims) {
-        // Beyond one wave per SIMD the resident waves per CU are limited by the 10.6 KB staging tile of every wave,
-        // not by registers (128 VGPRs): 4 waves per block -> 3 blocks = 12 waves per CU instead of one block of 8
-        // (64 cliques n=2000 D=15: 226 -> 169 us per iteration).  Up to 256 tiles every wave still gets a single
+        // 4 waves per block: a wave's staging tile is 6.3 KB (24 rows), so 16 waves fit a CU next to the particle tiles
+        // and the register allocation (OCC = 4) decides the occupancy.  Up to 256 tiles every wave still gets a single
         // unit (dims spread over grid.z); larger launches let a wave loop over its dims and amortise the tile load.
         W = 4;
         const char* e = getenv("NFISAM_BIG_W");
         if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) W = atoi(e);
         if (W > max_D) W = max_D;
         if (tiles <= 256) groups = (max_D + W - 1) / W;
+        if (groups == 1 && mf && a.tiles_per_block > 1) T = a.tiles_per_block;
     }
+    a.tiles_per_block = T;
     a.g_tiles = independent_dims ? 0 : 1;
     NSF_DISPATCH(K, H, {
-        const size_t tile_floats = (((size_t)a.L + 2 * a.g_tiles) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
+        const size_t xt = (size_t)(a.L > T ? a.L : T);
+        const size_t tile_floats = ((xt + 2 * a.g_tiles) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
         const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
         // parameter floats one block must hold: all layers, or its own dims' blocks when grouped
         size_t wfloats = (size_t)a.L * stride;
@@ -1971,16 +2360,19 @@ static int launch_train(const TrainArgs& a_in, int n_cliques, int max_n, int max
         // LDS copy of the parameters: pays when few waves share a SIMD (nothing hides a cold scalar-cache
         // miss per weight row); it must fit next to the tiles.  Large batches keep the scalar path.
         const int wm = weights_mode();
-        const long blocks = tiles * groups;
+        const long blocks = ((tiles + T - 1) / T) * groups;
         const bool fits = (tile_floats + wfloats) * sizeof(float) <= 150 * 1024;
-        const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096));
+        const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096 && !(independent_dims && blocks * W > 1024)));
         a.wl_floats = wl ? (int)wfloats : 0;
         const size_t lds = (tile_floats + (wl ? wfloats : 0)) * sizeof(float);
         int rc;
-        if (mf && wl) rc = launch_train_variant<KK, HH, true, true>(a, n_cliques, max_n, W, groups, lds, s);
-        else if (mf) rc = launch_train_variant<KK, HH, true, false>(a, n_cliques, max_n, W, groups, lds, s);
-        else if (wl) rc = launch_train_variant<KK, HH, false, true>(a, n_cliques, max_n, W, groups, lds, s);
-        else rc = launch_train_variant<KK, HH, false, false>(a, n_cliques, max_n, W, groups, lds, s);
+        if (!mf) {
+            if (wl) rc = launch_train_variant<KK, HH, false, true, 1>(a, n_cliques, max_n, W, groups, lds, s);
+            else rc = launch_train_variant<KK, HH, false, false, 1>(a, n_cliques, max_n, W, groups, lds, s);
+        } else {
+            if (wl) rc = launch_train_variant<KK, HH, true, true, 1>(a, n_cliques, max_n, W, groups, lds, s);
+            else rc = launch_train_variant<KK, HH, true, false, 1>(a, n_cliques, max_n, W, groups, lds, s);
+        }
         if (rc) return rc;
     });
     HIP_TRY(hipGetLastError());
@@ -2021,7 +2413,8 @@ static int slab_max_tiles() {
 }
 static bool use_slabs(int max_n, int tile) { return (max_n + tile - 1) / tile <= slab_max_tiles(); }
 
-// Upper bound over both kernel families (the family is picked per launch from the whole batch's size).
+// Upper bound over both kernel families (the launch shape is picked per launch; several tiles per block only
+// lower the number of copies).
 extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L) {
     if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
     const size_t tiles = use_slabs(n, TILE2) ? (size_t)((n + TILE2 - 1) / TILE2)
@@ -2029,12 +2422,23 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS;
 }
 
+// Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
+// shared copy accumulated with float atomics).
+struct TrainShape { int tile, T, slab; };
+static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L) {
+    TrainShape sh;
+    sh.tile = train_tile(n_cliques, max_n, max_D);
+    sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile);
+    sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
+    return sh;
+}
+
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
-    a.tile = train_tile(n_cliques, max_n, max_D);
-    a.slab = use_slabs(max_n, a.tile) ? a.tile : 0;
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L);
+    a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab;
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
@@ -2047,8 +2451,7 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
     ad.cfg = *cfg;
-    const int tile = train_tile(n_cliques, max_n, max_D);
-    ad.slab = use_slabs(max_n, tile) ? tile : 0;
+    ad.slab = train_shape(n_cliques, max_n, max_D, L).slab;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H; ad.max_n = max_n;
@@ -2068,6 +2471,8 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     int ablocks = (int)((Pmax + 31) / 32);
     if (ablocks < 1) ablocks = 1;
     if (ablocks > 256) ablocks = 256;
+    ad.few_copies = (ad.slab != 0 && (max_n + ad.slab - 1) / ad.slab <= 8) ? 1 : 0;
+    if (ad.few_copies) ablocks = (int)((Pmax + 255) / 256);
     hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;

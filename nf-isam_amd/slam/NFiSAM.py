@@ -304,13 +304,28 @@ class NFiSAM(FactorGraphSolver):
     def fit_clique_density_model(self, clique, samples: np.ndarray, var_ordering: List, timer: List, *args,
                                  **kwargs) -> NormalizingFlowModelWithSeparator:
         """Train the clique's flow on `samples` [n, D] (columns = simulated observations, separator
-        variables, frontal variables).  reference: NFiSAM.py:323-513."""
+        variables, frontal variables).  reference: NFiSAM.py:323-513.
+        = `prepare_fit` (normalise, initialise) + `train_prepared` (the device-resident loop) + `finish_fit` (wrap the
+        trained parameters); `slam.ReplicaNFiSAM` calls the three parts itself to train the cliques of several
+        replicas in ONE batched launch sequence."""
+        prep = self.prepare_fit(clique, samples, var_ordering)
+        if prep["testing_data"] is not None:
+            return self._fit_holdout(prep, timer)
+        opt_start = time.time()
+        self.train_prepared([prep])
+        torch.cuda.synchronize()
+        if timer is not None:
+            timer.append(time.time() - opt_start)
+        return self.finish_fit(prep)
+
+    def prepare_fit(self, clique, samples, var_ordering) -> dict:
+        """Everything of `fit_clique_density_model` in front of the training loop (NFiSAM.py:323-449): circular flags,
+        shuffle + split, normalisation (on the device when the batch was simulated there), fresh parameters."""
         a = self._args
         if a.flow_type != "NSF_AR":
             raise NotImplementedError("Unknown flow type for the pipeline")
         device = _device()
         frontal_dim = clique.frontal_dim
-        aug_separator_dim = samples.shape[-1] - frontal_dim
         aug_clique_dim = samples.shape[-1]
         circular_dim_list = []
         for var in var_ordering:
@@ -322,12 +337,12 @@ class NFiSAM(FactorGraphSolver):
         on_device = isinstance(samples, torch.Tensor) and samples.is_cuda
         if on_device and a.training_set_frac < 1.0:
             samples, on_device = samples.cpu().numpy(), False       # the hold-out split is done on the host
+        testing_data = None
         if on_device:
             # batch simulated on the GPU (sampler.DeviceSimulation): normalise it there too (f-3).  With
             # training_set_frac = 1 the reference's shuffle only permutes the rows of a full-batch mean.
             training_data, means, stds = _nh.normalize_columns(samples.to(torch.float32).contiguous(),
                                                                circular_dim_list)
-            testing_data = None
         else:
             # train/test split on a shuffled COPY (the reference shuffles the caller's array in place)
             samples = np.array(samples, dtype=np.float64, copy=True)
@@ -336,7 +351,6 @@ class NFiSAM(FactorGraphSolver):
             train_samples, test_samples = samples[:train_size], samples[train_size:]
             training_data, means, stds = self.normalize_training_samples(train_samples, circular_dim_list,
                                                                          a.flow_type)
-            testing_data = None
             if len(test_samples) > 0:
                 testing_data, _, _ = self.normalize_training_samples(test_samples, circular_dim_list, a.flow_type)
 
@@ -348,55 +362,76 @@ class NFiSAM(FactorGraphSolver):
             raise ValueError("no kernel instantiation for num_knots=%d, hidden_dim=%d" % (K, H))
         kp0 = torch.cat([_nh.pack(init_reference_blob(aug_clique_dim, K, H, device), aug_clique_dim, K, H, 1)
                          for _ in range(L)])
+        return dict(clique=clique, training_data=training_data, testing_data=testing_data, means=means, stds=stds,
+                    circular=circular_dim_list, kp0=kp0, D=aug_clique_dim, sep_dim=aug_clique_dim - frontal_dim,
+                    n=int(training_data.shape[0]), cfg=(K, H, B, L), device=device)
+
+    def train_prepared(self, preps: List[dict]) -> None:
+        """The reference's `for i in range(flow_iterations)` loop (NFiSAM.py:451-491) for one or several prepared
+        cliques at once (grid.y = clique; every clique has its own Adam state, loss record and early-stop decision).
+        Training plans (device buffers + the captured hipGraph of one chunk of iterations) are kept per batch shape
+        and re-used: the batches and the fresh parameters are copied into the plan's buffers, Adam moments / state /
+        loss record are cleared in place.  Fills prep["trained"], ["iters"], ["iter_loss"]."""
+        a = self._args
+        K, H, B, L = preps[0]["cfg"]
+        device = preps[0]["device"]
+        key = (tuple((p["n"], p["D"]) for p in preps), K, H, L, float(a.learning_rate), int(a.flow_iterations),
+               int(a.average_window), float(a.loss_delta_tol), str(device))
+        plans = self.__dict__.setdefault("_train_plans", {})
+        tb = plans.get(key)
+        if tb is None:
+            tb = _nh.TrainBatch([torch.empty(p["n"], p["D"], dtype=torch.float32, device=device) for p in preps],
+                                [torch.zeros_like(p["kp0"]) for p in preps], K, H, B, L, lr=a.learning_rate,
+                                max_iters=a.flow_iterations, average_window=a.average_window,
+                                loss_delta_tol=a.loss_delta_tol, early_stop=True)
+            plans[key] = tb
+        for x, p in zip(tb.xs, preps):
+            x.copy_(p["training_data"])
+        tb.reset(kparams=[p["kp0"] for p in preps])
+        iters = tb.run(use_graph=True)
         logger = logging.getLogger("flows on clique")
+        for c, p in enumerate(preps):
+            if iters[c] < a.flow_iterations:
+                logger.info(f"Early stopping at iter {iters[c]}")
+            p["trained"] = tb.kparams[c].clone()
+            p["iters"] = iters[c]
+            p["iter_loss"] = tb.iter_loss[c].clone()
 
+    def finish_fit(self, prep: dict) -> NormalizingFlowModelWithSeparator:
+        """Behind the loop (NFiSAM.py:493-513): wrap the trained parameters, record the loss curve."""
+        K, H, B, L = prep["cfg"]
+        D, device = prep["D"], prep["device"]
+        Pk = _nh.kparam_count(D, K, H)
+        trained = prep["trained"]
+        flows = [NSF_AR.from_kernel_params(D, K, B, H, trained[l * Pk:(l + 1) * Pk]) for l in range(L)]
+        normal_clique = CustomMultivariateNormal(dim=D, device=device)
+        normal_separator = CustomMultivariateNormal(dim=prep["sep_dim"], device=device) if prep["sep_dim"] > 0 else None
+        model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, prep["circular"],
+                                                  prep["means"], prep["stds"])
+        clique_name = ''.join([str(var.name) for var in prep["clique"].vars])
+        self._temp_training_loss[clique_name] = [float(v) for v in prep["iter_loss"].cpu().numpy().astype(np.float64)]
+        self.last_fit_iterations = prep["iters"]
+        return model
+
+    def _fit_holdout(self, prep: dict, timer) -> NormalizingFlowModelWithSeparator:
+        """training_set_frac < 1: the reference's validation-driven stop (NFiSAM.py:452-468), one iteration per launch."""
+        a = self._args
+        K, H, B, L = prep["cfg"]
+        device = prep["device"]
+        logger = logging.getLogger("flows on clique")
         opt_start = time.time()
-        if testing_data is None:
-            # Training plans (device buffers + the captured hipGraph of one chunk of iterations) are kept per
-            # clique shape and re-used: the batch and the fresh parameters are copied into the plan's buffers,
-            # Adam moments / state / loss record are cleared in place.
-            n_train = int(training_data.shape[0])
-            key = (n_train, aug_clique_dim, K, H, L, float(a.learning_rate), int(a.flow_iterations),
-                   int(a.average_window), float(a.loss_delta_tol), str(device))
-            plans = self.__dict__.setdefault("_train_plans", {})
-            tb = plans.get(key)
-            if tb is None:
-                tb = _nh.TrainBatch([torch.empty(n_train, aug_clique_dim, dtype=torch.float32, device=device)],
-                                    [torch.zeros_like(kp0)], K, H, B, L, lr=a.learning_rate,
-                                    max_iters=a.flow_iterations, average_window=a.average_window,
-                                    loss_delta_tol=a.loss_delta_tol, early_stop=True)
-                plans[key] = tb
-            tb.xs[0].copy_(training_data)
-            tb.reset(kparams=[kp0])
-            iters = tb.run(use_graph=True)[0]
-            if iters < a.flow_iterations:
-                logger.info(f"Early stopping at iter {iters}")
-            keep_plan = True
-        else:
-            x_dev = training_data.to(device).contiguous()
-            tb = _nh.TrainBatch([x_dev], [kp0], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
-                                average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
-            f0 = NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, kp0)
-            iters = self._fit_with_validation(tb, testing_data.to(device).contiguous(), f0, logger)
-            keep_plan = False
+        x_dev = prep["training_data"].to(device).contiguous()
+        tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                            average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
+        f0 = NSF_AR.from_kernel_params(prep["D"], K, B, H, prep["kp0"])
+        prep["iters"] = self._fit_with_validation(tb, prep["testing_data"].to(device).contiguous(), f0, logger)
         torch.cuda.synchronize()
-        opt_end = time.time()
         if timer is not None:
-            timer.append(opt_end - opt_start)
-        Pk = _nh.kparam_count(aug_clique_dim, K, H)
-        trained = tb.kparams[0].clone() if keep_plan else tb.kparams[0]
-        flows = [NSF_AR.from_kernel_params(aug_clique_dim, K, B, H, trained[l * Pk:(l + 1) * Pk]) for l in range(L)]
-        normal_clique = CustomMultivariateNormal(dim=aug_clique_dim, device=device)
-        normal_separator = CustomMultivariateNormal(dim=aug_separator_dim, device=device) \
-            if aug_separator_dim > 0 else None
-        model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, circular_dim_list, means,
-                                                  stds)
-
-        clique_name = ''.join([str(var.name) for var in clique.vars])
-        self._temp_training_loss[clique_name] = [float(v) for v in tb.iter_loss[0].cpu().numpy().astype(np.float64)]
-        self.last_fit_iterations = iters
-        if not keep_plan:
-            tb.close()
+            timer.append(time.time() - opt_start)
+        prep["trained"] = tb.kparams[0]
+        prep["iter_loss"] = tb.iter_loss[0]
+        model = self.finish_fit(prep)
+        tb.close()
         return model
 
     def _fit_with_validation(self, tb, testing_data, f0, logger):

@@ -21,6 +21,38 @@ args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000
                   learning_rate=.01, hidden_dim=8, cuda_training=True, elimination_method="pose_first",
                   training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50,
                   device_simulation=os.environ.get("DEVSIM", "1") != "0")
+replicas = int(os.environ.get("REPLICAS", "1"))
+if replicas > 1:
+    # R independent runs (seeds SEED .. SEED+R-1) in lock-step: every update trains R cliques per batched launch
+    # (slam.ReplicaNFiSAM; the reference loops over its dataset variants one after the other, run_nfisam.py:11-21)
+    from slam.ReplicaNFiSAM import ReplicaNFiSAM
+    rep = ReplicaNFiSAM(args, [seed + r for r in range(replicas)])
+    walls, fit_iters = [], 0
+    t_all = time.time()
+    for i, (vs, fs) in enumerate(steps[:max_updates]):
+        for v in vs: rep.add_node(v)
+        for f in fs: rep.add_factor(f)
+        t0 = time.time()
+        outs = rep.update()
+        walls.append(time.time() - t0)
+        fit_iters += sum(int(np.count_nonzero(v)) for s in rep.solvers for v in s._temp_training_loss.values())
+        if i % int(os.environ.get('EVERY', '10')) == 0 or i == len(steps) - 1:
+            rm = []
+            for s, o in zip(rep.solvers, outs):
+                poses = [v for v in s.physical_vars if str(v.name).startswith("X")]
+                err = np.array([o[v][:, :2].mean(0) - truth[v][:2] for v in poses])
+                rm.append(float(np.sqrt((err ** 2).sum(1).mean())))
+            print("update %3d: %.3f s for %d replicas = %.1f ms per replica-update, batches %s, traj RMSE %s" %
+                  (i, walls[-1], replicas, 1e3 * walls[-1] / replicas, rep.last_batches, " ".join("%.2f" % r for r in rm)), flush=True)
+    total = time.time() - t_all
+    w = np.array(walls)
+    summary = dict(replicas=replicas, updates=len(walls), total_s=total, wall_per_update_all_replicas_median=float(np.median(w)),
+                   wall_per_replica_update_mean=float(w.mean() / replicas), wall_per_replica_update_median=float(np.median(w) / replicas),
+                   training_sample_iters=float(2000 * fit_iters), final_rmse=rm)
+    print(json.dumps(summary))
+    if out_json:
+        json.dump(dict(summary=summary, walls=walls), open(out_json, "w"))
+    sys.exit(0)
 solver = NFiSAM(args)
 rows = []
 t_all = time.time()

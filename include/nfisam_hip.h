@@ -161,6 +161,11 @@ int nfisam_normalize_columns(const float* x, int n, int D, const uint8_t* circul
                                      p[0:k], noise p[4] z                          (Factors.py:3146-3157)             */
 #define NFISAM_SIM_NH_RING    9   /* RING whose noise is p[1] with probability p[3], else p[2]   (BinaryFactorWithNullHypo,   */
 #define NFISAM_SIM_NH_OBS    10   /* RANGE_OBS whose noise is p[0] with probability p[2], else p[1]    Factors.py:3300-3462)  */
+#define NFISAM_SIM_PRIOR_R2  11   /* c(xy) <- p[0:2] + L z, L = p[2] p[3] p[4] (l00 l10 l11)      (UnaryR2GaussianPriorFactor, :362)   */
+#define NFISAM_SIM_PRIOR_R2_RING 12 /* c(xy) <- p[0:2] + (p[2] + p[3] z)(cos phi, sin phi)  (UnaryR2RangeGaussianPriorFactor, :451)      */
+#define NFISAM_SIM_REL_R2_FWD 13  /* c(xy) <- a(xy) + p[0:2] + L z                                (R2RelativeGaussianLikelihoodFactor, */
+#define NFISAM_SIM_REL_R2_BWD 14  /* c(xy) <- a(xy) - L z - p[0:2]                                 Factors.py:998-1030)                */
+#define NFISAM_SIM_REL_R2_OBS 15  /* c(xy) <- b(xy) - a(xy) + L z                simulated displacement measurement                   */
 typedef struct nfisam_sim_op {
     int32_t code;
     int32_t a, b, c;

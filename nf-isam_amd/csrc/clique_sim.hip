@@ -162,6 +162,34 @@ __global__ void __launch_bounds__(SIM_BLOCK) nsf_clique_sim_kernel(SimArgs a) {
             col(op.c) = sqrtf(dx * dx + dy * dy) + ((r.u2 < op.p[2]) ? op.p[0] : op.p[1]) * r.z0;
             break;
         }
+        case NFISAM_SIM_PRIOR_R2: {               // point prior on the plane: mu + L z
+            const Rand r = draw(a.seed, sample, o);
+            col(op.c) = op.p[0] + op.p[2] * r.z0;
+            col(op.c + 1) = op.p[1] + op.p[3] * r.z0 + op.p[4] * r.z1;
+            break;
+        }
+        case NFISAM_SIM_PRIOR_R2_RING: {          // ring prior around a fixed centre
+            const Rand r = draw(a.seed, sample, o);
+            const float rad = op.p[2] + op.p[3] * r.z0;
+            const float phi = (2.0f * r.u2 - 1.0f) * 3.141592653589793f;
+            col(op.c) = op.p[0] + rad * cosf(phi);
+            col(op.c + 1) = op.p[1] + rad * sinf(phi);
+            break;
+        }
+        case NFISAM_SIM_REL_R2_FWD: case NFISAM_SIM_REL_R2_BWD: {   // displacement factor, either direction
+            const Rand r = draw(a.seed, sample, o);
+            const float nx = op.p[2] * r.z0, ny = op.p[3] * r.z0 + op.p[4] * r.z1;
+            const float sg = (op.code == NFISAM_SIM_REL_R2_FWD) ? 1.0f : -1.0f;
+            col(op.c) = col(op.a) + sg * (op.p[0] + nx);
+            col(op.c + 1) = col(op.a + 1) + sg * (op.p[1] + ny);
+            break;
+        }
+        case NFISAM_SIM_REL_R2_OBS: {             // simulated displacement: x_2 - x_1 + noise
+            const Rand r = draw(a.seed, sample, o);
+            col(op.c) = col(op.b) - col(op.a) + op.p[2] * r.z0;
+            col(op.c + 1) = col(op.b + 1) - col(op.a + 1) + op.p[3] * r.z0 + op.p[4] * r.z1;
+            break;
+        }
         default: break;
         }
     }
@@ -184,9 +212,10 @@ extern "C" int nfisam_simulate_clique(const nfisam_sim_op* ops, int n_ops, int n
         return NFISAM_ERR_ARG;
     for (int o = 0; o < n_ops; ++o) {
         const nfisam_sim_op& op = ops[o];
-        const int w = (op.code == NFISAM_SIM_COPY) ? op.k : ((op.code == NFISAM_SIM_RING || op.code == NFISAM_SIM_NH_RING) ? 2 :
+        const int w = (op.code == NFISAM_SIM_COPY) ? op.k : ((op.code == NFISAM_SIM_RING || op.code == NFISAM_SIM_NH_RING ||
+                                                              op.code >= NFISAM_SIM_PRIOR_R2) ? 2 :
                       ((op.code == NFISAM_SIM_RANGE_OBS || op.code == NFISAM_SIM_ADA_OBS || op.code == NFISAM_SIM_NH_OBS) ? 1 : 3));
-        if (op.code < NFISAM_SIM_COPY || op.code > NFISAM_SIM_NH_OBS || op.c < 0 || op.c + w > D_total) return NFISAM_ERR_ARG;
+        if (op.code < NFISAM_SIM_COPY || op.code > NFISAM_SIM_REL_R2_OBS || op.c < 0 || op.c + w > D_total) return NFISAM_ERR_ARG;
         if (op.code == NFISAM_SIM_COPY && (op.src == 0 || op.k < 1)) return NFISAM_ERR_ARG;
         if (op.code == NFISAM_SIM_ADA_OBS && (op.k < 1 || op.k > 4)) return NFISAM_ERR_ARG;
     }

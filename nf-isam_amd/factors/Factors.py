@@ -8,6 +8,9 @@ dispatch (`PriorFactor`, `BinaryFactor`, ...), `.fg` text (de)serialisation, and
     SE2RelativeGaussianLikelihoodFactor       (reference :1095-1478)
     SE2R2RangeGaussianLikelihoodFactor        (reference :2510-2751)
     AmbiguousDataAssociationFactor            (reference :3043-3298; k-way mixture over candidate landmarks)
+    BinaryFactorWithNullHypo                  (reference :3300-3462; possibly-outlier measurement)
+    UnaryR2GaussianPriorFactor, UnaryR2RangeGaussianPriorFactor, R2RelativeGaussianLikelihoodFactor,
+    R2RangeGaussianLikelihoodFactor           (reference :362, :451, :912, :2026; the toy range-only examples)
 The reference draws noise with TransportMaps' `GaussianDistribution.rvs` and then loops over
 samples building `SE2Pose` objects; here the noise comes from numpy's global RNG (seeded by the
 example scripts exactly like the reference's) and the pose algebra is vectorised
@@ -84,6 +87,10 @@ class ExplicitPriorFactor(PriorFactor):
 
 class ImplicitPriorFactor(PriorFactor):
     """A prior that is only available through sampling, e.g. a trained clique density."""
+
+
+class OdomFactor(object):
+    """Marker of relative-motion factors between consecutive poses (reference :908)."""
 
 
 class KWayFactor(Factor):
@@ -175,7 +182,7 @@ class UnarySE2ApproximateGaussianPriorFactor(ExplicitPriorFactor, UnaryFactor):
 
 
 # ---- SE(2) relative pose (odometry / loop closure) -------------------------------------------------
-class SE2RelativeGaussianLikelihoodFactor(LikelihoodFactor, BinaryFactor):
+class SE2RelativeGaussianLikelihoodFactor(LikelihoodFactor, BinaryFactor, OdomFactor):
     """T_j = T_i * (observation * Exp(eps)), eps ~ N(0, covariance)."""
     measurement_dim = 3
     measurement_type = SE2Variable
@@ -472,6 +479,202 @@ _FACTOR_CLASSES = {c.__name__: c for c in (UnarySE2ApproximateGaussianPriorFacto
                                            SE2RelativeGaussianLikelihoodFactor,
                                            SE2R2RangeGaussianLikelihoodFactor,
                                            AmbiguousDataAssociationFactor)}
+
+
+# ---- the R2 family of the toy range-only examples (BASELINE config[2]; reference :362, :451/:2226, :912, :2026) ----
+def _cov_of(covariance, precision):
+    if covariance is not None:
+        return np.array(covariance, dtype=np.float64)
+    if precision is not None:
+        return np.linalg.inv(np.array(precision, dtype=np.float64))
+    raise ValueError("None of cov and info. were defined.")
+
+
+def _mat2(tok, start):
+    return np.array([[float(tok[start]), float(tok[start + 1])], [float(tok[start + 2]), float(tok[start + 3])]])
+
+
+class UnaryR2GaussianPriorFactor(ExplicitPriorFactor, UnaryFactor):
+    """x ~ N(mu, covariance) on the plane (reference :362-448)."""
+
+    def __init__(self, var: Variable, mu: np.ndarray, covariance: np.ndarray = None, precision: np.ndarray = None):
+        assert var.dim == 2
+        self._vars = [var]
+        self._mu = np.array(mu, dtype=np.float64).ravel()
+        self._covariance = _cov_of(covariance, precision)
+        self._chol = np.linalg.cholesky(self._covariance)
+
+    @property
+    def vars(self):
+        return self._vars
+
+    @property
+    def mu(self):
+        return self._mu
+
+    @property
+    def observation(self):
+        return self._mu
+
+    @property
+    def covariance(self):
+        return self._covariance
+
+    @property
+    def is_gaussian(self):
+        return True
+
+    def sample(self, num_samples: int, **kwargs) -> np.ndarray:
+        return self._mu + _gaussian_noise(self._chol, num_samples)
+
+    @classmethod
+    def construct_from_text(cls, line: str, variables):
+        tok = line.strip().split()
+        if tok[0] != cls.__name__:
+            raise ValueError("The factor name is incorrect")
+        if tok[4] not in ("covariance", "precision"):
+            raise ValueError("Must specify either covariance or precision")
+        var = {v.name: v for v in variables}[tok[1]]
+        return cls(var=var, mu=np.array([float(tok[2]), float(tok[3])]), **{tok[4]: _mat2(tok, 5)})
+
+    def __str__(self):
+        c = self._covariance
+        return " ".join(["Factor", self.__class__.__name__, str(self.var.name), str(self._mu[0]), str(self._mu[1]),
+                         "covariance", str(c[0, 0]), str(c[0, 1]), str(c[1, 0]), str(c[1, 1])])
+
+
+class UnaryR2RangeGaussianPriorFactor(ExplicitPriorFactor, UnaryFactor):
+    """x on a ring around `center`: radius ~ N(mu, sigma^2), uniform bearing (reference :451-533, :2226-2308;
+    draws: src/stats/Distributions.py:125-130)."""
+
+    def __init__(self, var: Variable, center: np.ndarray, mu: float, sigma: float):
+        assert var.dim == 2
+        self._vars = [var]
+        self._center = np.array(center, dtype=np.float64).ravel()
+        self._mu, self._sigma = float(mu), float(sigma)
+
+    @property
+    def vars(self):
+        return self._vars
+
+    @property
+    def center(self):
+        return self._center
+
+    @property
+    def mu(self):
+        return self._mu
+
+    @property
+    def observation(self):
+        return self._mu
+
+    @property
+    def sigma(self):
+        return self._sigma
+
+    def sample(self, num_samples: int, **kwargs) -> np.ndarray:
+        r = self._mu + self._sigma * np.random.standard_normal(num_samples)
+        phi = np.random.uniform(-np.pi, np.pi, num_samples)
+        return self._center + np.stack([r * np.cos(phi), r * np.sin(phi)], 1)
+
+    @classmethod
+    def construct_from_text(cls, line: str, variables):
+        tok = line.strip().split()
+        if tok[0] != cls.__name__:
+            raise ValueError("The factor name is incorrect")
+        var = {v.name: v for v in variables}[tok[1]]
+        if tok[2] == "center":                      # the form `__str__` writes (reference :486-491)
+            return cls(var, np.array([float(tok[3]), float(tok[4])]), float(tok[6]), float(tok[8]))
+        return cls(var, np.array([float(tok[2]), float(tok[3])]), float(tok[4]), float(tok[5]))   # reference :500-505
+
+    def __str__(self):
+        return " ".join(["Factor", self.__class__.__name__, str(self.var.name), "center", str(self._center[0]),
+                         str(self._center[1]), "mu", str(self._mu), "sigma", str(self._sigma)])
+
+
+class R2RelativeGaussianLikelihoodFactor(LikelihoodFactor, BinaryFactor, OdomFactor):
+    """var2 - var1 = observation + N(0, covariance) (reference :912-1092)."""
+    measurement_dim = 2
+    measurement_type = R2Variable
+
+    def __init__(self, var1: Variable, var2: Variable, observation: np.ndarray, covariance: np.ndarray = None,
+                 precision: np.ndarray = None):
+        if var1.dim != var2.dim:
+            raise ValueError("The two variables must have the same dimensionality")
+        if len(observation) != var1.dim:
+            raise ValueError("The observation must have the same dimensionality as the two variables")
+        self._vars = [var1, var2]
+        self._observation = np.array(observation, dtype=np.float64).ravel()
+        self._covariance = _cov_of(covariance, precision)
+        self._chol = np.linalg.cholesky(self._covariance)
+        self._observation_var = R2Variable(name="O" + str(var1.name) + str(var2.name),
+                                           variable_type=VariableType.Measurement)
+
+    @property
+    def vars(self):
+        return self._vars
+
+    @property
+    def observation(self):
+        return self._observation
+
+    @property
+    def observation_var(self):
+        return self._observation_var
+
+    @property
+    def circular_dim_list(self):
+        return self._observation_var.circular_dim_list
+
+    @property
+    def covariance(self):
+        return self._covariance
+
+    @property
+    def is_gaussian(self):
+        return True
+
+    def sample(self, var1: np.ndarray = None, var2: np.ndarray = None) -> np.ndarray:
+        """var2 given -> var1 samples; var1 given -> var2 samples; both -> simulated observations (reference :998-1030)."""
+        if var1 is None:
+            if var2 is None:
+                raise ValueError("Samples of at least one variable must be specified")
+            return var2 - _gaussian_noise(self._chol, var2.shape[0]) - self._observation
+        if var2 is None:
+            return var1 + _gaussian_noise(self._chol, var1.shape[0]) + self._observation
+        if var1.shape != var2.shape or var1.shape[1] != 2:
+            raise ValueError("Dimensionality of variable 1 or variable 2 is wrong")
+        return var2 - var1 + _gaussian_noise(self._chol, var1.shape[0])
+
+    @classmethod
+    def construct_from_text(cls, line: str, variables):
+        tok = line.strip().split()
+        if tok[0] != cls.__name__:
+            raise ValueError("The factor name is incorrect")
+        name_to_var = {v.name: v for v in variables}
+        return cls(var1=name_to_var[tok[1]], var2=name_to_var[tok[2]], observation=np.array([float(tok[3]), float(tok[4])]),
+                   **{tok[5]: _mat2(tok, 6)})
+
+    def __str__(self):
+        c = self._covariance
+        return " ".join(["Factor", self.__class__.__name__, str(self.var1.name), str(self.var2.name),
+                         str(self._observation[0]), str(self._observation[1]), "covariance",
+                         str(c[0, 0]), str(c[0, 1]), str(c[1, 0]), str(c[1, 1])])
+
+
+class R2RangeGaussianLikelihoodFactor(SE2R2RangeGaussianLikelihoodFactor):
+    """|var2 - var1| = observation + N(0, sigma^2) between two points of the plane (reference :2026-2223): the same
+    ring / simulated-range draws as the pose-landmark range factor (both variables' translation indices are 0, 1)."""
+
+    def __init__(self, var1: Variable, var2: Variable, observation: Union[np.ndarray, float], sigma: float = 1.0):
+        if var1.dim != 2 or var2.dim != 2:
+            raise ValueError("R2RangeGaussianLikelihoodFactor connects two R2 variables")
+        super().__init__(var1, var2, observation, sigma)
+
+
+_FACTOR_CLASSES.update({c.__name__: c for c in (UnaryR2GaussianPriorFactor, UnaryR2RangeGaussianPriorFactor,
+                                                R2RelativeGaussianLikelihoodFactor, R2RangeGaussianLikelihoodFactor)})
 
 
 # ---- a binary factor that may be an outlier (reference :3300-3462) -------------------------------------

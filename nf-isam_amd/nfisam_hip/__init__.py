@@ -416,7 +416,7 @@ class SimOp(C.Structure):
 
 SIM_MAX_OPS = 40
 SIM_COPY, SIM_PRIOR_SE2, SIM_REL_FWD, SIM_REL_BWD, SIM_REL_OBS, SIM_RING, SIM_RANGE_OBS, SIM_ADA_OBS, SIM_NH_RING, \
-    SIM_NH_OBS = range(1, 11)
+    SIM_NH_OBS, SIM_PRIOR_R2, SIM_PRIOR_R2_RING, SIM_REL_R2_FWD, SIM_REL_R2_BWD, SIM_REL_R2_OBS = range(1, 16)
 assert C.sizeof(SimOp) == 80
 
 

@@ -23,8 +23,9 @@ import numpy as np
 import torch
 
 from factors.Factors import (AmbiguousDataAssociationFactor, BinaryFactorWithNullHypo,
-                             SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor,
-                             UnarySE2ApproximateGaussianPriorFactor)
+                             R2RelativeGaussianLikelihoodFactor, SE2R2RangeGaussianLikelihoodFactor,
+                             SE2RelativeGaussianLikelihoodFactor, UnaryR2GaussianPriorFactor,
+                             UnaryR2RangeGaussianPriorFactor, UnarySE2ApproximateGaussianPriorFactor)
 
 
 class DeviceSimulationUnsupported(NotImplementedError):
@@ -184,6 +185,11 @@ class FusedSimulationBackend(object):
             all(isinstance(c, SE2R2RangeGaussianLikelihoodFactor) for c in f.components)
 
     @staticmethod
+    def _chol3(f):
+        L = np.asarray(f._chol, dtype=np.float64)
+        return [L[0, 0], L[1, 0], L[1, 1]]
+
+    @staticmethod
     def _chol6(f):
         L = np.asarray(f._chol, dtype=np.float64)
         return [L[0, 0], L[1, 0], L[1, 1], L[2, 0], L[2, 1], L[2, 2]]
@@ -229,6 +235,10 @@ class FusedSimulationBackend(object):
                         src_col += v.dim
                 elif isinstance(f, UnarySE2ApproximateGaussianPriorFactor) and f._correlated_R_t:
                     emit(nh.SIM_PRIOR_SE2, c=column(f.vars[0]), p=list(f._prior_pose.array) + self._chol6(f))
+                elif isinstance(f, UnaryR2GaussianPriorFactor):
+                    emit(nh.SIM_PRIOR_R2, c=column(f.vars[0]), p=list(f.mu) + self._chol3(f))
+                elif isinstance(f, UnaryR2RangeGaussianPriorFactor):
+                    emit(nh.SIM_PRIOR_R2_RING, c=column(f.vars[0]), p=list(f.center) + [f.mu, f.sigma])
                 else:
                     raise DeviceSimulationUnsupported(type(f).__name__)
             elif kind == "draw":
@@ -237,6 +247,9 @@ class FusedSimulationBackend(object):
                 if isinstance(f, SE2RelativeGaussianLikelihoodFactor) and f._correlated_Rt:
                     emit(nh.SIM_REL_BWD if dst == f.var1 else nh.SIM_REL_FWD, a=column(src), c=column(dst),
                          p=list(f.observation) + self._chol6(f))
+                elif isinstance(f, R2RelativeGaussianLikelihoodFactor):
+                    emit(nh.SIM_REL_R2_BWD if dst == f.var1 else nh.SIM_REL_R2_FWD, a=column(src), c=column(dst),
+                         p=list(f.observation) + self._chol3(f))
                 elif isinstance(f, SE2R2RangeGaussianLikelihoodFactor) and dst.dim == 2:
                     emit(nh.SIM_RING, a=column(src), c=column(dst), p=[float(f._observation[0]), f._sigma])
                 elif self._nh_range(f) and dst.dim == 2:
@@ -250,6 +263,8 @@ class FusedSimulationBackend(object):
                 obs_vars.append(f.observation_var)
                 if isinstance(f, SE2RelativeGaussianLikelihoodFactor) and f._correlated_Rt:
                     emit(nh.SIM_REL_OBS, a=column(f.var1), b=column(f.var2), c=ocol, p=[0, 0, 0] + self._chol6(f))
+                elif isinstance(f, R2RelativeGaussianLikelihoodFactor):
+                    emit(nh.SIM_REL_R2_OBS, a=column(f.var1), b=column(f.var2), c=ocol, p=[0, 0] + self._chol3(f))
                 elif isinstance(f, SE2R2RangeGaussianLikelihoodFactor):
                     emit(nh.SIM_RANGE_OBS, a=column(f.var1), b=column(f.var2), c=ocol, p=[f._sigma])
                 elif self._nh_range(f):

@@ -2,7 +2,7 @@
 (reference: src/slam/RunBatch.py:90-336)."""
 from typing import List, Tuple, Union
 
-from factors.Factors import AmbiguousDataAssociationFactor, BinaryFactor, Factor, SE2RelativeGaussianLikelihoodFactor, \
+from factors.Factors import AmbiguousDataAssociationFactor, BinaryFactor, Factor, OdomFactor, \
     UnaryFactor
 from slam.FactorGraphSimulator import read_factor_graph_from_file
 from slam.Variables import Variable, VariableType
@@ -38,7 +38,7 @@ def group_nodes_factors_incrementally(nodes: List[Variable], factors: List[Facto
         elif isinstance(f, BinaryFactor):
             v1, v2 = f.var1, f.var2
             if v1.type == v2.type == VariableType.Pose:
-                consecutive = isinstance(f, SE2RelativeGaussianLikelihoodFactor) and \
+                consecutive = isinstance(f, OdomFactor) and \
                     str(v1.name)[0] == str(v2.name)[0] and int(str(v2.name)[1:]) - int(str(v1.name)[1:]) == 1
                 attach(v2 if consecutive else v1, "odom" if consecutive else "pose_obsv", fidx)
             elif v1.type == VariableType.Pose and v2.type == VariableType.Landmark:

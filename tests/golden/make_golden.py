@@ -8,6 +8,9 @@ inputs; inputs and outputs are stored as small float32/float64 fixtures:
     tests/golden/nsf_<case>.npz        flow forward / loss / grads / Adam / inverse   (a1-a8)
     tests/golden/rqs_direct.npz        direct unconstrained_RQS / RQS / searchsorted  (a5, a6)
     tests/golden/normalize.npz         normalize_training_samples + (un)normalize     (a9, a10)
+    tests/golden/se2_factors.npz       SE2Pose algebra + the `sample` bodies of the factor types of the clique
+                                       simulator (f-2): SE(2) prior, odometry (3 directions), range ring / simulated
+                                       range, k-way association and null-hypothesis mixtures
 
 Reference entry points exercised (paths relative to /root/reference):
     src/flows/flows.py:43-137   NSF_AR.{forward,inverse,inverse_given_separator}
@@ -17,6 +20,12 @@ Reference entry points exercised (paths relative to /root/reference):
     src/slam/NFiSAM.py:96-118,515-548  normalisation helpers (function bodies are executed via
         `ast` extraction because `slam.NFiSAM` imports TransportMaps/dynesty which are absent;
         only those three function definitions are compiled, in memory, never written to disk)
+    src/geometry/TwoDimension.py:303-541  SE2Pose.{by_exp_map, __mul__, __truediv__, inverse, log_map} (imported)
+    src/factors/Factors.py:725-743, 1196-1317, 2575-2649, 3146-3157, 3260-3276, 3300-3380  the `sample*` methods of
+        UnarySE2ApproximateGaussianPriorFactor, SE2RelativeGaussianLikelihoodFactor,
+        SE2R2RangeGaussianLikelihoodFactor, BinaryFactorMixture, AmbiguousDataAssociationFactor and
+        BinaryFactorWithNullHypo -- method bodies executed via `ast` extraction on stand-in `self` objects, because
+        `factors.Factors` imports TransportMaps (absent); nothing is written to disk
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -235,8 +244,170 @@ def gen_normalize():
     print("normalize done")
 
 
+def _extract_methods(path, wanted):
+    """{(class, method): function} compiled in memory from the reference file (no import of the module)."""
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    defs = []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef):
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and (node.name, item.name) in wanted:
+                    item.name = "%s__%s" % (node.name, item.name)
+                    item.decorator_list = []
+                    defs.append(item)
+    mod = ast.Module(body=defs, type_ignores=[])
+    from typing import Dict, Union
+    from geometry.TwoDimension import Point2, Rot2, SE2Pose
+    ns = dict(np=np, SE2Pose=SE2Pose, Point2=Point2, Rot2=Rot2, Union=Union, Dict=Dict, Variable=object)
+    exec(compile(mod, path, "exec"), ns)
+    return {k: ns["%s__%s" % k] for k in wanted}
+
+
+class _FixedNoise(object):
+    """Stand-in for the factors' `_noise_distribution`: hands out a prescribed array."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def rvs(self, n):
+        assert n == self.arr.shape[0]
+        return self.arr.copy()
+
+
+class _GaussNoise(object):
+    """scipy-free N(0, sigma^2) column drawn from numpy's global generator (seeded by the caller)."""
+
+    def __init__(self, sigma):
+        self.sigma = sigma
+
+    def rvs(self, n):
+        return self.sigma * np.random.standard_normal((n, 1))
+
+
+def gen_se2_and_factor_samplers():
+    from geometry.TwoDimension import SE2Pose
+    rng = np.random.RandomState(11)
+    out = {}
+    # ---- SE2Pose algebra (src/geometry/TwoDimension.py:303-541) ----
+    n = 64
+    v = rng.randn(n, 3) * np.array([3.0, 2.0, 1.5])
+    v[0] = [1.0, -2.0, 0.0]; v[1] = [0.5, 0.25, 1e-12]; v[2] = [1.0, 1.0, np.pi - 1e-9]; v[3] = [-1.0, 2.0, -3.1]
+    a = rng.randn(n, 3) * np.array([10.0, 10.0, 2.0]); a[:, 2] = (a[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    b = rng.randn(n, 3) * np.array([5.0, 5.0, 2.0]); b[:, 2] = (b[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    a[5, 2], b[5, 2] = 3.0, 2.5      # sum wraps
+    out["se2_v"] = v
+    out["se2_exp"] = np.array([SE2Pose.by_exp_map(x).array for x in v])
+    out["se2_a"], out["se2_b"] = a, b
+    out["se2_mul"] = np.array([(SE2Pose.by_array(x) * SE2Pose.by_array(y)).array for x, y in zip(a, b)])
+    out["se2_div"] = np.array([(SE2Pose.by_array(x) / SE2Pose.by_array(y)).array for x, y in zip(a, b)])
+    out["se2_inv"] = np.array([SE2Pose.by_array(x).inverse().array for x in a])
+    out["se2_log"] = np.array([SE2Pose.by_array(x).log_map() for x in a])
+    out["se2_explog"] = np.array([SE2Pose.by_exp_map(SE2Pose.by_array(x).log_map()).array for x in a])
+
+    # ---- factor sampler bodies on stand-in objects ----
+    S = types.SimpleNamespace
+    wanted = [("UnarySE2ApproximateGaussianPriorFactor", "sample"), ("SE2RelativeGaussianLikelihoodFactor", "sample"),
+              ("SE2R2RangeGaussianLikelihoodFactor", "sample_var2_from_var1"),
+              ("SE2R2RangeGaussianLikelihoodFactor", "sample_var1_from_var2"),
+              ("SE2R2RangeGaussianLikelihoodFactor", "sample_observations"),
+              ("BinaryFactorMixture", "sample_observations"), ("AmbiguousDataAssociationFactor", "sample_observer"),
+              ("BinaryFactorWithNullHypo", "sample_var2_from_var1"), ("BinaryFactorWithNullHypo", "sample_observations"),
+              ("R2RelativeGaussianLikelihoodFactor", "sample"), ("R2RangeGaussianLikelihoodFactor", "sample_var2_from_var1"),
+              ("R2RangeGaussianLikelihoodFactor", "sample_observations")]
+    M = _extract_methods(os.path.join(REF, "factors/Factors.py"), wanted)
+    m = 48
+    noise3 = rng.randn(m, 3) * np.array([0.3, 0.2, 0.1])
+    noise1 = rng.randn(m, 1) * 0.7
+    x1 = rng.randn(m, 3) * np.array([8.0, 8.0, 1.5]); x1[:, 2] = (x1[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    x2 = rng.randn(m, 3) * np.array([8.0, 8.0, 1.5]); x2[:, 2] = (x2[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    lm = rng.randn(m, 2) * 15.0
+    out.update(f_noise3=noise3, f_noise1=noise1, f_x1=x1, f_x2=x2, f_lm=lm)
+    prior_pose = np.array([3.0, -1.0, 2.8])
+    prior = S(_noise_distribution=_FixedNoise(noise3), _correlated_R_t=True, _prior_pose=SE2Pose.by_array(prior_pose))
+    out["prior_pose"] = prior_pose
+    out["prior_out"] = M[wanted[0]](prior, m)
+    obs = np.array([4.0, 0.7, -2.9])
+    rel = S(_noise_distribution=_FixedNoise(noise3), _correlated_Rt=True, _observation=SE2Pose.by_array(obs), _unary_dim=3)
+    out["rel_obs_value"] = obs
+    out["rel_fwd"] = M[wanted[1]](rel, var1=x1, var2=None)          # var2 from var1
+    out["rel_bwd"] = M[wanted[1]](rel, var1=None, var2=x2)          # var1 from var2
+    out["rel_meas"] = M[wanted[1]](rel, var1=x1, var2=x2)           # simulated measurement
+    zero3 = np.zeros((m, 3))                                        # noise-free variants (the device ops are checked on these)
+    rel0 = S(_noise_distribution=_FixedNoise(zero3), _correlated_Rt=True, _observation=SE2Pose.by_array(obs), _unary_dim=3)
+    out["rel_fwd0"] = M[wanted[1]](rel0, var1=x1, var2=None)
+    out["rel_bwd0"] = M[wanted[1]](rel0, var1=None, var2=x2)
+    out["rel_meas0"] = M[wanted[1]](rel0, var1=x1, var2=x2)
+    pose_var = S(dim=3, t_dim_indices=[0, 1])
+    lmk_var = S(dim=2, t_dim_indices=[0, 1])
+    rng_f = S(_noise_distribution=_FixedNoise(noise1), _observation=np.array([12.0]), var1=pose_var, var2=lmk_var)
+    np.random.seed(5)
+    out["ring_angles"] = np.random.uniform(-np.pi, np.pi, m)           # what the body draws after the fixed noise
+    np.random.seed(5)
+    out["ring_from_pose"] = M[wanted[2]](rng_f, x1)
+    np.random.seed(5)
+    out["ring_from_lmk"] = M[wanted[3]](rng_f, lm)                   # pose xy from the landmark (translation part only)
+    out["range_meas"] = M[wanted[4]](rng_f, x1, lm)
+    rng_f0 = S(_noise_distribution=_FixedNoise(np.zeros((m, 1))), _observation=np.array([12.0]), var1=pose_var, var2=lmk_var)
+    out["range_meas0"] = M[wanted[4]](rng_f0, x1, lm)
+    # ---- R2 family of the toy examples (src/factors/Factors.py:998-1030, 2080-2135) ----
+    noise2 = rng.randn(m, 2) * np.array([0.3, 0.2])
+    p1, p2 = rng.randn(m, 2) * 6.0, rng.randn(m, 2) * 6.0
+    r2rel = S(_noise_distribution=_FixedNoise(noise2), _observation=np.array([5.0, -5.0]), _unary_dim=2)
+    out.update(r2_noise2=noise2, r2_p1=p1, r2_p2=p2)
+    out["r2rel_fwd"] = M[wanted[9]](r2rel, var1=p1, var2=None)
+    out["r2rel_bwd"] = M[wanted[9]](r2rel, var1=None, var2=p2)
+    out["r2rel_meas"] = M[wanted[9]](r2rel, var1=p1, var2=p2)
+    r2rng = S(_noise_distribution=_FixedNoise(noise1), _observation=np.array([12.0]), _unary_dim=2)
+    np.random.seed(5)
+    out["r2ring"] = M[wanted[10]](r2rng, p1)                          # same angle draws as `ring_angles`
+    out["r2range_meas"] = M[wanted[11]](r2rng, p1, p2)
+    # ---- mixtures, real random numbers under a seed: frequencies and conditional moments are pinned ----
+    N = 3000
+    pose = rng.randn(N, 3) * np.array([2.0, 2.0, 0.5])
+    cands = [np.array([30.0, 0.0]) + 0.1 * rng.randn(N, 2), np.array([0.0, 45.0]) + 0.1 * rng.randn(N, 2),
+             np.array([-60.0, 0.0]) + 0.1 * rng.randn(N, 2)]
+    class V(object):                      # hashable stand-in for slam.Variables.Variable
+        def __init__(self, name, dim):
+            self.name, self.dim, self.t_dim_indices = name, dim, [0, 1]
+    Pv, Lv = V("X", 3), [V("L%d" % k, 2) for k in range(3)]
+
+    def range_comp(v1, v2, sigma):
+        c = S(_noise_distribution=_GaussNoise(sigma), _observation=np.array([20.0]), var1=v1, var2=v2)
+        c.sample_var2_from_var1 = lambda x: M[wanted[2]](c, x)
+        c.sample_var1_from_var2 = lambda x: M[wanted[3]](c, x)
+        c.sample_observations = lambda p, q: M[wanted[4]](c, p, q)
+        c.sample = lambda var1=None, var2=None: (c.sample_var1_from_var2(var2) if var1 is None else
+                                                 (c.sample_var2_from_var1(var1) if var2 is None else
+                                                  c.sample_observations(var1, var2)))
+        return c
+    w = np.array([0.5, 0.3, 0.2])
+    ada = S(observer_var=Pv, observed_vars=Lv, weights=w, measurement_dim=1,
+            components=[range_comp(Pv, Lv[k], 0.5) for k in range(3)])
+    np.random.seed(21)
+    out["ada_counts"] = np.random.multinomial(N, w)
+    np.random.seed(21)
+    out["ada_obs"] = M[wanted[5]](ada, {Pv: pose, Lv[0]: cands[0], Lv[1]: cands[1], Lv[2]: cands[2]})
+    out.update(ada_pose=pose, ada_c0=cands[0], ada_c1=cands[1], ada_c2=cands[2], ada_weights=w, ada_sigma=np.array(0.5))
+    nh_w, nh_sigma, nh_scale = np.array([0.7, 0.3]), 0.5, 6.0
+    nh = S(var1=Pv, var2=Lv[0], weights=nh_w, measurement_dim=1,
+           components=[range_comp(Pv, Lv[0], nh_sigma), range_comp(Pv, Lv[0], nh_sigma * nh_scale)])
+    np.random.seed(22)
+    out["nh_counts"] = np.random.multinomial(N, nh_w)
+    np.random.seed(22)
+    out["nh_obs"] = M[wanted[8]](nh, pose, cands[0])
+    np.random.seed(23)
+    out["nh_ring_counts"] = np.random.multinomial(N, nh_w)
+    np.random.seed(23)
+    out["nh_ring"] = M[wanted[7]](nh, pose)
+    out.update(nh_weights=nh_w, nh_sigma=np.array(nh_sigma), nh_scale=np.array(nh_scale), mix_obs=np.array(20.0))
+    np.savez_compressed(os.path.join(OUT, "se2_factors.npz"), **out)
+    print("se2_factors done", {k: np.shape(v) for k, v in out.items() if k.startswith(("prior", "rel", "ring", "range"))})
+
+
 if __name__ == "__main__":
     for name, (n, D, K, seed) in CASES.items():
         gen_flow_case(name, n, D, K, seed)
     gen_rqs_direct()
     gen_normalize()
+    gen_se2_and_factor_samplers()

@@ -272,3 +272,88 @@ def test_dataset_first_updates_end_to_end(tmp_path, dataset, args, n_updates, rm
         assert n_pose == len([v for v in seen if v.startswith("X")])
         rmses.append(r)
     assert max(rmses) < rmse_each and float(np.median(rmses)) < rmse_median, rmses
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config[2] as a REAL graph: toy range-only SLAM in R2 (20 poses, 4 landmarks) with the R2 factor family
+# ---------------------------------------------------------------------------------------------------------
+def _toy_r2_graph(seed=0):
+    """The generative recipe of example/slam/toy_examples/R2RangeGaussian_example (R2 poses on a path, displacement
+    odometry, range factors to R2 landmarks, Gaussian prior on the first pose) at BASELINE config[2]'s size."""
+    from factors.Factors import (R2RangeGaussianLikelihoodFactor, R2RelativeGaussianLikelihoodFactor,
+                                 UnaryR2GaussianPriorFactor)
+    from slam.Variables import R2Variable, VariableType
+    rng = np.random.RandomState(seed)
+    poses = [R2Variable("X%d" % i) for i in range(20)]
+    lms = [R2Variable("L%d" % j, VariableType.Landmark) for j in range(4)]
+    lm_xy = np.array([[15.0, 20.0], [45.0, -15.0], [75.0, 25.0], [100.0, -10.0]])
+    xy = np.stack([np.array([6.0 * i, 8.0 * np.sin(i / 3.0)]) for i in range(20)])
+    truth = {v: xy[i] for i, v in enumerate(poses)}
+    truth.update({v: lm_xy[j] for j, v in enumerate(lms)})
+    factors = [UnaryR2GaussianPriorFactor(poses[0], xy[0], covariance=np.eye(2) * 0.04)]
+    odo_cov = np.eye(2) * 0.04
+    for i in range(19):
+        factors.append(R2RelativeGaussianLikelihoodFactor(poses[i], poses[i + 1], xy[i + 1] - xy[i] + 0.2 * rng.randn(2),
+                                                          covariance=odo_cov))
+    for i in range(20):
+        j = int(np.argmin(np.linalg.norm(lm_xy - xy[i], axis=1)))
+        for jj in {j, (j + 1) % 4 if i % 3 == 0 else j}:
+            factors.append(R2RangeGaussianLikelihoodFactor(poses[i], lms[jj], float(np.linalg.norm(lm_xy[jj] - xy[i]) +
+                                                                                     0.5 * rng.randn()), 0.5))
+    return poses + lms, truth, factors
+
+
+def test_toy_r2_range_only_graph_runs_on_the_device_simulator(tmp_path):
+    """BASELINE config[2] ("toy_examples range-only SLAM, 20 poses / 4 landmarks") as a factor graph: `.fg` text round trip,
+    incremental updates through NFiSAM with every clique batch simulated by `nfisam_simulate_clique` (R2 ops 11-15),
+    posterior means near the truth once every landmark has been ranged from several poses."""
+    import sampler.DeviceSimulation as DS
+    from slam.FactorGraphSimulator import factor_graph_to_string, read_factor_graph_from_file
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.RunBatch import group_nodes_factors_incrementally
+    nodes, truth, factors = _toy_r2_graph()
+    p = tmp_path / "factor_graph.fg"
+    p.write_text(factor_graph_to_string(nodes, factors, truth))
+    nodes2, truth2, factors2 = read_factor_graph_from_file(str(p))
+    assert [str(f) for f in factors2] == [str(f) for f in factors] and len(nodes2) == 24
+    steps = group_nodes_factors_incrementally(nodes2, factors2, incremental_step=5)
+    assert len(steps) == 4
+    unsupported = []
+    orig = DS.FusedSimulationBackend.run_plan
+
+    def spy(self, steps_, pattern, n):
+        try:
+            return orig(self, steps_, pattern, n)
+        except DS.DeviceSimulationUnsupported as e:      # would silently fall back to the host samplers
+            unsupported.append(str(e))
+            raise
+    DS.FusedSimulationBackend.run_plan = spy
+    try:
+        random.seed(1); np.random.seed(1); torch.manual_seed(1)
+        solver = NFiSAM(NFiSAMArgs(num_knots=9, flow_iterations=1500, local_sample_num=2000, learning_rate=.02,
+                                   hidden_dim=8, cuda_training=True, elimination_method="pose_first",
+                                   training_set_frac=1.0, loss_delta_tol=.01, posterior_sample_num=500))
+        trained = 0
+        for vs, fs in steps:
+            for v in vs:
+                solver.add_node(v)
+            for f in fs:
+                solver.add_factor(f)
+            solver.update_physical_and_working_graphs()
+            res = solver.incremental_inference()
+            trained += len(solver._temp_training_loss)
+    finally:
+        DS.FusedSimulationBackend.run_plan = orig
+    assert unsupported == []
+    assert trained >= 8                                   # "8 cliques" of config[2]: at least that many flows were trained
+    name = {str(v.name): v for v in solver.physical_vars}
+    err = np.array([res[name["X%d" % i]].mean(0) - truth2[name["X%d" % i]] for i in range(20)])
+    assert np.sqrt((err ** 2).sum(1).mean()) < 1.5, np.sqrt((err ** 2).sum(1).mean())
+    for j in range(4):
+        s = res[name["L%d" % j]]
+        assert s.shape == (500, 2) and np.all(np.isfinite(s))
+        # range-only landmark posteriors are broad arcs: the truth must lie inside the sample cloud (a sixth of the
+        # samples within 5 m) and the median within 8 m
+        d = np.linalg.norm(s - truth2[name["L%d" % j]], axis=1)
+        assert np.quantile(d, 1.0 / 6.0) < 5.0 and np.linalg.norm(np.median(s, 0) - truth2[name["L%d" % j]]) < 8.0, \
+            (j, np.median(s, 0), np.quantile(d, 1.0 / 6.0))

@@ -58,8 +58,8 @@ def test_fg_roundtrip_and_grouping(small_graph):
     assert sum(len(s[1]) for s in steps) == len(factors)
     two = group_nodes_factors_incrementally(nodes, factors, incremental_step=2)
     assert [[v.name for v in s[0]] for s in two] == [["X0", "L1", "L2", "X1"], ["X2", "X3"], ["X4", "X5"]]
-    with pytest.raises(NotImplementedError):
-        Factor.construct_from_text("Factor R2RangeGaussianLikelihoodFactor X0 L1 1 1", nodes)
+    with pytest.raises(NotImplementedError):      # a factor type outside the rebuilt scope is refused loudly
+        Factor.construct_from_text("Factor SE2BearingLikelihoodFactor X0 L1 1 1", nodes)
 
 
 def test_factor_sampling_statistics():

@@ -330,3 +330,92 @@ def test_fused_simulator_ops_are_exact_without_noise():
     np.testing.assert_allclose(d[:, 3], np.linalg.norm(d[:, 4:6] - x0, axis=1), atol=1e-4)
     phi = np.arctan2(d[:, 5] - x2[:, 1], d[:, 4] - x2[:, 0])
     assert phi.min() < -2.5 and phi.max() > 2.5 and abs(np.mean(np.cos(phi))) < 0.2
+
+
+def test_fused_simulator_ops_match_reference_se2_algebra():
+    """The SE(2) ops of `nfisam_simulate_clique` (csrc/clique_sim.hip) against vectors produced by the REFERENCE's factor
+    `sample` bodies with zero noise (tests/golden/se2_factors.npz, src/factors/Factors.py:1196-1317, 2610-2619 executed by
+    tests/golden/make_golden.py): odometry forward T_j = T_i * obs, backward T_i = T_j / obs, odometry as a measurement
+    T_i^-1 T_j, simulated range, SE(2) prior.  The op list is written by hand so that every op gets the golden inputs."""
+    import nfisam_hip as nh
+    g = dict(np.load(os.path.join(GOLDEN, "se2_factors.npz")))
+    n = g["f_x1"].shape[0]
+    src = torch.from_numpy(np.hstack([g["f_x1"], g["f_x2"], g["f_lm"]]).astype(np.float32)).to(DEV).contiguous()
+
+    def op(code, a=0, b=0, c=0, k=0, p=(), srcp=0):
+        o = nh.SimOp()
+        o.code, o.a, o.b, o.c, o.k, o.src = code, a, b, c, k, srcp
+        for i, v in enumerate(p):
+            o.p[i] = float(v)
+        return o
+    z6 = [0.0] * 6
+    obs = list(g["rel_obs_value"])
+    ops = [op(nh.SIM_COPY, a=8, b=0, c=4, k=3, srcp=src.data_ptr()), op(nh.SIM_COPY, a=8, b=3, c=7, k=3, srcp=src.data_ptr()),
+           op(nh.SIM_COPY, a=8, b=6, c=10, k=2, srcp=src.data_ptr()),
+           op(nh.SIM_REL_FWD, a=4, c=12, p=obs + z6), op(nh.SIM_REL_BWD, a=7, c=15, p=obs + z6),
+           op(nh.SIM_REL_OBS, a=4, b=7, c=0, p=[0, 0, 0] + z6), op(nh.SIM_RANGE_OBS, a=4, b=10, c=3, p=[0.0]),
+           op(nh.SIM_PRIOR_SE2, c=18, p=list(g["prior_pose"]) + z6)]
+    out = nh.simulate_clique(ops, n, 21, 21, 12345, DEV).cpu().numpy().astype(np.float64)
+
+    def pose_close(got, ref):
+        np.testing.assert_allclose(got[:, :2], ref[:, :2], atol=4e-5)
+        d = np.abs((got[:, 2] - ref[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+        assert np.minimum(d, 2 * np.pi - d).max() < 5e-6
+    np.testing.assert_allclose(out[:, 4:12], src.cpu().numpy(), atol=0)
+    pose_close(out[:, 12:15], g["rel_fwd0"])
+    pose_close(out[:, 15:18], g["rel_bwd0"])
+    pose_close(out[:, 0:3], g["rel_meas0"])
+    np.testing.assert_allclose(out[:, 3], g["range_meas0"][:, 0], atol=4e-5)
+    pose_close(out[:, 18:21], np.tile(g["prior_pose"], (n, 1)))
+
+
+def test_fused_simulator_mixture_ops_match_reference_statistics():
+    """k-way association (`SIM_ADA_OBS`) and null-hypothesis (`SIM_NH_OBS`, `SIM_NH_RING`) ops: component frequencies and
+    conditional residual moments equal the ones the REFERENCE's `sample_observations` / `sample_var2_from_var1` bodies
+    (src/factors/Factors.py:3146-3157, 3300-3380) produce on the same inputs (tests/golden/se2_factors.npz).  The
+    candidates are 30 / 45 / 60 m from the poses, so the chosen component of a sample is identified by its value."""
+    import nfisam_hip as nh
+    g = dict(np.load(os.path.join(GOLDEN, "se2_factors.npz")))
+    N = g["ada_pose"].shape[0]
+    w, sigma, mix_obs = g["ada_weights"], float(g["ada_sigma"]), float(g["mix_obs"])
+    cands = [g["ada_c0"], g["ada_c1"], g["ada_c2"]]
+    src = torch.from_numpy(np.hstack([g["ada_pose"]] + cands).astype(np.float32)).to(DEV).contiguous()   # [N, 9]
+
+    def op(code, a=0, b=0, c=0, k=0, p=(), cand=(), srcp=0):
+        o = nh.SimOp()
+        o.code, o.a, o.b, o.c, o.k, o.src = code, a, b, c, k, srcp
+        for i, v in enumerate(p):
+            o.p[i] = float(v)
+        for i, v in enumerate(cand):
+            o.cand[i] = int(v)
+        return o
+    cum = list(np.cumsum(w)) + [1.0]
+    nw, ns, scale = g["nh_weights"], float(g["nh_sigma"]), float(g["nh_scale"])
+    # columns: 0 ada obs | 1 nh obs | 2..4 pose | 5..10 candidates | 11..12 nh ring
+    ops = [op(nh.SIM_COPY, a=9, b=0, c=2, k=3, srcp=src.data_ptr())] + \
+          [op(nh.SIM_COPY, a=9, b=3 + 2 * k, c=5 + 2 * k, k=2, srcp=src.data_ptr()) for k in range(3)] + \
+          [op(nh.SIM_ADA_OBS, a=2, c=0, cand=[5, 7, 9], k=3, p=cum + [sigma]),
+           op(nh.SIM_NH_OBS, a=2, b=5, c=1, p=[ns, ns * scale, float(nw[0])]),
+           op(nh.SIM_NH_RING, a=2, c=11, p=[mix_obs, ns, ns * scale, float(nw[0])])]
+    out = nh.simulate_clique(ops, N, 13, 13, 777, DEV).cpu().numpy().astype(np.float64)
+    dist = np.stack([np.linalg.norm(c - g["ada_pose"][:, :2], axis=1) for c in cands], 1)
+    pick = np.abs(out[:, 0:1] - dist).argmin(1)
+    # the reference's block layout -> its per-component residual std
+    lo = 0
+    for k, cnt in enumerate(g["ada_counts"]):
+        ref_r = g["ada_obs"][lo:lo + cnt, 0] - dist[lo:lo + cnt, k]
+        lo += cnt
+        mine = out[pick == k, 0] - dist[pick == k, k]
+        assert abs((pick == k).mean() - w[k]) < 4 * np.sqrt(w[k] * (1 - w[k]) / N), (k, (pick == k).mean())
+        assert abs(mine.std() / ref_r.std() - 1) < 0.12 and abs(mine.mean()) < 5 * sigma / np.sqrt(len(mine))
+    # null hypothesis: a two-scale mixture around the true range; compare the mixture's quantiles with the reference's draw
+    r_dev = out[:, 1] - dist[:, 0]
+    r_ref = g["nh_obs"][:, 0] - dist[:, 0]
+    for q in (0.05, 0.25, 0.5, 0.75, 0.95):
+        assert abs(np.quantile(r_dev, q) - np.quantile(r_ref, q)) < 0.12 * (1 + abs(np.quantile(r_ref, q))), q
+    assert abs(r_dev.std() / r_ref.std() - 1) < 0.12
+    rad_dev = np.linalg.norm(out[:, 11:13] - g["ada_pose"][:, :2], axis=1) - mix_obs
+    rad_ref = np.linalg.norm(g["nh_ring"] - g["ada_pose"][:, :2], axis=1) - mix_obs
+    assert abs(rad_dev.std() / rad_ref.std() - 1) < 0.12 and abs(rad_dev.mean() - rad_ref.mean()) < 0.15
+    phi = np.arctan2(out[:, 12] - g["ada_pose"][:, 1], out[:, 11] - g["ada_pose"][:, 0])
+    assert phi.min() < -3.0 and phi.max() > 3.0 and abs(np.cos(phi).mean()) < 0.08

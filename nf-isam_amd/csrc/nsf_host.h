@@ -1,0 +1,156 @@
+// nsf_host.h -- what the translation units of libnfisam_hip.so share on the host side.
+//
+// The library is built from one COMMON unit (nsf_kernels.hip: the C ABI of include/nfisam_hip.h, training plans, the
+// Adam / bookkeeping / normalisation / elementwise-spline kernels, launch-shape decisions) and several KERNEL units
+// (nsf_unit.hip compiled once per -DNSF_UNIT=u): the kernels templated on (K bins, H hidden width) and their launchers
+// for the (K, H) pairs of that unit (nsf_units.h).  Splitting the instantiations lets `make -j` compile them in
+// parallel, which is what makes K = 2..16 x H in {4, 8, 16} affordable.  The common unit reaches a kernel unit through
+// the `NsfUnitOps` table that unit exports.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/nfisam_hip.h"
+#include "nsf_device.h"
+#include "nsf_split.h"
+#include "nsf_units.h"
+
+using namespace nsf;
+
+extern thread_local int nfisam_g_last_hip_error;      // defined in the common unit
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) {                         \
+            nfisam_g_last_hip_error = (int)e_;          \
+            return NFISAM_ERR_LAUNCH;                   \
+        }                                               \
+    } while (0)
+
+constexpr int XS = 66;            // LDS row stride (floats) of every [feature][particle] tile
+// Per-iteration loss sums live behind the gradient slabs in the kgrad workspace: a ring of LOSS_RING
+// iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
+// bookkeeping kernel that closes a chunk of iterations consumes and clears them.
+constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
+
+struct TrainArgs {
+    const nfisam_clique* cliques;   // device array (batched) or nullptr
+    nfisam_clique single;           // by-value descriptor when cliques == nullptr
+    const float* gz;                // VJP mode: upstream dL/dz [n,D]
+    const float* gl;                // VJP mode: upstream dL/dlogdet [n] (nullable => 0)
+    float* gx;                      // optional dL/dx [n,D]
+    float* loss_sum;                // optional accumulator when no train state is attached
+    float B;
+    int L;
+    int max_iters;
+    int nll_mode;
+    int layer_stride;               // floats between layers in kparams/kgrad (0: kparam_count(D))
+    int wl_floats;                  // LDS floats reserved for the parameter copy (WL variants)
+    int slab;                       // != 0: kgrad is [n_tiles][L*Pk], plain stores (see gsink)
+    int tile;                       // host only: particles per tile (kernel family)
+    int iter_idx;                   // iteration index inside the chunk (state->step advances once per chunk)
+    int g_tiles;                    // 1: LDS holds the two dL/dx tiles (L > 1 or gx requested)
+    int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
+    int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
+    int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
+};
+
+
+// Launchers of one (K, H) pair, exported by the kernel unit that instantiates it.
+struct NsfUnitOps {
+    int K, H;
+    int (*forward)(const float* x, const float* kparams, int n, int D, float B, int L, int layer_stride, float* z, float* logdet,
+                   float* logprob, hipStream_t s);
+    int (*inverse)(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds, float B, int L,
+                   int layer_stride, const float* mean, const float* stdv, const uint8_t* circular, float* x_out,
+                   float* logdet, hipStream_t s);
+    int (*walk)(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs, int max_D, float B,
+                int L, int n, const float* Zt, float* St, hipStream_t s);
+    int (*train)(const TrainArgs& a, int n_cliques, int max_n, int max_D, hipStream_t s);   // gradient kernel of an iteration
+};
+#define NSF_DECLARE_UNIT(u) extern "C" const NsfUnitOps* nsf_unit_ops_u##u(int K, int H);
+NSF_UNITS(NSF_DECLARE_UNIT)
+
+static inline size_t kcount(int D, int K, int H) {
+    const size_t PoP = (size_t)pop_of(K);
+    const size_t kfixed = (size_t)H + (size_t)H * H + H + (size_t)H * PoP + PoP;
+    return PoP + (size_t)(D - 1) * kfixed + (size_t)H * ((size_t)(D - 1) * D / 2);
+}
+
+static inline int pick_waves(int D) { return D < 1 ? 1 : (D > 8 ? 8 : D); }
+
+template <typename KernelT>
+static int set_lds(KernelT kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return NFISAM_ERR_ARG;
+    if (bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+    return NFISAM_OK;
+}
+
+// ---- launch-shape knobs (environment variables are for A/B measurements and tests) -------------------------------
+// The weight-gradient GEMMs run on the matrix cores when H == 8 (ga2 | ga1 share one 16-row MFMA operand tile); other
+// hidden widths, and NFISAM_GRAD=butterfly, take the cross-lane butterfly reduction of round 1.
+static inline bool use_mfma_grad(int H) {
+    const char* e = getenv("NFISAM_GRAD");
+    return H == 8 && !(e != nullptr && strcmp(e, "butterfly") == 0);
+}
+
+static inline int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: automatic
+    const char* e = getenv("NFISAM_WEIGHTS");
+    return (e == nullptr) ? -1 : (strcmp(e, "lds") == 0 ? 1 : (strcmp(e, "scalar") == 0 ? 0 : -1));
+}
+
+// Training kernel family, chosen per launch: "split" (two lanes per particle, 32-particle tiles) while the
+// launch leaves SIMDs idle -- it halves the instructions per wave and doubles the waves -- and "wide" (one
+// lane per particle, 64-particle tiles: no duplicated scalar spline work, half the gradient copies) once the
+// chip is full.  NFISAM_TRAIN=wide|split forces one family (A/B measurements).  The split kernel exists for H == 8.
+static inline int train_tile(int n_cliques, int max_n, int max_D, int H) {
+    if (H != 8) return TILE;
+    const char* e = getenv("NFISAM_TRAIN");            // read per call: tests switch families in-process
+    if (e != nullptr) {
+        if (strcmp(e, "wide") == 0) return TILE;
+        if (strcmp(e, "split") == 0) return TILE2;
+    }
+    const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
+    return waves <= 1280 ? TILE2 : TILE;
+}
+
+// Throughput launches (wide family, L == 1) go to nsf_train1_kernel (dim-major blocks) unless NFISAM_DIM_MAJOR=0
+// (A/B against nsf_train_kernel's tile-major blocks).
+static inline bool dim_major_enabled() {
+    const char* e = getenv("NFISAM_DIM_MAJOR");
+    return !(e != nullptr && e[0] == '0');
+}
+static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
+    const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && tiles * max_D > 1024;
+}
+
+// 64-particle tiles summed into one gradient copy (one wave's sweep in nsf_train1_kernel, one block's in
+// nsf_train_kernel).  More tiles per copy = fewer copies for the Adam kernel to read back, fewer prologues and
+// better scalar-cache reuse of the weights, as long as the launch still has ~1.5x the waves the chip holds at four
+// waves per SIMD (4096).  The decision depends on the launch shape only, so the gradient, Adam and bookkeeping
+// launches of an iteration agree on the number of gradient copies.
+static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
+    if (tile != TILE || L != 1 || !use_mfma_grad(H)) return 1;
+    const long tiles_c = (max_n + TILE - 1) / TILE, tiles = tiles_c * n_cliques;
+    if (tiles * max_D <= 1024) return 1;
+    const char* e = getenv("NFISAM_TILES_PER_BLOCK");
+    int T = 1;
+    if (is_dim_major(n_cliques, max_n, max_D, L, tile, H)) {
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
+        while (T < 8 && (long)n_cliques * ((tiles_c + 2 * T - 1) / (2 * T)) * max_D >= 6144) T *= 2;
+        return T;
+    }
+    if (tiles <= 256) return 1;                  // nsf_train_kernel spreads the dims over grid.z there: one tile per block
+    if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
+    const int W = max_D < 4 ? max_D : 4;
+    while (T < 4 && tiles * W / (2 * T) >= 4096) T *= 2;
+    return T;
+}

@@ -1,0 +1,1877 @@
+// nsf_unit.hip -- one KERNEL unit of libnfisam_hip.so: the gfx950 kernels templated on (K bins, H hidden width) and
+// their launchers, instantiated for the (K, H) pairs of unit NSF_UNIT (nsf_units.h).  Compiled once per unit
+// (Makefile: -DNSF_UNIT=u); see nsf_host.h for how the units fit together.
+//
+// Work decomposition:
+//   training   latency regime   nsf_train2_kernel (two lanes per particle) / nsf_train_kernel: block = W waves over ONE
+//                               particle tile, wave w owns the dims w, w+W, ... of every layer (in the density
+//                               direction all D conditioners depend only on the layer input, src/flows/flows.py:77-83);
+//                               layers are sequential: layer inputs live in LDS and waves meet at __syncthreads()
+//              throughput       nsf_train1_kernel: one wave = one dim x T tiles, dim-major blocks
+//   inverse    one wave per 64 particles, dims sequential (true data dependence, flows.py:115-137)
+//   walk       whole Bayes tree root -> leaves in one launch
+#include <type_traits>
+
+#include "nsf_host.h"
+
+#ifndef NSF_UNIT
+#error "compile with -DNSF_UNIT=<unit index> (see nsf_units.h)"
+#endif
+#define NSF_PASTE_(a, b) a##b
+#define NSF_PASTE(a, b) NSF_PASTE_(a, b)
+#define NSF_FOR_EACH_KH(X) NSF_PASTE(NSF_KH_, NSF_UNIT)(X)
+
+// =============================================================================================
+// cross-lane reduce-scatter: on return lane l holds the wave total of input v[l & (N-1)].
+// log2(N) exchange steps move N-1 values in total (vs 6 per value for a plain wave reduction).
+// =============================================================================================
+template <int N>
+__device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
+#pragma unroll
+    for (int half = N / 2; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int t = 0; t < half; ++t) {
+            const float lo = v[t], hi = v[t + half];   // load first: keeps v[] in registers (no select-of-address)
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            v[t] = keep + __shfl_xor(send, half, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int off = N; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
+    return r;
+}
+
+// Gradient sink.  slab = false: accumulate into one shared buffer with float atomics (any number of
+// tiles).  slab = true: this tile owns a private copy of the gradient buffer and every entry is written
+// exactly once per iteration with a plain store; the Adam kernel sums the tiles in a fixed order
+// (no memory-side atomic tail on small launches, bitwise-reproducible training).
+typedef __attribute__((address_space(1))) float gfloat;       // device-memory float (global_ instead of flat_ instructions)
+typedef __attribute__((ext_vector_type(4))) float vf4_t;
+typedef __attribute__((address_space(1))) vf4_t gvf4_t;
+__device__ __forceinline__ void gsink(float* dst, float v, bool slab) {
+    if (slab) *dst = v; else atomicAdd(dst, v);
+}
+__device__ __forceinline__ void gsink(gfloat* dst, float v, bool slab) {
+    if (slab) *dst = v; else __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gsink4(gfloat* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
+    if (slab) {
+        *(gvf4_t*)dst = v;
+        return;
+    }
+    gsink(dst + 0, v.x, slab);
+    gsink(dst + 1, v.y, slab);
+    gsink(dst + 2, v.z, slab);
+    gsink(dst + 3, v.w, slab);
+}
+__device__ __forceinline__ void gsink4(float* dst, const __attribute__((ext_vector_type(4))) float& v, bool slab) {
+    if (slab) {   // every destination of a 4-group is 16-byte aligned (kernel-layout rows are multiples of 4 floats)
+        *(__attribute__((ext_vector_type(4))) float*)dst = v;
+        return;
+    }
+    gsink(dst + 0, v.x, slab);
+    gsink(dst + 1, v.y, slab);
+    gsink(dst + 2, v.z, slab);
+    gsink(dst + 3, v.w, slab);
+}
+
+// =============================================================================================
+// training / VJP kernels
+// =============================================================================================
+template <int K, int H, typename WP>
+__device__ __forceinline__ void load_theta(WP lp, int i, const float* xin, int xstride, int lane,
+                                           float (&h1)[H], float (&h2)[H],
+                                           float (&th)[Layout<K, H>::PoP]) {
+    using LY = Layout<K, H>;
+    if (i == 0) {
+        load_row<LY::PoP>(lp, th);
+    } else {
+        WP blk = lp + LY::off(i);
+        cond_hidden<K, H, WP>(blk, i, xin, xstride, lane, h1, h2);
+        cond_theta<K, H, WP>(blk, i, h2, th);
+    }
+}
+
+// ---- weight-gradient GEMMs on the matrix cores -------------------------------------------------
+// For one (layer, dim) unit the parameter gradients are sums over the wave's 64 particles of outer
+// products:  dW2t[c][o] = sum_p h2ext[p][c] * gth[p][o],  dW1t[c][j] = sum_p h1ext[p][c] * ga2[p][j],
+// dW0t[c][j] = sum_p xext[p][c] * ga1[p][j]   (ext = activation vector with a trailing 1 for the bias).
+// With the particle index as the contraction dimension these are GEMMs, and
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) does the cross-lane reduction for free:
+// 4 particles per instruction.  The VALU phase holds "particle on the lane, feature in the
+// register"; the MFMA operands need "feature on lane&15, particle on lane>>4", so the vectors take
+// one trip through a wave-private LDS tile, feature-major with a row stride of XS = 66 floats
+// (66 mod 32 = 2 makes both the 64-lane row writes and the 16x4 operand reads conflict-free).
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- diagnostic build only (-DNSF_STAMPS): per-wave s_memtime stamps at phase boundaries ---------
+#if defined(NSF_STAMPS) && NSF_UNIT == 0   // stamps exist in the K = 9, H = 8 unit only
+__device__ unsigned long long g_stamps[64 * 32];
+__device__ unsigned long long g_blk[4096 * 2];
+__device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
+#define STAMP_DECL unsigned long long sacc_[16] = {0ull}; unsigned long long sprev_ = 0ull;
+#define STAMP(id)                                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (sprev_ != 0ull) sacc_[(id) & 15] += t_ - sprev_;                                        \
+        sprev_ = t_;                                                                                \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) {                         \
+            const int sw_ = ((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32;                      \
+            g_stamps[sw_ + (id)] = t_;                                                              \
+            g_stamps[sw_ + 16 + ((id) & 15)] = sacc_[(id) & 15];                                    \
+        }                                                                                           \
+        if (((id) == 0 || (id) == 9) && lane == 0 && w == 0) {                                                     \
+            const unsigned bid_ = blockIdx.x + gridDim.x * (blockIdx.z + gridDim.z * blockIdx.y);                   \
+            if (bid_ < 4096) g_blk[bid_ * 2 + ((id) == 9)] = __builtin_amdgcn_s_memrealtime();                       \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+extern "C" int nfisam_debug_read_blocks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 4096 * 2);
+}
+extern "C" int nfisam_debug_write_stamps(const unsigned long long* in) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), in, sizeof(unsigned long long) * 64 * 32);
+}
+extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 32);
+}
+#else
+#define STAMP(id) do { } while (0)
+#define STAMP_DECL
+#endif
+
+// Per-iteration loss sums live behind the gradient slabs in the kgrad workspace: a ring of LOSS_RING
+// iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
+// bookkeeping kernel that closes a chunk of iterations consumes and clears them.
+// staging rows per wave.  nsf_train_kernel: phase A stages one 16-row tile of gth at a time next to h2 (16 + H rows),
+// phase B ga2 | ga1 | h1 (3H rows); the atomics sink transposes (H+1) x PoP floats through the same rows.
+template <int K, int H>
+struct StgRows {
+    static constexpr int PoP = Layout<K, H>::PoP;
+    static constexpr int a = 16 + H, b = 3 * H, c = ((H + 1) * PoP + 65) / 66;   // bias rows come from the shared `ones` row
+    static constexpr int value = (a > b ? (a > c ? a : c) : (b > c ? b : c));
+    static constexpr int split = PoP + 16 + 3 * H;      // nsf_train2_kernel: gth | h2 | pad to +16 | ga2 | ga1 | h1
+};
+
+// Lanes of ONE wave exchange data through LDS: the hardware executes a wave's LDS operations in
+// order, but the compiler must be told that other lanes write between this lane's store and its
+// later load (otherwise it forwards the lane's own store).  Wavefront-scope release/acquire
+// fences + wave barrier: no instructions, only ordering.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// OCC = waves per SIMD the register allocation aims at (amdgpu_waves_per_eu): the throughput launches (many cliques
+// per launch, 4-wave blocks, scalar-path weights) want 4 resident waves per SIMD to cover the scalar-load and LDS
+// round trips of a wave's dependent instruction stream; the latency launches (one clique) run one or two waves per
+// SIMD and keep every intermediate in registers.
+template <int K, int H, bool MF, bool WL, int OCC>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, 8))) nsf_train_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    using WP = typename std::conditional<WL, const float*, cfloat*>::type;
+    constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;                       // 16-row output tiles of gth
+    constexpr int STG_ROWS = StgRows<K, H>::value;
+    static_assert(!MF || H == 8, "MFMA gradient path packs ga2|ga1 into one 16-row operand tile: H = 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
+    const float* x = batched ? cp->x : a.single.x;
+    float* kparams = batched ? cp->kparams : a.single.kparams;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int L = a.L;
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;      // 64-particle tiles this block sums over (L == 1 only)
+    const size_t gstride = (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    float* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
+    if (slab) G += (size_t)blockIdx.x * gstride;
+
+    const int p0 = blockIdx.x * TILE * T;
+    if (p0 >= n) return;
+    // state words as per-lane loads issued now and consumed only after the prologue's global loads have
+    // been issued too: one exposed memory round trip instead of two
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    // With L == 1 the dims of a tile never exchange data: blockIdx.z picks a group of W dims so that
+    // every wave runs exactly one unit (grid.z = ceil(D / W)).  L > 1 needs all dims in one block.
+    const int dim_lo = blockIdx.z * W;
+    const int dim_step = (gridDim.z > 1) ? D : W;       // one pass over [dim_lo + w] when grouped
+    if (dim_lo >= D) return;
+    const int DT = D * XS;
+    STAMP_DECL
+    STAMP(0);
+
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    // parameter range this block needs: everything, or (L == 1, grouped) only its own dims' blocks
+    const int dim_hi = (gridDim.z > 1) ? ((dim_lo + W < D) ? dim_lo + W : D) : D;
+    const int w_lo = (gridDim.z > 1 && dim_lo > 0) ? LY::off(dim_lo) : 0;
+    const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
+    float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only), 16-byte aligned rows
+    float* xs = smem + (WL ? a.wl_floats : 0);   // [L or T][D][XS] layer inputs / particle tiles, dimension-major
+    const int gt = a.g_tiles ? DT : 0;   // dL/dx tiles exist only when a layer input gradient is needed
+    float* g0 = xs + (L > T ? L : T) * DT;   // [D][XS]
+    float* g1 = g0 + gt;              // [D][XS]
+    float* ones = g1 + gt;            // [XS] constant 1 (bias column of the gradient GEMMs)
+    float* stg = ones + XS + w * (STG_ROWS * XS);   // wave-private staging tile (MF only)
+
+    // ---- prologue: ALL global loads first (particle tiles + parameter rows), one wait, then LDS ----
+    // The T tiles are 64*T*D contiguous floats; element e belongs to particle e / D, column e % D (the
+    // quotient by a reciprocal multiply: exact for e < 2^20).  Rows beyond n read as 0.
+    {
+        constexpr int XB = 16, WB = 4;               // loads in flight per lane: dwords of x, float4 of weights
+        const int nx = D * TILE * T;
+        const int rows = (n - p0) < TILE * T ? (n - p0) : TILE * T;
+        const int lim = rows * D;                                     // floats of these tiles that exist
+        const float* xt = x + (size_t)p0 * D;
+        const float invD = 1.0f / (float)D;
+        const int tot4 = WL ? ((w_hi - w_lo) >> 2) : 0;               // block offsets are multiples of 4 floats
+        const f32x4* wsrc = (const f32x4*)(kparams + w_lo);
+        f32x4* wdst = (f32x4*)wlds;
+        int e0 = threadIdx.x, f0 = threadIdx.x;
+        while (e0 < nx || f0 < tot4) {
+            float xv[XB];
+            f32x4 wv[WB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                xv[u] = (e < lim) ? xt[e] : 0.0f;
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform (first consumer of the state loads)
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nx) {
+                    int pq = (int)(((float)e + 0.5f) * invD);
+                    int k = e - pq * D;
+                    if (k < 0) { k += D; pq -= 1; }
+                    if (k >= D) { k -= D; pq += 1; }
+                    xs[(pq >> 6) * DT + k * XS + (pq & 63)] = xv[u];
+                }
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    if (f < tot4) wdst[f] = wv[u];
+                }
+            }
+            e0 += XB * (int)blockDim.x;
+            f0 += WB * (int)blockDim.x;
+        }
+    }
+    if (threadIdx.x < XS) ones[threadIdx.x] = 1.0f;
+    __syncthreads();
+
+    WP kp;
+    if constexpr (WL) kp = wlds - w_lo; else kp = (cfloat*)kparams;
+    STAMP(1);
+
+    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    for (int l = 0; l + 1 < L; ++l) {
+        WP lp = kp + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        float* xout = xs + (l + 1) * DT;
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
+            Spline<K> S;
+            float z, lad;
+            spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
+            xout[i * XS + lane] = z;
+        }
+        STAMP(10);
+        __syncthreads();
+        STAMP(11);
+    }
+
+    // ---- backward with recompute, last layer first ------------------------------------------
+    float lossv = 0.0f;
+    float* gcur = g0;
+    float* gprev = g1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const bool need_gx = (l > 0) || (a.gx != nullptr);
+        WP lp = kp + (size_t)l * Pk;
+        float* Gl = G + (size_t)l * Pk;
+        if (need_gx) {
+            for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
+            __syncthreads();
+        }
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            // gradient accumulators of this dim: they persist over the block's T tiles (the MFMAs add into them), so a
+            // block emits ONE gradient copy however many tiles it covers
+            f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float r0 = 0.0f;                           // i == 0: init_param gradient of lane < PoP
+            WP blk = lp + LY::off(i);
+            float* Gb = Gl + LY::off(i);
+            for (int tt = 0; tt < T; ++tt) {
+                if (p0 + tt * TILE >= n) break;
+                const float* xin = xs + (T > 1 ? tt : l) * DT;
+                const int gp = p0 + tt * TILE + lane;
+                const bool valid = gp < n;
+                float h1[H], h2[H], th[PoP], gth[PoP];
+                STAMP(2);
+                load_theta<K, H, WP>(lp, i, xin, XS, lane, h1, h2, th);
+                STAMP(3);
+                Spline<K> S;
+                float z, lad;
+                spline_eval<K, PoP, false>(xin[i * XS + lane], th, B, S, z, lad);
+                STAMP(4);
+                float gz, gl;
+                if (a.nll_mode) {
+                    gl = -1.0f;
+                    gz = last ? z : gcur[i * XS + lane];
+                    if (valid) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+                } else {
+                    gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                    gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS + lane];
+                }
+                if (!valid) { gz = 0.0f; gl = 0.0f; }
+                const float gxs = spline_backward<K, PoP>(S, B, gz, gl, gth);
+                if (need_gx) atomicAdd(&gprev[i * XS + lane], gxs);
+                STAMP(5);
+
+                if (i == 0) {   // init_param: plain sum over particles of gth
+                    constexpr int N0 = (PoP <= 32) ? 32 : 64;
+                    float v[N0];
+#pragma unroll
+                    for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+                    r0 += butterfly<N0>(v, lane);
+                    continue;
+                }
+                // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights)
+                float gh2[H], ga2[H], ga1[H];
+                {
+                    WP W2 = reload_ptr(blk + LY::oW2(i));
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        float wr[PoP];
+                        load_row<PoP>(W2 + k * PoP, wr);
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
+                        gh2[k] = acc;
+                        if (k & 1) row_group_fence<WP>();
+                    }
+#pragma unroll
+                    for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
+                    WP W1 = reload_ptr(blk + LY::oW1(i));
+#pragma unroll
+                    for (int k = 0; k < H; ++k) {
+                        float wr[H];
+                        load_row<H>(W1 + k * H, wr);
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
+                        ga1[k] = acc * (1.0f - h1[k] * h1[k]);
+                        if ((k & 7) == 7) row_group_fence<WP>();
+                    }
+                    if (need_gx) {
+                        WP W0 = blk;
+                        for (int k = 0; k < i; k += 4) {       // 4 rows in flight (rows >= i alias later weights: unused)
+                            float wq[4][H], acc[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) load_row<H>(W0 + (k + u) * H, wq[u]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc[u] = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < H; ++j) acc[u] = __builtin_fmaf(wq[u][j], ga1[j], acc[u]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (k + u < i) atomicAdd(&gprev[(k + u) * XS + lane], acc[u]);
+                        }
+                    }
+                }
+                STAMP(6);
+                if constexpr (MF) {
+                    // ======== phase A: dW2t | db2 = [h2, 1]^T (x) gth, one 16-row tile of gth per staging round ========
+                    // (staging rows 0..15: the gth tile, rows 16..16+H-1: h2 -- 24 rows instead of PoP + H = 40: the
+                    //  staging tile is what limits the resident waves per CU)
+                    {
+#pragma unroll
+                        for (int k = 0; k < H; ++k) stg[(16 + k) * XS + lane] = h2[k];
+                        const float* pa = stg + r16 * XS + kq;             // A: gth rows 16t + r16 (>= Po: unused outputs)
+                        // B: [h2 | 1]; the bias column and the unused columns beyond it read the constant-one row
+                        const float* pb = ((r16 < H) ? (stg + (16 + r16) * XS) : ones) + kq;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                            for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
+                            wave_lds_sync();
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) cacc[t] = mfma4(pa[s4], pb[s4], cacc[t]);
+                            wave_lds_sync();
+                        }
+                    }
+                    STAMP(7);
+                    // ======== phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1 ========
+                    {
+#pragma unroll
+                        for (int j = 0; j < H; ++j) {
+                            stg[j * XS + lane] = ga2[j];
+                            stg[(H + j) * XS + lane] = ga1[j];
+                            stg[(2 * H + j) * XS + lane] = h1[j];
+                        }
+                        wave_lds_sync();
+                        const float* pa = stg + r16 * XS + kq;                   // A: rows 0..7 ga2, 8..15 ga1
+                        const float* pb1 = ((r16 < H) ? (stg + (2 * H + r16) * XS) : ones) + kq;   // B1: [h1 | 1]
+                        float areg[TILE / 4];
+#pragma unroll
+                        for (int s4 = 0; s4 < TILE; s4 += 4) {
+                            areg[s4 / 4] = pa[s4];
+                            c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
+                        }
+                        // x tiles (16 input columns each); column i is the bias (ones row).  Tile 0 (columns 0..15) keeps
+                        // its accumulator over the block's tiles; further column tiles (D > 16) add into the block's
+                        // own gradient copy: the same lane owns the same entries for every tile, so a plain
+                        // read-add-write is race-free (slab) / a float atomic (shared copy).
+                        {
+                            const float* pb0 = ((r16 < i) ? (xin + r16 * XS) : ones) + kq;
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
+                        }
+                        for (int ct = 1; ct * 16 <= i; ++ct) {
+                            const int cab = ct * 16 + r16;
+                            const float* pb0 = ((cab < i) ? (xin + cab * XS) : ones) + kq;
+                            f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int s4 = 0; s4 < TILE; s4 += 4) cx = mfma4(areg[s4 / 4], pb0[s4], cx);
+                            if (kq >= 2 && cab <= i) {
+                                float* dst = &Gb[cab * H + 4 * (kq - 2)];
+                                if (slab && tt > 0) cx += *(const f32x4*)dst;
+                                gsink4(dst, cx, slab);
+                            }
+                        }
+                        wave_lds_sync();
+                    }
+                    STAMP(8);
+                } else {
+                    // ======== butterfly variant (round-1 v1): reduce-scatter over lanes with ds_bpermute (T == 1) ========
+                    {
+                        constexpr int TOT = (H + 1) * PoP;
+                        float* Gw = Gb + LY::oW2(i);
+#pragma unroll
+                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                            float v[64];
+#pragma unroll
+                            for (int t = 0; t < 64; ++t) {
+                                const int f = c * 64 + t;
+                                const int k = f / PoP, o = f % PoP;
+                                v[t] = (f < TOT) ? ((k < H) ? gth[o] * h2[k < H ? k : 0] : gth[o]) : 0.0f;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
+                        }
+                    }
+                    {
+                        constexpr int TOT = (H + 1) * H;
+                        float* Gw = Gb + LY::oW1(i);
+#pragma unroll
+                        for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                            float v[64];
+#pragma unroll
+                            for (int t = 0; t < 64; ++t) {
+                                const int f = c * 64 + t;
+                                const int k = f / H, j = f % H;
+                                v[t] = (f < TOT) ? ((k < H) ? ga2[j] * h1[k < H ? k : 0] : ga2[j]) : 0.0f;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (c * 64 + lane < TOT) gsink(&Gw[c * 64 + lane], r, slab);
+                        }
+                    }
+                    {
+                        float* Gw = Gb;
+                        constexpr int RPC = 64 / H;
+                        const int tot = (i + 1) * H;
+                        for (int kc = 0; kc <= i; kc += RPC) {
+                            float v[64];
+#pragma unroll
+                            for (int r_ = 0; r_ < RPC; ++r_) {
+                                const int k = kc + r_;
+                                const float xk = (k < i) ? xin[k * XS + lane] : ((k == i) ? 1.0f : 0.0f);
+#pragma unroll
+                                for (int j = 0; j < H; ++j) v[r_ * H + j] = ga1[j] * xk;
+                            }
+                            const float r = butterfly<64>(v, lane);
+                            if (kc * H + lane < tot) gsink(&Gw[kc * H + lane], r, slab);
+                        }
+                    }
+                }
+            }
+            // ---- this dim's gradient copy: every entry written once (slab) or added once (atomics) per block ----
+            if (i == 0) {
+                if (lane < PoP) gsink(&Gl[lane], r0, slab);
+                continue;
+            }
+            if constexpr (MF) {
+                // C layout of the MFMAs: col = lane&15 (= input column c), rows 4*(lane>>4)+r (= four consecutive outputs)
+                float* Gw = Gb + LY::oW2(i);
+                if (slab) {
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+                    }
+                } else {
+                    // atomics: transpose through LDS to the flat order (64 consecutive addresses per wave instruction)
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) {   // scalar stores: same type as the float re-reads below
+                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                            }
+                    }
+                    wave_lds_sync();
+                    constexpr int TOT = (H + 1) * PoP;
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        const int f = c * 64 + lane;
+                        if (f < TOT) atomicAdd(&Gw[f], stg[f]);
+                    }
+                    wave_lds_sync();
+                }
+                // c1 rows 0..7 (kq < 2) are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
+                if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+                // c0 rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = c*H + j, input column c = r16
+                if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
+            }
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        float* tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input (T == 1)
+        for (int e = threadIdx.x; e < D * TILE; e += blockDim.x) {
+            const int p = e / D, k = e - p * D;
+            const int q = p0 + p;
+            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * XS + p];
+        }
+    }
+    STAMP(9);
+    if (a.nll_mode) {
+        const float tot = wave_sum(lossv);
+        if (lane == 0) {
+            float* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                   ((blockIdx.x * 7 + blockIdx.z * 13 + w) & (LOSS_SLOTS - 1))]
+                                         : a.loss_sum;
+            if (dst != nullptr) atomicAdd(dst, tot);
+        }
+    }
+}
+
+// =============================================================================================
+// throughput training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, blocks are dim-major.
+//
+// Why: in nsf_train_kernel the four waves of a block run four different dims and every wave walks through all of
+// its dims, so a CU's resident waves read 12-16 different weight sets through the 16 KB scalar data cache: 58 % of
+// the scalar loads miss (rocprofv3 SQC_DCACHE_HITS / _MISSES, 64-clique batch) and every miss is an exposed
+// ~500-cycle round trip in front of an `s_waitcnt lgkmcnt(0)`.  Here grid = (tile groups, cliques, dims): the W
+// waves of a block run the SAME (clique, dim) on different particle tiles, each wave sweeps T tiles with that one
+// weight set and keeps the weight-gradient MFMA accumulators across them, so a CU holds 3-4 weight sets (< 8 KB),
+// emits one gradient copy per T tiles, and needs no workgroup barrier at all (every LDS byte is wave-private).
+// LDS per wave: the particle tile [D][XS] + a 16-row staging tile (the [h|1] operands of the gradient GEMMs are
+// parked in registers while the staging rows are re-used for the other operand): 8.4 KB at D = 15, so the
+// register allocation (OCC) decides the occupancy, not LDS.
+// =============================================================================================
+template <int K, int H, int OCC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) nsf_train1_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;
+    constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
+    static_assert(H == 8, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
+    // atomics, which count against both memory counters)
+    const nfisam_clique* cp = a.cliques != nullptr ? (a.cliques + blockIdx.y) : nullptr;
+    const gfloat* x = (const gfloat*)(cp ? cp->x : a.single.x);
+    const float* kparams = cp ? cp->kparams : a.single.kparams;
+    gfloat* G = (gfloat*)(cp ? cp->kgrad : a.single.kgrad);
+    nfisam_train_state* st = cp ? cp->state : a.single.state;
+    const int n = cp ? cp->n : a.single.n;
+    const int D = cp ? cp->D : a.single.D;
+    const int i = blockIdx.z;                                 // this block's dim
+    if (i >= D) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+    const int slot = blockIdx.x * W + w;                      // this wave's gradient copy
+    const int p0 = slot * TILE * T;
+    if (p0 >= n) return;
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const size_t gstride = (size_t)LY::count(D);
+    gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
+    if (slab) G += (size_t)slot * gstride;
+    const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
+    float* xt = smem + (size_t)w * ((xrows + 16) * XS);       // [xrows][XS] particle tile, dimension-major
+    float* stg = xt + xrows * XS;                             // [16][XS] staging rows
+    const int r16 = lane & 15, kq = lane >> 4;
+    cfloat* lp = (cfloat*)kparams;
+    cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
+    gfloat* Gb = G + LY::off(i > 0 ? i : 1);
+
+    f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float r0 = 0.0f, lossv = 0.0f;
+
+    // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
+    // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
+    // arithmetic, no column the dim does not need.  Rows beyond n re-read row n-1 (masked out of loss and gradient).
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto load_tile = [&](int pt) {
+        const int pr = (pt + lane < n) ? pt + lane : n - 1;
+        const gfloat* row = x + (size_t)pr * D;
+        for (int c0 = 0; c0 <= i; c0 += 16) {
+            float xr[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = c0 + 4 * q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k <= i) {                                 // wave-uniform
+                    if (k + 3 < D) {
+                        const f32x4u u = *(const __attribute__((address_space(1))) f32x4u*)(row + k);
+                        v = f32x4{u.x, u.y, u.z, u.w};
+                    } else {
+                        v.x = row[k];
+                        if (k + 1 < D) v.y = row[k + 1];
+                        if (k + 2 < D) v.z = row[k + 2];
+                    }
+                }
+                xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+            }
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // wave-uniform; first consumer of the state loads
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+        }
+        return true;
+    };
+
+    for (int tt = 0; tt < T; ++tt) {
+        const int pt = p0 + tt * TILE;
+        if (pt >= n) break;
+        if (!load_tile(pt)) return;
+        wave_lds_sync();
+        const bool valid = pt + lane < n;
+        float h1[H], h2[H], th[PoP], gth[PoP];
+        load_theta<K, H, cfloat*>(lp, i, xt, XS, lane, h1, h2, th);
+        Spline<K> S;
+        float z, lad;
+        spline_eval<K, PoP, false>(xt[i * XS + lane], th, B, S, z, lad);
+        if (valid) lossv += 0.5f * z * z - lad;
+        const float gxs = spline_backward<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
+        (void)gxs;
+        if (i == 0) {   // init_param: plain sum over particles of gth
+            constexpr int N0 = (PoP <= 32) ? 32 : 64;
+            float v[N0];
+#pragma unroll
+            for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+            r0 += butterfly<N0>(v, lane);
+            wave_lds_sync();                                    // the tile is overwritten by the next iteration's loads
+            continue;
+        }
+        // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights) ----
+        float ga2[H], ga1[H];
+        {
+            float gh2[H];
+            cfloat* W2 = reload_ptr(blk + LY::oW2(i));
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                float wr[PoP];
+                load_row<PoP>(W2 + k * PoP, wr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
+                gh2[k] = acc;
+                if (k & 1) row_group_fence<cfloat*>();
+            }
+#pragma unroll
+            for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
+            cfloat* W1 = reload_ptr(blk + LY::oW1(i));
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                float wr[H];
+                load_row<H>(W1 + k * H, wr);
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
+                ga1[k] = acc * (1.0f - h1[k] * h1[k]);
+                if ((k & 7) == 7) row_group_fence<cfloat*>();
+            }
+        }
+        // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
+        //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
+        const float* pa = stg + r16 * XS + kq;
+        const float* pah = stg + (r16 < H ? r16 : 0) * XS + kq;     // [h | 1] operand: every lane loads, lanes >= H take 1
+        float breg[NS];
+        {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth
+#pragma unroll
+            for (int k = 0; k < H; ++k) stg[k * XS + lane] = h2[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) cacc[t] = mfma4(pa[4 * s4], breg[s4], cacc[t]);
+                wave_lds_sync();
+            }
+        }
+        {   // phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
+#pragma unroll
+            for (int j = 0; j < H; ++j) stg[j * XS + lane] = h1[j];
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                stg[j * XS + lane] = ga2[j];
+                stg[(H + j) * XS + lane] = ga1[j];
+            }
+            wave_lds_sync();
+            float areg[NS];
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) {
+                areg[s4] = pa[4 * s4];
+                c1 = mfma4(areg[s4], breg[s4], c1);
+            }
+            {   // input columns 0..15 (column i = bias)
+                const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; c0 = mfma4(areg[s4], (r16 < i) ? v : 1.0f, c0); }
+            }
+            for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
+                const int cab = ct * 16 + r16;
+                const float* pb0 = xt + (cab < i ? cab : 0) * XS + kq;
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; cx = mfma4(areg[s4], (cab < i) ? v : 1.0f, cx); }
+                if (kq >= 2 && cab <= i) {
+                    gfloat* dst = &Gb[cab * H + 4 * (kq - 2)];
+                    if (slab && tt > 0) cx += *(const gvf4_t*)dst;
+                    gsink4(dst, cx, slab);
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+
+    // ---- the wave's gradient copy of this dim ----
+    if (i == 0) {
+        if (lane < PoP) gsink(&G[lane], r0, slab);
+    } else {
+        gfloat* Gw = Gb + LY::oW2(i);
+        if (slab) {
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+            }
+        } else {
+            // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
+            constexpr int TOT = (H + 1) * PoP;
+            static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) {
+                        float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                        d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                    }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                const int f = c * 64 + lane;
+                if (f < TOT) gsink(&Gw[f], stg[f], false);
+            }
+        }
+        if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+        if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
+    }
+    const float tot = wave_sum(lossv);
+    if (lane == 0) {
+        gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
+                                      : (gfloat*)a.loss_sum;
+        if (dst != nullptr) gsink(dst, tot, false);
+    }
+}
+
+// =============================================================================================
+// training / VJP kernel, two lanes per particle (nsf_split.h): a wave covers 32 particles, so the same
+// clique spreads over twice as many waves / CUs and every unit issues about half the instructions.
+// Same arguments, LDS plan and gradient sinks as nsf_train_kernel, with TILE2 / XS2 in place of TILE / XS.
+// =============================================================================================
+template <int K, int H>
+__device__ __forceinline__ void load_theta2(const float* lp, int i, const float* xin, int p, int hf,
+                                            float (&h1m)[H / 2], float (&h1o)[H / 2], float (&h2m)[H / 2],
+                                            float (&h2o)[H / 2], float (&th)[hp_of(K)]) {
+    using LY = Layout<K, H>;
+    if (i == 0) {
+        load_row_used<LY::HP, K + LY::ND0>(lp + LY::HP * hf, th);
+    } else {
+        const float* blk = lp + LY::off(i);
+        cond_hidden2<K, H>(blk, i, xin, p, hf, h1m, h1o, h2m, h2o);
+        cond_theta2<K, H>(blk, i, hf, h2m, h2o, th);
+    }
+}
+
+template <int K, int H, bool WL>
+__global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP, HP = LY::HP, HH = H / 2;
+    constexpr int NT = (PoP + 15) / 16;                       // 16-row output tiles of gth
+    constexpr int UO = K + LY::ND0;                           // used outputs per half (the rest is padding)
+    static_assert(H == 8, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
+    const float* x = batched ? cp->x : a.single.x;
+    float* kparams = batched ? cp->kparams : a.single.kparams;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int L = a.L;
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const size_t gstride = (size_t)L * (size_t)(a.layer_stride > 0 ? a.layer_stride : LY::count(D));
+    float* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
+    if (slab) G += (size_t)blockIdx.x * gstride;
+
+    const int p0 = blockIdx.x * TILE2;
+    if (p0 >= n) return;
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int lane = threadIdx.x & 63;
+    const int hf = lane & 1, p = lane >> 1;               // half (axis) and particle of this lane
+    const int mo = HH * hf, oo = HH - mo;                 // my / the partner's hidden-unit offset
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int dim_lo = blockIdx.z * W;
+    const int dim_step = (gridDim.z > 1) ? D : W;
+    if (dim_lo >= D) return;
+    const int gp = p0 + p;
+    const bool valid = gp < n;
+    const int DT = D * XS2;
+    STAMP_DECL
+    STAMP(0);
+
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    const int dim_hi = (gridDim.z > 1) ? ((dim_lo + W < D) ? dim_lo + W : D) : D;
+    const int w_lo = (gridDim.z > 1 && dim_lo > 0) ? LY::off(dim_lo) : 0;
+    const int w_hi = (gridDim.z > 1) ? LY::off(dim_hi) : L * Pk;
+    float* wlds = smem;               // [w_hi - w_lo] parameter copy (WL only)
+    float* xs = smem + (WL ? a.wl_floats : 0);   // [L][D][XS2] layer inputs, dimension-major
+    const int gt = a.g_tiles ? DT : 0;   // dL/dx tiles exist only when a layer input gradient is needed
+    float* g0 = xs + L * DT;          // [D][XS2]
+    float* g1 = g0 + gt;              // [D][XS2]
+    float* ones = g1 + gt;            // [XS2]
+    float* stg = ones + XS2 + w * (StgRows<K, H>::split * XS2);   // wave-private staging tile
+
+    // ---- prologue: all global loads first (particle tile + parameter rows), one wait, then LDS ----
+    {
+        constexpr int XB = 8, WB = 4;
+        const int nx = D * TILE2;
+        const int lim = ((n - p0) < TILE2 ? (n - p0) : TILE2) * D;
+        const float* xt = x + (size_t)p0 * D;
+        const float invD = 1.0f / (float)D;
+        const int tot4 = WL ? ((w_hi - w_lo) >> 2) : 0;
+        const f32x4* wsrc = (const f32x4*)(kparams + w_lo);
+        f32x4* wdst = (f32x4*)wlds;
+        int e0 = threadIdx.x, f0 = threadIdx.x;
+        while (e0 < nx || f0 < tot4) {
+            float xv[XB];
+            f32x4 wv[WB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                xv[u] = (e < lim) ? xt[e] : 0.0f;
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    wv[u] = (f < tot4) ? wsrc[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * (int)blockDim.x;
+                if (e < nx) {
+                    int pq = (int)(((float)e + 0.5f) * invD);
+                    int k = e - pq * D;
+                    if (k < 0) { k += D; pq -= 1; }
+                    if (k >= D) { k -= D; pq += 1; }
+                    xs[k * XS2 + pq] = xv[u];
+                }
+            }
+            if constexpr (WL) {
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int f = f0 + u * (int)blockDim.x;
+                    if (f < tot4) wdst[f] = wv[u];
+                }
+            }
+            e0 += XB * (int)blockDim.x;
+            f0 += WB * (int)blockDim.x;
+        }
+    }
+    if (threadIdx.x < XS2) ones[threadIdx.x] = 1.0f;
+    __syncthreads();
+
+    const float* kp;
+    if constexpr (WL) kp = wlds - w_lo; else kp = kparams;
+    STAMP(1);
+
+    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    for (int l = 0; l + 1 < L; ++l) {
+        const float* lp = kp + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        float* xout = xs + (l + 1) * DT;
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP];
+            load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
+            Spline2<K> S;
+            float z, lad;
+            spline_eval2<K, false>(xin[i * XS2 + p], th, hf, B, S, z, lad);
+            if (hf == 0) xout[i * XS2 + p] = z;
+        }
+        STAMP(10);
+        __syncthreads();
+        STAMP(11);
+    }
+
+    // ---- backward with recompute, last layer first ------------------------------------------
+    float lossv = 0.0f;
+    float* gcur = g0;
+    float* gprev = g1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const bool need_gx = (l > 0) || (a.gx != nullptr);
+        const float* lp = kp + (size_t)l * Pk;
+        float* Gl = G + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        if (need_gx) {
+            for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
+            __syncthreads();
+        }
+        for (int i = dim_lo + w; i < D; i += dim_step) {
+            float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP], gth[HP];
+            STAMP(2);
+            load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
+            STAMP(3);
+            Spline2<K> S;
+            float z, lad;
+            spline_eval2<K, false>(xin[i * XS2 + p], th, hf, B, S, z, lad);
+            STAMP(4);
+            float gz, gl;
+            if (a.nll_mode) {
+                gl = -1.0f;
+                gz = last ? z : gcur[i * XS2 + p];
+                if (valid && hf == 0) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+            } else {
+                gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                gz = last ? (valid ? a.gz[(size_t)gp * D + i] : 0.0f) : gcur[i * XS2 + p];
+            }
+            if (!valid) { gz = 0.0f; gl = 0.0f; }
+            const float gxs = spline_backward2<K>(S, hf, B, gz, gl, gth);
+            if (need_gx && hf == 0) atomicAdd(&gprev[i * XS2 + p], gxs);
+            STAMP(5);
+
+            if (i == 0) {   // init_param: plain sum over particles of gth
+                constexpr int N0 = (HP <= 8) ? 8 : ((HP <= 16) ? 16 : 32);
+                float v[N0];
+#pragma unroll
+                for (int t = 0; t < N0; ++t) v[t] = (t < HP) ? gth[t] : 0.0f;
+                const float r = butterfly2<N0>(v, p);
+                if (p < HP) gsink(&Gl[HP * hf + p], r, slab);
+                continue;
+            }
+            const float* blk = lp + LY::off(i);
+            float* Gb = Gl + LY::off(i);
+            // ---- per-particle back-propagation through the conditioner (VALU, partial sums + DPP) ----
+            float ga2m[HH], ga1m[HH];
+            {
+                const float* W2 = blk + LY::oW2(i) + HP * hf;
+                float pm[HH], po[HH];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    float wr[HP], wo[HP];
+                    load_row_used<HP, UO>(W2 + (mo + kk) * PoP, wr);
+                    load_row_used<HP, UO>(W2 + (oo + kk) * PoP, wo);
+                    float am = 0.0f, ao = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < UO; ++o) {
+                        am = __builtin_fmaf(wr[o], gth[o], am);
+                        ao = __builtin_fmaf(wo[o], gth[o], ao);
+                    }
+                    pm[kk] = am; po[kk] = ao;
+                }
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    const float gh2 = pm[kk] + pswap(po[kk]);
+                    ga2m[kk] = gh2 * (1.0f - h2m[kk] * h2m[kk]);
+                }
+                const float* W1 = blk + LY::oW1(i) + mo;
+                float qm[HH], qo[HH];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    float wr[HH], wo[HH];
+                    load_row<HH>(W1 + (mo + kk) * H, wr);
+                    load_row<HH>(W1 + (oo + kk) * H, wo);
+                    float am = 0.0f, ao = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < HH; ++jj) {
+                        am = __builtin_fmaf(wr[jj], ga2m[jj], am);
+                        ao = __builtin_fmaf(wo[jj], ga2m[jj], ao);
+                    }
+                    qm[kk] = am; qo[kk] = ao;
+                }
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    const float gh1 = qm[kk] + pswap(qo[kk]);
+                    ga1m[kk] = gh1 * (1.0f - h1m[kk] * h1m[kk]);
+                }
+                if (need_gx) {
+                    const float* W0 = blk + mo;
+                    for (int k = 0; k < i; k += 2) {       // the pair splits two input columns (row i aliases b0: unused)
+                        float w0[HH], w1[HH];
+                        load_row<HH>(W0 + k * H, w0);
+                        load_row<HH>(W0 + (k + 1) * H, w1);
+                        float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < HH; ++jj) {
+                            r0 = __builtin_fmaf(w0[jj], ga1m[jj], r0);
+                            r1 = __builtin_fmaf(w1[jj], ga1m[jj], r1);
+                        }
+                        const float t0 = r0 + pswap(r0), t1 = r1 + pswap(r1);
+                        const int kk = k + hf;
+                        if (kk < i) atomicAdd(&gprev[kk * XS2 + p], hf ? t1 : t0);
+                    }
+                }
+            }
+            STAMP(6);
+            // ======== weight gradients on the matrix cores: one staging round for all three GEMMs ========
+            //   dW2t | db2 = [h2, 1]^T (x) gth ;  dW1t | db1 = [h1, 1]^T (x) ga2 ;  dW0t | db0 = [x, 1]^T (x) ga1
+            {
+                constexpr int R2 = PoP + 16;                   // first row of the ga2 | ga1 | h1 group
+#pragma unroll
+                for (int o = 0; o < HP; ++o) stg[(HP * hf + o) * XS2 + p] = gth[o];
+#pragma unroll
+                for (int kk = 0; kk < HH; ++kk) {
+                    stg[(PoP + mo + kk) * XS2 + p] = h2m[kk];
+                    stg[(R2 + mo + kk) * XS2 + p] = ga2m[kk];
+                    stg[(R2 + H + mo + kk) * XS2 + p] = ga1m[kk];
+                    stg[(R2 + 2 * H + mo + kk) * XS2 + p] = h1m[kk];
+                }
+                wave_lds_sync();
+                // operand rows: lane&15 = feature, lane>>4 = particle within the k-group of 4; the bias column
+                // (and the unused columns beyond it) read the constant-one row
+                const float* pa = stg + r16 * XS2 + kq;                                    // gth rows 16t + r16
+                const float* pb = ((r16 < H) ? (stg + (PoP + r16) * XS2) : ones) + kq;     // [h2 | 1]
+                const float* pa2 = stg + (R2 + r16) * XS2 + kq;                            // rows 0..7 ga2, 8..15 ga1
+                const float* pb1 = ((r16 < H) ? (stg + (R2 + 2 * H + r16) * XS2) : ones) + kq;   // [h1 | 1]
+                f32x4 cacc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
+                float areg[TILE2 / 4];
+#pragma unroll
+                for (int s4 = 0; s4 < TILE2; s4 += 4) {
+                    const float b = pb[s4];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) cacc[t] = mfma4(pa[t * 16 * XS2 + s4], b, cacc[t]);
+                    areg[s4 / 4] = pa2[s4];
+                    c1 = mfma4(areg[s4 / 4], pb1[s4], c1);
+                }
+                STAMP(7);
+                // C layout: col = lane&15 (= c), rows 4*(lane>>4)+r: four consecutive outputs per lane
+                float* Gw2 = Gb + LY::oW2(i);
+                if (slab) {
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw2[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+                    }
+                } else {
+                    // atomics: transpose through LDS to the flat order so that a wave's 64 atomics hit 256
+                    // consecutive bytes (scattered float atomics serialise in the memory pipeline)
+                    wave_lds_sync();
+                    if (r16 <= H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) {
+                                float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                                d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                            }
+                    }
+                    wave_lds_sync();
+                    constexpr int TOT = (H + 1) * PoP;
+#pragma unroll
+                    for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                        const int f = c * 64 + lane;
+                        if (f < TOT) atomicAdd(&Gw2[f], stg[f]);
+                    }
+                }
+                // rows 0..7 (kq < 2) of c1 are ga2[j], j = 4*kq + r ; flat f = c*H + j, c <= H
+                if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
+                // x tiles (16 input columns each); column i is the bias (ones row)
+                float* Gw0 = Gb;
+                for (int ct = 0; ct * 16 <= i; ++ct) {
+                    const int cab = ct * 16 + r16;
+                    const float* pb0 = ((cab < i) ? (xin + cab * XS2) : ones) + kq;
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < TILE2; s4 += 4) c0 = mfma4(areg[s4 / 4], pb0[s4], c0);
+                    // rows 8..15 (kq >= 2) are ga1[j], j = 4*(kq-2)+r ; flat f = cab*H + j
+                    if (kq >= 2 && cab <= i) gsink4(&Gw0[cab * H + 4 * (kq - 2)], c0, slab);
+                }
+                wave_lds_sync();
+            }
+            STAMP(8);
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        float* tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
+        for (int e = threadIdx.x; e < D * TILE2; e += blockDim.x) {
+            const int pp = e / D, k = e - pp * D;
+            const int q = p0 + pp;
+            if (q < n) a.gx[(size_t)q * D + k] = gcur[k * XS2 + pp];
+        }
+    }
+    STAMP(9);
+    if (a.nll_mode) {
+        const float tot = wave_sum(lossv);
+        if (lane == 0) {
+            float* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                   ((blockIdx.x * 7 + blockIdx.z * 13 + w) & (LOSS_SLOTS - 1))]
+                                         : a.loss_sum;
+            if (dst != nullptr) atomicAdd(dst, tot);
+        }
+    }
+}
+
+// =============================================================================================
+// inference: forward (density direction)
+// =============================================================================================
+template <int K, int H>
+__global__ void __launch_bounds__(512) nsf_forward_kernel(const float* __restrict__ x, const float* kparams,
+                                                           int n, int D, float B, int L, int layer_stride,
+                                                           float* __restrict__ z, float* __restrict__ logdet,
+                                                           float* __restrict__ logprob) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int p0 = blockIdx.x * TILE;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int DT = D * TILE;
+    float* xa = smem;            // [D][TILE]
+    float* xb = xa + DT;         // [D][TILE]
+    float* ldacc = xb + DT;      // [TILE]
+    for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+        const int p = e / D, k = e - p * D;
+        const int q = p0 + p;
+        xa[k * TILE + p] = (q < n) ? x[(size_t)q * D + k] : 0.0f;
+    }
+    if (threadIdx.x < TILE) ldacc[threadIdx.x] = 0.0f;
+    __syncthreads();
+    cfloat* kp = (cfloat*)kparams;
+    const int Pk = layer_stride > 0 ? layer_stride : LY::count(D);
+    float* xin = xa;
+    float* xout = xb;
+    for (int l = 0; l < L; ++l) {
+        cfloat* lp = kp + (size_t)l * Pk;
+        float ld = 0.0f;
+        for (int i = w; i < D; i += W) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H, cfloat*>(lp, i, xin, TILE, lane, h1, h2, th);
+            Spline<K> S;
+            float zz, lad;
+            spline_eval<K, PoP, false>(xin[i * TILE + lane], th, B, S, zz, lad);
+            xout[i * TILE + lane] = zz;
+            ld += lad;
+        }
+        atomicAdd(&ldacc[lane], ld);
+        __syncthreads();
+        float* tmp = xin; xin = xout; xout = tmp;
+    }
+    // xin holds z
+    if (z != nullptr) {
+        for (int e = threadIdx.x; e < DT; e += blockDim.x) {
+            const int p = e / D, k = e - p * D;
+            const int q = p0 + p;
+            if (q < n) z[(size_t)q * D + k] = xin[k * TILE + p];
+        }
+    }
+    if (threadIdx.x < TILE && p0 + (int)threadIdx.x < n) {
+        const int q = p0 + threadIdx.x;
+        const float ld = ldacc[threadIdx.x];
+        if (logdet != nullptr) logdet[q] = ld;
+        if (logprob != nullptr) {
+            float zz = 0.0f;
+            for (int k = 0; k < D; ++k) { const float t = xin[k * TILE + threadIdx.x]; zz += t * t; }
+            logprob[q] = -0.5f * zz - 0.5f * (float)D * 1.8378770664093453f + ld;
+        }
+    }
+}
+
+// =============================================================================================
+// inference: inverse / conditional sampling (one wave per 64 particles, dims sequential)
+// =============================================================================================
+__device__ __forceinline__ float wrap_pi(float t) {   // src/utils/Functions.py:20-21 (python % semantics)
+    const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+    float r = fmodf(t + pi, two_pi);
+    if (r < 0.0f) r += two_pi;
+    return r - pi;
+}
+
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_inverse_kernel(const float* __restrict__ zin, const float* __restrict__ x_sep,
+                                                         const float* kparams, int n, int D, int Ds, float B, int L,
+                                                         int layer_stride, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                         const uint8_t* __restrict__ circ,
+                                                         float* __restrict__ x_out, float* __restrict__ logdet) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int p0 = blockIdx.x * TILE;
+    const int F = D - Ds;
+    float* xs = smem;                 // [D][TILE]  row being reconstructed
+    float* zs = xs + D * TILE;        // [F][TILE]  latent of the current layer
+    // L > 1 with given columns: ych[l] = the given columns as layer l sees them (pushed through the marginal flow of
+    // layers 0..l-1; the flow is autoregressive, so they depend on the given columns only).  The reference conditions
+    // every layer on the raw columns (src/slam/NFiSAM.py:151-152), which inverts no composition.
+    const bool chain = (L > 1 && Ds > 0);
+    float* ych = chain ? (zs + F * TILE) : xs;      // [L][Ds][TILE]
+    // given columns: normalise (NFiSAM.py:96-106)
+    for (int e = lane; e < Ds * TILE; e += TILE) {
+        const int p = e / Ds, k = e - p * Ds;
+        const int q = p0 + p;
+        float v = (q < n) ? x_sep[(size_t)q * Ds + k] : 0.0f;
+        if (mean != nullptr) {
+            const float d = v - mean[k];
+            v = ((circ != nullptr && circ[k]) ? wrap_pi(d) : d) / stdv[k];
+        }
+        ych[k * TILE + p] = v;
+    }
+    for (int e = lane; e < F * TILE; e += TILE) {
+        const int p = e / F, k = e - p * F;
+        const int q = p0 + p;
+        zs[k * TILE + p] = (q < n) ? zin[(size_t)q * F + k] : 0.0f;
+    }
+    __syncthreads();
+    cfloat* kp = (cfloat*)kparams;
+    const int Pk = layer_stride > 0 ? layer_stride : LY::count(D);
+    if (chain) {
+        for (int l = 0; l + 1 < L; ++l) {
+            cfloat* lp = kp + (size_t)l * Pk;
+            const float* yin = ych + (size_t)l * Ds * TILE;
+            float* yout = ych + (size_t)(l + 1) * Ds * TILE;
+            for (int i = 0; i < Ds; ++i) {
+                float h1[H], h2[H], th[PoP];
+                load_theta<K, H, cfloat*>(lp, i, yin, TILE, lane, h1, h2, th);
+                Spline<K> S;
+                float yi, lad;
+                spline_eval<K, PoP, false>(yin[i * TILE + lane], th, B, S, yi, lad);
+                yout[i * TILE + lane] = yi;
+            }
+        }
+    }
+    float ld = 0.0f;
+    for (int l = L - 1; l >= 0; --l) {
+        cfloat* lp = kp + (size_t)l * Pk;
+        if (chain) for (int i = 0; i < Ds; ++i) xs[i * TILE + lane] = ych[((size_t)l * Ds + i) * TILE + lane];
+        for (int i = Ds; i < D; ++i) {
+            float h1[H], h2[H], th[PoP];
+            load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
+            Spline<K> S;
+            float xi, lad;
+            spline_eval<K, PoP, true>(zs[(i - Ds) * TILE + lane], th, B, S, xi, lad);
+            xs[i * TILE + lane] = xi;     // only this lane reads its own column entries
+            ld += lad;
+        }
+        if (l > 0) for (int i = Ds; i < D; ++i) zs[(i - Ds) * TILE + lane] = xs[i * TILE + lane];
+    }
+    __syncthreads();
+    for (int e = lane; e < F * TILE; e += TILE) {
+        const int p = e / F, k = e - p * F;
+        const int q = p0 + p;
+        if (q < n) {
+            float v = xs[(Ds + k) * TILE + p];
+            if (mean != nullptr) {
+                v = v * stdv[Ds + k] + mean[Ds + k];
+                if (circ != nullptr && circ[Ds + k]) v = wrap_pi(v);
+            }
+            x_out[(size_t)q * F + k] = v;
+        }
+    }
+    if (logdet != nullptr && p0 + lane < n) logdet[p0 + lane] = ld;
+}
+
+// =============================================================================================
+// posterior traversal of a whole Bayes tree in ONE launch (SURVEY.md §8 f-1;
+// reference: FactorGraphSolver.sample_posterior, src/slam/FactorGraphSolver.py:497-550, which
+// makes one host-synchronised conditional-sampling call per clique).
+// Sample j of a child clique is conditioned on sample j of its parent only, so a wave of 64
+// samples can walk all cliques root -> leaves on its own: no inter-block synchronisation, samples
+// never leave the device.  St / Zt are COLUMN-major [total_dim][n] (one variable column = one
+// coalesced run over particles); St receives the un-normalised posterior samples.
+// =============================================================================================
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_posterior_walk_kernel(const nfisam_post_clique* __restrict__ table,
+                                                                int n_cliques, const int32_t* __restrict__ cols,
+                                                                const float* __restrict__ obs, float B, int L, int n,
+                                                                int dmax, const float* __restrict__ Zt, float* __restrict__ St) {
+    using LY = Layout<K, H>;
+    constexpr int PoP = LY::PoP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.x * TILE + lane;
+    const bool valid = p < n;
+    const size_t pp = valid ? (size_t)p : 0;
+    float* xs = smem;                       // [Dmax][TILE]
+    float* ych = xs + (size_t)dmax * TILE;  // [L][Dmax][TILE] given columns per layer (L > 1 only, see nsf_inverse_kernel)
+    int zoff = 0;                           // latent rows are consumed in walk order
+    for (int c = 0; c < n_cliques; ++c) {
+        const nfisam_post_clique q = table[c];
+        const int n_obs = q.n_obs, Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const float* mean = q.mean;
+        const float* stdv = q.std;
+        const uint8_t* circ = q.circular;
+        const bool chain = (L > 1 && Ds > 0);
+        float* y0 = chain ? ych : xs;
+        // given columns: true observations (same for every sample) then the separator samples
+        for (int k = 0; k < Ds; ++k) {
+            float v = (k < n_obs) ? obs[q.obs_off + k] : St[(size_t)cols[q.sep_off + (k - n_obs)] * n + pp];
+            const float d = v - mean[k];
+            y0[k * TILE + lane] = (circ[k] ? wrap_pi(d) : d) / stdv[k];
+        }
+        cfloat* kp = (cfloat*)q.kparams;
+        const int Pk = LY::count(q.D_model);
+        if (chain) {
+            for (int l = 0; l + 1 < L; ++l) {
+                cfloat* lp = kp + (size_t)l * Pk;
+                const float* yin = ych + (size_t)l * dmax * TILE;
+                float* yout = ych + (size_t)(l + 1) * dmax * TILE;
+                for (int i = 0; i < Ds; ++i) {
+                    float h1[H], h2[H], th[PoP];
+                    load_theta<K, H, cfloat*>(lp, i, yin, TILE, lane, h1, h2, th);
+                    Spline<K> S;
+                    float yi, lad;
+                    spline_eval<K, PoP, false>(yin[i * TILE + lane], th, B, S, yi, lad);
+                    yout[i * TILE + lane] = yi;
+                }
+            }
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            cfloat* lp = kp + (size_t)l * Pk;
+            if (chain) for (int i = 0; i < Ds; ++i) xs[i * TILE + lane] = ych[((size_t)l * dmax + i) * TILE + lane];
+            for (int i = Ds; i < D; ++i) {
+                float h1[H], h2[H], th[PoP];
+                load_theta<K, H, cfloat*>(lp, i, xs, TILE, lane, h1, h2, th);
+                // layer L-1 consumes the latent draw; lower layers consume the previous layer's output
+                const float zin = (l == L - 1) ? Zt[(size_t)(zoff + (i - Ds)) * n + pp] : xs[i * TILE + lane];
+                Spline<K> S;
+                float xi, lad;
+                spline_eval<K, PoP, true>(zin, th, B, S, xi, lad);
+                xs[i * TILE + lane] = xi;
+            }
+        }
+        for (int i = Ds; i < D; ++i) {
+            float v = xs[i * TILE + lane] * stdv[i] + mean[i];
+            if (circ[i]) v = wrap_pi(v);
+            if (valid) St[(size_t)cols[q.front_off + (i - Ds)] * n + p] = v;
+        }
+        zoff += q.n_frontal;
+        // the next clique may read the columns just written by THIS lane only: program order suffices
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same walk, latency-engineered for trees of hundreds of small cliques (one trained flow each, all
+// parameters cold): a wave covers 32 samples with two lanes per sample (nsf_split.h), and while it computes
+// clique c from LDS it has the parameters, normalisation constants, column indices and latent draws of clique
+// c+1 in flight into registers (software pipeline, one LDS double buffer per wave).  Only the separator
+// samples (produced by the ancestors a moment earlier) are read on the critical path.
+// ---------------------------------------------------------------------------------------------
+struct WalkArgs {
+    const nfisam_post_clique* table;
+    const int32_t* cols;
+    const float* obs;
+    const float* Zt;
+    float* St;
+    float B;
+    int n_cliques, L, n;
+    int wmax;      // floats of one parameter buffer
+    int dmax;      // largest clique dimension
+};
+
+template <int K, int H>
+__device__ __forceinline__ int walk_range_start(int Ds) { return Ds > 0 ? Layout<K, H>::off(Ds) : 0; }
+
+// A 64-byte clique descriptor fetched as 16 dwords by lanes 0..15 (vector memory: returns in order with the
+// other prefetch loads, unlike a scalar load that every later LDS wait would have to wait for), made
+// wave-uniform with readlane.
+__device__ __forceinline__ int desc_fetch(const nfisam_post_clique* e, int lane) {
+    return (lane < 16) ? ((const int*)e)[lane] : 0;
+}
+__device__ __forceinline__ nfisam_post_clique desc_uniform(int tw) {
+    static_assert(sizeof(nfisam_post_clique) == 64, "descriptor is 16 dwords");
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = __builtin_amdgcn_readlane(tw, k);
+    nfisam_post_clique q;
+    __builtin_memcpy(&q, d, sizeof(q));
+    return q;
+}
+
+template <int K, int H>
+__global__ void __launch_bounds__(64) nsf_posterior_walk2_kernel(WalkArgs a) {
+    using LY = Layout<K, H>;
+    constexpr int HP = LY::HP, HH = H / 2;
+    constexpr int R = 8;                       // float4 of parameters in flight per lane
+    constexpr int FP = 4;                      // latent columns in flight per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int hf = lane & 1, p = lane >> 1;
+    const int gp = blockIdx.x * TILE2 + p;
+    const bool valid = gp < a.n;
+    const size_t pp = valid ? (size_t)gp : 0;
+    const int n = a.n, L = a.L, dmax = a.dmax;
+    const float B = a.B;
+    float* wb = smem;                                   // [2][wmax] parameters of the current / next clique
+    float* aux = wb + 2 * (size_t)a.wmax;               // [2][4][dmax]: mean, std, circular, obs
+    int* colb = (int*)(aux + 8 * dmax);                 // [2][dmax] separator then frontal column indices
+    float* zb = (float*)(colb + 2 * dmax);              // [2][dmax][XS2] latent draws
+    float* xs = zb + 2 * dmax * XS2;                    // [dmax][XS2] row being reconstructed
+
+    // ---- clique 0: plain synchronous loads into buffer 0 ------------------------------------------
+    nfisam_post_clique q = a.table[0];
+    {
+        const int Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const int start = walk_range_start<K, H>(Ds), len = LY::off(D) - start, Pk = LY::count(q.D_model);
+        const int len4 = len >> 2;
+        for (int l = 0; l < L; ++l) {
+            const f32x4* src = (const f32x4*)(q.kparams + (size_t)l * Pk + start);
+            f32x4* dst = (f32x4*)(wb + (size_t)l * len);
+            for (int f = lane; f < len4; f += 64) dst[f] = src[f];
+        }
+        if (lane < D) {
+            aux[lane] = q.mean[lane]; aux[dmax + lane] = q.std[lane]; aux[2 * dmax + lane] = q.circular[lane] ? 1.0f : 0.0f;
+        }
+        if (lane < q.n_obs) aux[3 * dmax + lane] = a.obs[q.obs_off + lane];
+        if (lane < q.n_sep + q.n_frontal) colb[lane] = a.cols[q.sep_off + lane];
+        for (int j = 0; j < q.n_frontal; ++j) if (hf == 0) zb[j * XS2 + p] = a.Zt[(size_t)j * n + pp];
+    }
+    nfisam_post_clique qn = q;
+    if (a.n_cliques > 1) qn = desc_uniform(desc_fetch(a.table + 1, lane));
+    wave_lds_sync();
+    int zoff = 0;
+    for (int c = 0; c < a.n_cliques; ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        const int n_obs = q.n_obs, Ds = q.n_obs + q.n_sep, D = Ds + q.n_frontal;
+        const float* ax = aux + cur * 4 * dmax;
+        const int* cl = colb + cur * dmax;
+        const bool more = (c + 1 < a.n_cliques);
+        // ---- 1. given columns: true observations, then the separator samples written by the ancestors.  The
+        //         even lane of a pair is the one that wrote them (program order makes them visible to it).
+        // All loads are issued before any is consumed (one memory round trip instead of one per column): lanes 0..31
+        // take the wave's 32 samples of column k, lanes 32..63 those of column k + 1 (128 contiguous bytes each).
+        // The values were stored by this wave: agent-scope loads read them back from L2.
+        {
+            const int half = lane >> 5, pl = lane & 31;
+            const int gq = blockIdx.x * TILE2 + pl;
+            const size_t pq = (gq < n) ? (size_t)gq : 0;
+            constexpr int KMAX = 16;                       // columns in flight per lane: covers Ds <= 32
+            float v[KMAX];
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const int k = 2 * j + half;
+                v[j] = 0.0f;
+                if (k < Ds) {
+                    if (k < n_obs) v[j] = ax[3 * dmax + k];
+                    else v[j] = __hip_atomic_load(&a.St[(size_t)cl[k - n_obs] * n + pq], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const int k = 2 * j + half;
+                if (k < Ds) {
+                    const float d = v[j] - ax[k];
+                    xs[k * XS2 + pl] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+                }
+            }
+            for (int k = 2 * KMAX + half; k < Ds; k += 2) {          // very wide separators: the rest, one by one
+                float vv = (k < n_obs) ? ax[3 * dmax + k]
+                                       : __hip_atomic_load(&a.St[(size_t)cl[k - n_obs] * n + pq], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                const float d = vv - ax[k];
+                xs[k * XS2 + pl] = ((ax[2 * dmax + k] != 0.0f) ? wrap_pi(d) : d) / ax[dmax + k];
+            }
+        }
+        wave_lds_sync();
+        // ---- 2. next clique: everything that does not depend on this one goes in flight now ----------
+        const int tw2 = (c + 2 < a.n_cliques) ? desc_fetch(a.table + c + 2, lane) : 0;
+        const int nDs = qn.n_obs + qn.n_sep, nD = nDs + qn.n_frontal;
+        const int nstart = walk_range_start<K, H>(nDs), nlen = LY::off(nD) - nstart, nPk = LY::count(qn.D_model);
+        const int nlen4 = nlen >> 2, ntot4 = more ? L * nlen4 : 0;
+        f32x4 pf[R];
+        float pm = 0.0f, ps = 1.0f, pc = 0.0f, po = 0.0f, pz[FP];
+        int pcol = 0;
+        const int nz0 = zoff + q.n_frontal;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int f = lane + 64 * r;
+            pf[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < ntot4) {
+                const int l = f / nlen4, o = f - l * nlen4;
+                pf[r] = ((const f32x4*)(qn.kparams + (size_t)l * nPk + nstart))[o];
+            }
+        }
+        if (more) {
+            if (lane < nD) { pm = qn.mean[lane]; ps = qn.std[lane]; pc = qn.circular[lane] ? 1.0f : 0.0f; }
+            if (lane < qn.n_obs) po = a.obs[qn.obs_off + lane];
+            if (lane < qn.n_sep + qn.n_frontal) pcol = a.cols[qn.sep_off + lane];
+#pragma unroll
+            for (int j = 0; j < FP; ++j) pz[j] = (j < qn.n_frontal) ? a.Zt[(size_t)(nz0 + j) * n + pp] : 0.0f;
+        }
+        // ---- 3. this clique, from LDS only --------------------------------------------------------------
+        {
+            const int start = walk_range_start<K, H>(Ds), len = LY::off(D) - start;
+            const float* zc = zb + cur * dmax * XS2;
+            for (int l = L - 1; l >= 0; --l) {
+                const float* lp = wb + (size_t)cur * a.wmax + (size_t)l * len - start;
+                for (int i = Ds; i < D; ++i) {
+                    float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP];
+                    load_theta2<K, H>(lp, i, xs, p, hf, h1m, h1o, h2m, h2o, th);
+                    const float zin = (l == L - 1) ? zc[(i - Ds) * XS2 + p] : xs[i * XS2 + p];
+                    Spline2<K> S;
+                    float xi, lad;
+                    spline_eval2<K, true>(zin, th, hf, B, S, xi, lad);
+                    if (hf == 0) xs[i * XS2 + p] = xi;
+                    wave_lds_sync();
+                }
+            }
+            for (int i = Ds; i < D; ++i) {
+                float v = xs[i * XS2 + p] * ax[dmax + i] + ax[i];
+                if (ax[2 * dmax + i] != 0.0f) v = wrap_pi(v);
+                if (valid && hf == 0) a.St[(size_t)cl[q.n_sep + (i - Ds)] * n + gp] = v;
+            }
+        }
+        zoff = nz0;
+        // ---- 4. land the next clique's data in the other buffer -----------------------------------------
+        if (more) {
+            float* wn = wb + (size_t)nxt * a.wmax;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int f = lane + 64 * r;
+                if (f < ntot4) ((f32x4*)wn)[f] = pf[r];          // layer l at l*nlen: f = l*nlen4 + o
+            }
+            for (int f = lane + 64 * R; f < ntot4; f += 64) {      // big cliques: the rest, synchronously
+                const int l = f / nlen4, o = f - l * nlen4;
+                ((f32x4*)wn)[f] = ((const f32x4*)(qn.kparams + (size_t)l * nPk + nstart))[o];
+            }
+            float* an = aux + nxt * 4 * dmax;
+            if (lane < nD) { an[lane] = pm; an[dmax + lane] = ps; an[2 * dmax + lane] = pc; }
+            if (lane < qn.n_obs) an[3 * dmax + lane] = po;
+            if (lane < qn.n_sep + qn.n_frontal) colb[nxt * dmax + lane] = pcol;
+            float* zn = zb + nxt * dmax * XS2;
+#pragma unroll
+            for (int j = 0; j < FP; ++j) if (j < qn.n_frontal && hf == 0) zn[j * XS2 + p] = pz[j];
+            for (int j = FP; j < qn.n_frontal; ++j) if (hf == 0) zn[j * XS2 + p] = a.Zt[(size_t)(nz0 + j) * n + pp];
+            wave_lds_sync();
+        }
+        q = qn;
+        if (c + 2 < a.n_cliques) qn = desc_uniform(tw2);
+    }
+}
+
+
+// =============================================================================================
+// launchers of one (K, H) pair
+// =============================================================================================
+template <int KK, int HH>
+static int unit_forward(const float* x, const float* kparams, int n, int D, float B, int L, int layer_stride, float* z,
+                        float* logdet, float* logprob, hipStream_t s) {
+    const int W = pick_waves(D);
+    const size_t lds = ((size_t)2 * D * TILE + TILE) * sizeof(float);
+    int rc = set_lds(nsf_forward_kernel<KK, HH>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nsf_forward_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64 * W), lds, s, x, kparams, n, D, B, L,
+                       layer_stride, z, logdet, logprob);
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+template <int KK, int HH>
+static int unit_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds, float B, int L,
+                        int layer_stride, const float* mean, const float* stdv, const uint8_t* circular, float* x_out,
+                        float* logdet, hipStream_t s) {
+    const size_t lds = ((size_t)D + (D - Ds) + ((L > 1 && Ds > 0) ? (size_t)L * Ds : 0)) * TILE * sizeof(float);
+    int rc = set_lds(nsf_inverse_kernel<KK, HH>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nsf_inverse_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds, s, z, x_sep, kparams, n, D, Ds,
+                       B, L, layer_stride, mean, stdv, circular, x_out, logdet);
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+template <int KK, int HH>
+static int unit_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs, int max_D, float B,
+                     int L, int n, const float* Zt, float* St, hipStream_t s) {
+    // pipelined two-lanes-per-sample walk (H == 8, L == 1) when its LDS double buffer fits (a clique needs at most the
+    // parameter blocks of all its max_D dims), else the plain one-lane-per-sample walk
+    const size_t wmax = (size_t)L * (size_t)Layout<KK, HH>::off(max_D);
+    const size_t lds2 = (2 * wmax + 8 * (size_t)max_D + 2 * (size_t)max_D + (size_t)3 * max_D * XS2) * sizeof(float);
+    const char* walk_env = getenv("NFISAM_WALK");          // "plain" forces the one-lane walk (tests, A/B)
+    const bool force_plain = (walk_env != nullptr && strcmp(walk_env, "plain") == 0);
+    if constexpr (HH == 8) {
+        if (L == 1 && lds2 <= 150 * 1024 && max_D <= 64 && !force_plain) {
+            int rc = set_lds(nsf_posterior_walk2_kernel<KK, HH>, lds2);
+            if (rc) return rc;
+            WalkArgs wa;
+            wa.table = table; wa.cols = cols; wa.obs = obs; wa.Zt = Zt; wa.St = St; wa.B = B;
+            wa.n_cliques = n_cliques; wa.L = L; wa.n = n; wa.wmax = (int)wmax; wa.dmax = max_D;
+            hipLaunchKernelGGL((nsf_posterior_walk2_kernel<KK, HH>), dim3((n + TILE2 - 1) / TILE2), dim3(64), lds2, s, wa);
+            HIP_TRY(hipGetLastError());
+            return NFISAM_OK;
+        }
+    }
+    const size_t lds = (size_t)max_D * TILE * sizeof(float) * (L > 1 ? (size_t)(L + 1) : 1);
+    int rc = set_lds(nsf_posterior_walk_kernel<KK, HH>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nsf_posterior_walk_kernel<KK, HH>), dim3((n + TILE - 1) / TILE), dim3(64), lds, s, table, n_cliques, cols,
+                       obs, B, L, n, max_D, Zt, St);
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+template <int KK, int HH, bool MF, bool WL, int OCC>
+static int launch_train_variant(const TrainArgs& a, int n_cliques, int max_n, int W, int groups, size_t lds, hipStream_t s) {
+    int rc = set_lds(nsf_train_kernel<KK, HH, MF, WL, OCC>, lds);
+    if (rc) return rc;
+    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+    hipLaunchKernelGGL((nsf_train_kernel<KK, HH, MF, WL, OCC>), dim3((max_n + TILE * T - 1) / (TILE * T), n_cliques, groups),
+                       dim3(64 * W), lds, s, a);
+    return NFISAM_OK;
+}
+
+// parameter floats one block must hold: all layers, or (dims spread over grid.z) its own dims' blocks
+template <int KK, int HH>
+static size_t block_weight_floats(const TrainArgs& a, int max_D, int W, int groups) {
+    const size_t stride = a.layer_stride > 0 ? (size_t)a.layer_stride : kcount(max_D, KK, HH);
+    size_t wfloats = (size_t)a.L * stride;
+    if (groups > 1) {
+        const int lo = ((max_D - 1) / W) * W;            // the last group holds the largest blocks
+        wfloats = (size_t)Layout<KK, HH>::off(max_D) - (lo > 0 ? (size_t)Layout<KK, HH>::off(lo) : 0);
+        if (W >= max_D) wfloats = (size_t)Layout<KK, HH>::off(max_D);
+        const size_t first = (size_t)Layout<KK, HH>::off(W < max_D ? W : max_D);
+        if (first > wfloats) wfloats = first;
+    }
+    return wfloats;
+}
+
+template <int KK, int HH>
+static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
+    if constexpr (HH != 8) {
+        return NFISAM_ERR_ARG;
+    } else {
+        const long tiles = (long)((max_n + TILE2 - 1) / TILE2) * n_cliques;
+        // L == 1 and no dL/dx requested: the dims of a tile never exchange data, so a small (latency-bound) launch
+        // turns every (tile, dim) unit into its own single-wave block; big batches keep a tile's dims together.
+        const bool independent_dims = (a.L == 1 && a.gx == nullptr);
+        int W = pick_waves(max_D), groups = 1;
+        // (measured: single-wave blocks beat 2-4 dims per block by 1-5 % here, although they dispatch more slowly)
+        if (independent_dims && tiles * max_D <= 2048) { W = 1; groups = max_D; }
+        else if (independent_dims && tiles * W <= 4096) groups = (max_D + W - 1) / W;
+        a.g_tiles = independent_dims ? 0 : 1;
+        const size_t tile_floats = (((size_t)a.L + 2 * a.g_tiles) * max_D + 1 + (size_t)W * StgRows<KK, HH>::split) * XS2;
+        const size_t wfloats = block_weight_floats<KK, HH>(a, max_D, W, groups);
+        // the lanes of a pair read different weight rows: LDS copy whenever it fits, global loads otherwise
+        const bool wl = weights_mode() != 0 && (tile_floats + wfloats) * sizeof(float) <= 150 * 1024;
+        a.wl_floats = wl ? (int)wfloats : 0;
+        const size_t lds = (tile_floats + (wl ? wfloats : 0)) * sizeof(float);
+        int rc;
+        if (wl) {
+            rc = set_lds(nsf_train2_kernel<KK, HH, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train2_kernel<KK, HH, true>), dim3((max_n + TILE2 - 1) / TILE2, n_cliques, groups), dim3(64 * W),
+                               lds, s, a);
+        } else {
+            rc = set_lds(nsf_train2_kernel<KK, HH, false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train2_kernel<KK, HH, false>), dim3((max_n + TILE2 - 1) / TILE2, n_cliques, groups), dim3(64 * W),
+                               lds, s, a);
+        }
+        HIP_TRY(hipGetLastError());
+        return NFISAM_OK;
+    }
+}
+
+template <int KK, int HH>
+static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
+    if constexpr (HH != 8) {
+        return NFISAM_ERR_ARG;
+    } else {
+        // throughput regime: one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
+        int W = 4;
+        const char* e = getenv("NFISAM_BIG_W");
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) W = atoi(e);
+        const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
+        a.tiles_per_block = T;
+        a.xrows = max_D;
+        a.n_copies = (max_n + TILE * T - 1) / (TILE * T);
+        const int gx = (a.n_copies + W - 1) / W;
+        const size_t lds = (size_t)W * (size_t)(max_D + 16) * XS * sizeof(float);
+        int occ = 3;           // 149 VGPRs, no scratch; the 128-register build (4 waves per SIMD) spills 40 VGPRs and measures 5 % slower
+        const char* oe = getenv("NFISAM_OCC");
+        if (oe != nullptr) occ = atoi(oe);
+        int rc;
+        if (occ >= 4) {
+            rc = set_lds(nsf_train1_kernel<KK, 8, 4>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 4>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+        } else {
+            rc = set_lds(nsf_train1_kernel<KK, 8, 3>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 3>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+        }
+        HIP_TRY(hipGetLastError());
+        return NFISAM_OK;
+    }
+}
+
+// gradient kernel of one training iteration / VJP: picks the kernel family and block shape for the launch
+template <int KK, int HH>
+static int unit_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D, hipStream_t s) {
+    if (a_in.tile == TILE2) return unit_train2<KK, HH>(a_in, n_cliques, max_n, max_D, s);
+    TrainArgs a = a_in;
+    const bool mf = use_mfma_grad(HH);
+    const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
+    // L == 1 and no dL/dx requested: the dims of a tile never exchange data.  When the launch is small
+    // (latency-bound) every (tile, dim) unit becomes its own single-wave block, so that every wave has
+    // a SIMD to itself; with thousands of waves in flight tiles keep their dims together instead.
+    const bool independent_dims = (a.L == 1 && a.gx == nullptr);
+    if (independent_dims && a.nll_mode && a.gz == nullptr && is_dim_major(n_cliques, max_n, max_D, a.L, TILE, HH))
+        return unit_train1<KK, HH>(a, n_cliques, max_n, max_D, s);
+    int W = pick_waves(max_D), groups = 1, T = 1;
+    if (independent_dims && tiles * max_D <= 1024) { W = 1; groups = max_D; }
+    else if (independent_dims) {
+        // 4 waves per block: a wave's staging tile is 6.3 KB (24 rows), so 16 waves fit a CU next to the particle tiles.
+        // Up to 256 tiles every wave still gets a single unit (dims spread over grid.z); larger launches let a wave
+        // loop over its dims and amortise the tile load.
+        W = 4;
+        const char* e = getenv("NFISAM_BIG_W");
+        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) W = atoi(e);
+        if (W > max_D) W = max_D;
+        if (tiles <= 256) groups = (max_D + W - 1) / W;
+        if (groups == 1 && mf && a.tiles_per_block > 1) T = a.tiles_per_block;
+    }
+    a.tiles_per_block = T;
+    a.g_tiles = independent_dims ? 0 : 1;
+    const size_t xt = (size_t)(a.L > T ? a.L : T);
+    const size_t tile_floats = ((xt + 2 * a.g_tiles) * max_D + 1 + (mf ? (size_t)W * StgRows<KK, HH>::value : 0)) * XS;
+    const size_t wfloats = block_weight_floats<KK, HH>(a, max_D, W, groups);
+    // LDS copy of the parameters: pays when few waves share a SIMD (nothing hides a cold scalar-cache
+    // miss per weight row); it must fit next to the tiles.  Large batches keep the scalar path.
+    const int wm = weights_mode();
+    const long blocks = ((tiles + T - 1) / T) * groups;
+    const bool fits = (tile_floats + wfloats) * sizeof(float) <= 150 * 1024;
+    const bool wl = fits && (wm == 1 || (wm == -1 && blocks * W <= 4096 && !(independent_dims && blocks * W > 1024)));
+    a.wl_floats = wl ? (int)wfloats : 0;
+    const size_t lds = (tile_floats + (wl ? wfloats : 0)) * sizeof(float);
+    int rc;
+    if constexpr (HH == 8) {
+        if (mf) {
+            if (wl) rc = launch_train_variant<KK, HH, true, true, 1>(a, n_cliques, max_n, W, groups, lds, s);
+            else rc = launch_train_variant<KK, HH, true, false, 1>(a, n_cliques, max_n, W, groups, lds, s);
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
+            return NFISAM_OK;
+        }
+    }
+    if (wl) rc = launch_train_variant<KK, HH, false, true, 1>(a, n_cliques, max_n, W, groups, lds, s);
+    else rc = launch_train_variant<KK, HH, false, false, 1>(a, n_cliques, max_n, W, groups, lds, s);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
+// ---- the unit's table -------------------------------------------------------------------------------------------
+#define NSF_OPS_ENTRY(k, h) {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>},
+static const NsfUnitOps g_unit_ops[] = {NSF_FOR_EACH_KH(NSF_OPS_ENTRY)};
+
+#define NSF_UNIT_FN_(u) nsf_unit_ops_u##u
+#define NSF_UNIT_FN(u) NSF_UNIT_FN_(u)
+extern "C" const NsfUnitOps* NSF_UNIT_FN(NSF_UNIT)(int K, int H) {
+    for (const NsfUnitOps& o : g_unit_ops)
+        if (o.K == K && o.H == H) return &o;
+    return nullptr;
+}

@@ -289,6 +289,15 @@ class FlowsPriorFactor(CliqueSeparatorFactor):
 class NFiSAM(FactorGraphSolver):
     def __init__(self, args: NFiSAMArgs = None):
         super().__init__(args=args if args is not None else NFiSAMArgs())
+        a = self._args
+        # fail at construction, not in the middle of an incremental update (the kernels are compiled per (K, H))
+        if a.flow_type != "NSF_AR":
+            raise NotImplementedError("Unknown flow type for the pipeline")
+        if not _nh.supported(a.num_knots, a.hidden_dim):
+            raise ValueError("num_knots=%r, hidden_dim=%r: the gfx950 kernels are instantiated for num_knots in 2..16 and "
+                             "hidden_dim in {4, 8, 16} (nf-isam_amd/csrc/nsf_units.h)" % (a.num_knots, a.hidden_dim))
+        if int(a.flow_number) < 1:
+            raise ValueError("flow_number must be >= 1")
 
     def _simulation_backend(self):
         if not getattr(self._args, "device_simulation", False) or not torch.cuda.is_available():

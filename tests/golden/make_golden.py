@@ -58,6 +58,10 @@ CASES = {
     "n256_d11_k9": (256, 11, 9, 2),
     "n128_d16_k12": (128, 16, 12, 3),
     "n96_d1_k9": (96, 1, 9, 4),       # degenerate: only init_param, no conditioner
+    # other (num_knots, hidden_dim) than the examples' usual ones: the reference takes any (src/flows/flows.py:51-60)
+    "n96_d5_k3_h4": (96, 5, 3, 5, 4),
+    "n80_d7_k15_h16": (80, 7, 15, 6, 16),
+    "n64_d4_k15_h8": (64, 4, 15, 7, 8),   # num_knots=15: toy_examples/R2RangeGaussian_example/...incremental.py:85
 }
 
 
@@ -73,7 +77,7 @@ def state_to_np(sd):
     return {k.replace(".", "__"): v.detach().numpy().astype(np.float32) for k, v in sd.items()}
 
 
-def gen_flow_case(name, n, D, K, seed):
+def gen_flow_case(name, n, D, K, seed, H=8):
     torch.manual_seed(seed)
     flow = NSF_AR(dim=D, K=K, B=B, hidden_dim=H)
     prior = CustomMultivariateNormal(dim=D)
@@ -406,8 +410,8 @@ def gen_se2_and_factor_samplers():
 
 
 if __name__ == "__main__":
-    for name, (n, D, K, seed) in CASES.items():
-        gen_flow_case(name, n, D, K, seed)
+    for name, spec in CASES.items():
+        gen_flow_case(name, *spec)
     gen_rqs_direct()
     gen_normalize()
     gen_se2_and_factor_samplers()

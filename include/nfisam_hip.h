@@ -193,16 +193,13 @@ int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int 
                         float* gx, float* loss_sum, nfisam_stream_t stream);
 
 /* Device-resident control block of one clique's training run. */
-typedef struct nfisam_train_state {
+typedef struct nfisam_train_state {      /* 32 bytes since ABI 1200 (the unused loss_acc / loss_slots[64] of ABI 1100 are gone) */
     int32_t step;        /* iterations completed and recorded so far (advances when a chunk is closed) */
     int32_t stop;        /* set by the device when the early-stop rule fired                 */
     int32_t have_avg;    /* a previous window mean exists                                    */
     float   loss_avg;    /* previous window mean (NFiSAM.py:481-491)                         */
-    float   loss_acc;    /* (unused, kept for layout)                                         */
     int32_t domain_err;  /* non-zero if a kernel saw a non-finite loss                       */
-    int32_t reserved[10];
-    float   loss_slots[64]; /* (unused since ABI 1100: the per-iteration loss sums live in a ring behind the
-                               gradient copies of the kgrad workspace; kept for layout)              */
+    int32_t reserved[3];
 } nfisam_train_state;
 
 typedef struct nfisam_adam_cfg {

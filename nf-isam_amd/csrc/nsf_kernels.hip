@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-extern "C" int nfisam_abi_version(void) { return 1100; }
+extern "C" int nfisam_abi_version(void) { return 1200; }
 extern "C" int nfisam_last_hip_error(void) { return nfisam_g_last_hip_error; }
 
 // (K, H) -> launchers of the kernel unit that instantiates the pair (nsf_units.h), nullptr if none does
@@ -692,34 +692,42 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
         HIP_TRY(hipStreamWaitEvent(p->cap, p->ev, 0));
         work = p->cap;
     }
+    // An error return must not leave graph work running on buffers the caller is about to reset or free: every
+    // failure path drains the work stream first.
+    auto fail = [&](int rc) { (void)hipStreamSynchronize(work); return rc; };
     int status = NFISAM_OK, done = 0;
     bool read_back = false;
     while (done < p->cfg.max_iters) {
         const int left = p->cfg.max_iters - done;
         const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
         if (p->exec && todo == p->chunk) {
-            HIP_TRY(hipGraphLaunch(p->exec, work));
+            const hipError_t e = hipGraphLaunch(p->exec, work);
+            if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
         } else {
             for (int it = 0; it < todo; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
                                       &p->cfg, it, work);
-                if (rc) return rc;
+                if (rc) return fail(rc);
             }
             int rcb = enqueue_bookkeeping(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
                                           todo, work);
-            if (rcb) return rcb;
+            if (rcb) return fail(rcb);
         }
         done += p->chunk;
-        HIP_TRY(read_states(p, work));
+        const hipError_t e = read_states(p, work);
+        if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
         read_back = true;
         bool all_stopped = true;
         for (int c = 0; c < p->n_cliques; ++c) {
             if (p->hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
             if (!p->hst[c].stop && p->hst[c].step < p->cfg.max_iters) all_stopped = false;
         }
-        if (all_stopped || status != NFISAM_OK) break;
+        if (all_stopped) break;        // (a clique with a domain error has stop set: the others run to their own end)
     }
-    if (!read_back) HIP_TRY(read_states(p, work));
+    if (!read_back) {
+        const hipError_t e = read_states(p, work);
+        if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
+    }
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;
 }

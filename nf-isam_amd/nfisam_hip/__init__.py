@@ -33,8 +33,7 @@ class HipLibraryMissing(ImportError):
 
 class TrainState(C.Structure):
     _fields_ = [("step", C.c_int32), ("stop", C.c_int32), ("have_avg", C.c_int32), ("loss_avg", C.c_float),
-                ("loss_acc", C.c_float), ("domain_err", C.c_int32), ("reserved", C.c_int32 * 10),
-                ("loss_slots", C.c_float * 64)]
+                ("domain_err", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class AdamCfg(C.Structure):
@@ -55,7 +54,7 @@ class PostClique(C.Structure):
                 ("obs_off", C.c_int32), ("sep_off", C.c_int32), ("front_off", C.c_int32), ("reserved", C.c_int32)]
 
 
-assert C.sizeof(TrainState) == 320 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64 and C.sizeof(PostClique) == 64
+assert C.sizeof(TrainState) == 32 and C.sizeof(AdamCfg) == 32 and C.sizeof(Clique) == 64 and C.sizeof(PostClique) == 64
 
 _lib = None
 
@@ -342,8 +341,10 @@ class TrainBatch:
         -> list of iterations run per clique."""
         self.prepare(use_graph)
         iters = (C.c_int32 * self.nc)()
-        _check(lib().nfisam_nsf_train_plan_run(self._plan, iters, _stream()), "nfisam_nsf_train_plan_run")
-        return [int(v) for v in iters]
+        rc = lib().nfisam_nsf_train_plan_run(self._plan, iters, _stream())
+        self.last_iters = [int(v) for v in iters]          # valid also when a clique hit a domain error
+        _check(rc, "nfisam_nsf_train_plan_run")
+        return self.last_iters
 
     def reset(self, kparams=None):
         """Re-initialise Adam moments / state / loss record in place (pointers stay valid, so a
@@ -368,7 +369,7 @@ class TrainBatch:
     def state(self, c=0):
         s = self.states[c].cpu().numpy()
         return {"step": int(s[0]), "stop": int(s[1]), "have_avg": int(s[2]),
-                "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[5])}
+                "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[4])}
 
 
 def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt=None):

@@ -94,7 +94,7 @@ class SimulationBasedSampler:
 
     def sample(self, num_samples: int, backend=None):
         """-> (batch [n, D], variable ordering incl. observation variables, true observations).  `backend` draws the
-        columns: the factors' numpy methods by default, `sampler.DeviceSimulation.TorchSimulationBackend` keeps
+        columns: the factors' numpy methods by default (`HostSimulationBackend`); a backend whose arrays live on the device keeps
         them on the GPU (the batch is then a device tensor); a backend with `run_plan` executes the whole schedule
         itself (`FusedSimulationBackend`: one kernel per clique)."""
         be = backend if backend is not None else HostSimulationBackend

@@ -159,78 +159,92 @@ class FactorGraphSolver:
 
     # ---- graph / tree update ------------------------------------------------------------------
     def update_physical_and_working_graphs(self, timer: List[float] = None, device: str = "cpu") -> "FactorGraphSolver":
+        """Fold the staged nodes / factors into the graphs and re-eliminate only the part of the Bayes tree they touch
+        (what the reference does in :256-358).  Three stages:
+          1. check the staged input and fix the new elimination ordering -- nothing has been modified yet, so a bad
+             factor or an unsupported ordering method leaves the solver exactly as it was;
+          2. cut the unaffected subtrees out of the physical tree (they are moved, not copied), build the working graph
+             (affected variables + the separator factors of the cut subtrees + the staged input) and its Bayes tree,
+             and hang the cut subtrees under the new tree;
+          3. carry trained models over to cliques that reappear with the same variables in the same relative order."""
         start = time.time()
-        old_nodes = set(self.physical_vars)
-        touched = set().union(*[set(f.vars) for f in self._new_factors]) if self._new_factors else set()
-        if self._physical_bayes_tree:
-            # the old physical tree is replaced below: its unaffected subtrees are moved, not copied
-            affected_nodes, sub_trees = self._physical_bayes_tree.get_affected_vars_and_partial_bayes_trees(
-                vars=old_nodes & touched, detach=True)
+        staged_nodes, staged_factors = list(self._new_nodes), list(self._new_factors)
+        # -- 1. validation + ordering (no state is touched before this succeeds)
+        known = set(self.physical_vars) | set(staged_nodes)
+        for f in staged_factors:
+            missing = [str(v.name) for v in f.vars if v not in known]
+            if missing:
+                raise KeyError("factor %s refers to variables that are neither in the graph nor staged: %s"
+                               % (f, " ".join(missing)))
+        previous_ordering = self._elimination_ordering
+        self.generate_ordering()                      # raises NotImplementedError for an unknown method
+        # -- 2. working graph and trees
+        kept_subtrees = []
+        if self._physical_bayes_tree is not None:
+            touched_old = {v for f in staged_factors for v in f.vars} & set(self.physical_vars)
+            affected, kept_subtrees = self._physical_bayes_tree.get_affected_vars_and_partial_bayes_trees(
+                vars=touched_old, detach=True)
             self._working_graph = self._physical_graph.get_sub_factor_graph_with_prior(
-                variables=affected_nodes, sub_trees=sub_trees, clique_prior_dict=self._implicit_factors)
-        else:
-            sub_trees = []
-        for node in self._new_nodes:
-            self._working_graph.add_node(node)
-        for factor in self._new_factors:
-            self._working_graph.add_factor(factor)
-
-        old_ordering = self._elimination_ordering
-        self.generate_ordering()
-        working = set(self.working_vars)
+                variables=affected, sub_trees=kept_subtrees, clique_prior_dict=self._implicit_factors)
+        for graph in (self._working_graph, self._physical_graph):
+            for node in staged_nodes:
+                graph.add_node(node)
+            for factor in staged_factors:
+                graph.add_factor(factor)
+        in_working = set(self.working_vars)
         self._working_bayes_tree = self._working_graph.get_bayes_tree(
-            ordering=[v for v in self._elimination_ordering if v in working])
-
-        for node in self._new_nodes:
-            self._physical_graph.add_node(node)
-        for factor in self._new_factors:
-            self._physical_graph.add_factor(factor)
+            ordering=[v for v in self._elimination_ordering if v in in_working])
         self._physical_bayes_tree = self._working_bayes_tree.__copy__()
-        self._physical_bayes_tree.append_child_bayes_trees(sub_trees)
-
-        # Old cliques that vanished: if one reappears with the same variables in the same relative
-        # order (last update's root is now a leaf), its trained flow is re-used instead of re-trained.
-        live = self._physical_bayes_tree.clique_nodes
-        to_delete = []
-        for old_clique in list(self._clique_density_model.keys()):
-            if old_clique in live:
-                continue
-            for new_clique in self._working_bayes_tree.clique_ordering():
-                if old_clique.vars == new_clique.vars and \
-                        [v for v in old_ordering if v in old_clique.vars] == \
-                        [v for v in self._elimination_ordering if v in new_clique.vars]:
-                    self._clique_true_obs[new_clique] = self._clique_true_obs[old_clique]
-                    if old_clique in self._clique_variable_pattern:
-                        self._clique_variable_pattern[new_clique] = self._clique_variable_pattern[old_clique]
-                    if old_clique in self._clique_samples:
-                        self._clique_samples[new_clique] = self._clique_samples[old_clique]
-                    self._clique_density_model[new_clique] = \
-                        self.root_clique_density_model_to_leaf(old_clique, new_clique, device)
-                    new_separator_factor = None
-                    if new_clique.separator:
-                        separator_var_list = sorted(new_clique.separator, key=lambda x: self._reverse_ordering_map[x])
-                        new_separator_factor = self.clique_density_to_separator_factor(
-                            separator_var_list, self._clique_density_model[new_clique],
-                            self._clique_true_obs[old_clique])
-                        self._implicit_factors[new_clique] = new_separator_factor
-                    self._working_graph = self._working_graph.eliminate_clique_variables(
-                        clique=new_clique, new_factor=new_separator_factor)
-                    break
-            to_delete.append(old_clique)
-        for old_clique in to_delete:
-            # (an old clique equal to a re-used new clique shares its key: keep the new entries)
-            if old_clique in self._working_bayes_tree.clique_nodes:
-                continue
-            self._clique_density_model.pop(old_clique, None)
-            self._clique_true_obs.pop(old_clique, None)
-            self._clique_variable_pattern.pop(old_clique, None)
-            self._clique_samples.pop(old_clique, None)
-
-        self._new_nodes = []
-        self._new_factors = []
+        self._physical_bayes_tree.append_child_bayes_trees(kept_subtrees)
+        # -- 3. trained models of cliques that dropped out of the tree
+        self._recycle_models(previous_ordering, device)
+        self._new_nodes, self._new_factors = [], []
         if timer is not None:
             timer.append(time.time() - start)
         return self
+
+    def _recycle_models(self, previous_ordering: List[Variable], device) -> None:
+        """A clique that vanished from the tree may reappear with the same variables in the same relative elimination
+        order but another frontal / separator split (typically last update's root, now a leaf).  Its flow is still the
+        right joint density: re-wrap it (`root_clique_density_model_to_leaf`) instead of training again, emit its
+        separator factor and eliminate it from the working graph.  Everything else that vanished is forgotten."""
+        alive = self._physical_bayes_tree.clique_nodes
+        vanished = [c for c in list(self._clique_density_model) if c not in alive]
+        if not vanished:
+            return
+        rank_prev = {v: k for k, v in enumerate(previous_ordering)}
+        rank_now = {v: k for k, v in enumerate(self._elimination_ordering)}
+        candidates = {}                               # variable set -> new clique (first in tree order wins)
+        for c in self._working_bayes_tree.clique_ordering():
+            candidates.setdefault(frozenset(c.vars), c)
+        reused = set()
+        for old in vanished:
+            new = candidates.get(frozenset(old.vars))
+            same_order = new is not None and all(v in rank_prev for v in old.vars) and \
+                sorted(old.vars, key=rank_prev.__getitem__) == sorted(new.vars, key=rank_now.__getitem__)
+            if not same_order or new in reused:
+                continue
+            reused.add(new)
+            obs = self._clique_true_obs[old]
+            self._clique_true_obs[new] = obs
+            for store in (self._clique_variable_pattern, self._clique_samples):
+                if old in store:
+                    store[new] = store[old]
+            model = self.root_clique_density_model_to_leaf(old, new, device)
+            self._clique_density_model[new] = model
+            factor = None
+            if new.separator:
+                sep = sorted(new.separator, key=self._reverse_ordering_map.__getitem__)
+                factor = self.clique_density_to_separator_factor(sep, model, obs)
+                self._implicit_factors[new] = factor
+            self._working_graph = self._working_graph.eliminate_clique_variables(clique=new, new_factor=factor)
+        working = self._working_bayes_tree.clique_nodes
+        for old in vanished:
+            if old in working:                        # equal (same frontal + separator) to a re-used clique: the key is shared
+                continue
+            for store in (self._clique_density_model, self._clique_true_obs, self._clique_variable_pattern,
+                          self._clique_samples):
+                store.pop(old, None)
 
     # ---- hooks of the density back end ----------------------------------------------------------
     def fit_clique_density_model(self, clique, samples, var_ordering, timer, *args, **kwargs) -> ConditionalSampler:

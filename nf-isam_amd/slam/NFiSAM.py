@@ -68,9 +68,9 @@ class NFiSAMArgs(SolverArgs):
         self.data_parallel = data_parallel
         self.training_loss_dir = training_loss_dir
         # not in the reference: simulate and normalise the clique training batches on the GPU.
-        # True: one fused kernel per clique (csrc/clique_sim.hip); "torch": batched torch ops; False: the factors'
-        # host (numpy, float64) samplers.  Cliques with a factor type the device simulator does not know fall back
-        # to the host.  Plaza1: the fused simulator takes ~1.3 s off the 4-5 s spent outside training.
+        # True: one fused kernel per clique (csrc/clique_sim.hip); False: the factors' host (numpy, float64) samplers.
+        # Cliques with a factor type the device simulator does not know fall back to the host.  Plaza1: the fused
+        # simulator takes ~1.3 s off the 4-5 s spent outside training.
         self.device_simulation = device_simulation
         self.tl_cnt = 0
 
@@ -304,9 +304,8 @@ class NFiSAM(FactorGraphSolver):
             return None
         be = self.__dict__.get("_sim_backend")
         if be is None:
-            from sampler.DeviceSimulation import FusedSimulationBackend, TorchSimulationBackend
-            fused = str(getattr(self._args, "device_simulation", "")).lower() != "torch"
-            be = self._sim_backend = (FusedSimulationBackend if fused else TorchSimulationBackend)(_device())
+            from sampler.DeviceSimulation import FusedSimulationBackend
+            be = self._sim_backend = FusedSimulationBackend(_device())
         return be
 
     # ---- the hot loop ---------------------------------------------------------------------------
@@ -375,7 +374,7 @@ class NFiSAM(FactorGraphSolver):
                     circular=circular_dim_list, kp0=kp0, D=aug_clique_dim, sep_dim=aug_clique_dim - frontal_dim,
                     n=int(training_data.shape[0]), cfg=(K, H, B, L), device=device)
 
-    def train_prepared(self, preps: List[dict]) -> None:
+    def train_prepared(self, preps: List[dict], retry: bool = True) -> None:
         """The reference's `for i in range(flow_iterations)` loop (NFiSAM.py:451-491) for one or several prepared
         cliques at once (grid.y = clique; every clique has its own Adam state, loss record and early-stop decision).
         Training plans (device buffers + the captured hipGraph of one chunk of iterations) are kept per batch shape
@@ -397,8 +396,30 @@ class NFiSAM(FactorGraphSolver):
         for x, p in zip(tb.xs, preps):
             x.copy_(p["training_data"])
         tb.reset(kparams=[p["kp0"] for p in preps])
-        iters = tb.run(use_graph=True)
         logger = logging.getLogger("flows on clique")
+        try:
+            iters = tb.run(use_graph=True)
+        except RuntimeError as err:
+            # A non-finite loss (the reference raises "Input outside domain" / fails its discriminant assert there,
+            # src/flows/utils.py:74-76,133, and the whole update dies).  The other cliques of the batch have run to their
+            # own end; a failed clique is retried ONCE from a fresh initialisation, on its own.
+            if "domain" not in str(err):
+                raise
+            iters = tb.last_iters
+            failed = [c for c in range(len(preps)) if tb.state(c)["domain_err"]]
+            if retry and failed:
+                from flows.flows import init_reference_blob
+                for c in failed:
+                    logger.warning("non-finite loss while fitting clique %d of the batch: retrying once with fresh parameters", c)
+                    p = preps[c]
+                    p["kp0"] = torch.cat([_nh.pack(init_reference_blob(p["D"], K, H, device), p["D"], K, H, 1) for _ in range(L)])
+                    self.train_prepared([p], retry=False)
+                done = set(failed)
+                for c, p in enumerate(preps):
+                    if c not in done:
+                        p["trained"], p["iters"], p["iter_loss"] = tb.kparams[c].clone(), iters[c], tb.iter_loss[c].clone()
+                return
+            raise
         for c, p in enumerate(preps):
             if iters[c] < a.flow_iterations:
                 logger.info(f"Early stopping at iter {iters[c]}")

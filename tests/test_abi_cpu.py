@@ -24,11 +24,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nh.EXPORTS), declared ^ set(nh.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfisam_abi_version() == 1100
+    assert lib.nfisam_abi_version() == 1200
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(nh.TrainState) == 320
+def test_struct_sizes_match_header(tmp_path):
+    # what a C compiler makes of include/nfisam_hip.h (the binding's ctypes mirrors must agree with it)
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "nfisam_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(nfisam_train_state), sizeof(nfisam_adam_cfg), sizeof(nfisam_clique), sizeof(nfisam_post_clique), '
+                   'sizeof(nfisam_sim_op)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(nh.TrainState), C.sizeof(nh.AdamCfg), C.sizeof(nh.Clique), C.sizeof(nh.PostClique),
+                     C.sizeof(nh.SimOp)], sizes
+    assert C.sizeof(nh.TrainState) == 32
     assert C.sizeof(nh.AdamCfg) == 32
     assert C.sizeof(nh.Clique) == 64
 

@@ -16,7 +16,8 @@ Stated tolerances (training is stochastic; the reference never seeds torch, so p
   * step 3 (bimodal landmark): <= 0.315 = 1.5 x 0.21, the reference's own run-to-run spread at this step
     (SURVEY.md §4: stored run vs re-run 0.21; stored run vs nested 0.14);
   * steps 4-5 (no nested-sampling blobs in the checkout, a single stored reference run): <= 0.45 against
-    that run, plus first/second-moment checks against the known ground-truth geometry.
+    that run (8 seeds on MI355X: 0.18-0.37), plus first/second-moment checks against the known ground-truth geometry.
+Every variant is run with three seeds and every seed has to meet the tolerances.
 """
 import json
 import os
@@ -39,17 +40,22 @@ def xy(order, arr):
     return np.hstack([cols[v] for v in sorted(order)]), cols
 
 
-@pytest.mark.parametrize("device_simulation", [False, True, "torch"],
-                         ids=["host-simulator", "fused-device-simulator", "torch-device-simulator"])
+@pytest.mark.parametrize("device_simulation", [False, True], ids=["host-simulator", "fused-device-simulator"])
 def test_small_range_problem_incremental_posteriors(tmp_path, device_simulation):
-    """device simulators: the clique training batches are simulated (one fused kernel per clique, or batched torch
-    ops) and normalised on the GPU (sampler.DeviceSimulation + nfisam_normalize_columns) instead of by the factors'
-    numpy samplers."""
+    """device simulator: the clique training batches are simulated (one fused kernel per clique) and normalised on the
+    GPU (sampler.DeviceSimulation + nfisam_normalize_columns) instead of by the factors' numpy samplers."""
+    for seed in (0, 1, 2):          # three seeds per variant: a tolerance met by one lucky seed proves nothing
+        sub = tmp_path / ("seed%d" % seed)
+        sub.mkdir()
+        _one_run(sub, device_simulation, seed)
+
+
+def _one_run(tmp_path, device_simulation, seed):
     from slam.NFiSAM import NFiSAM_empirial_study
     from utils.Statistics import MMDb
     g = np.load(os.path.join(GOLDEN, "small_range_case1.npz"))
     (tmp_path / "factor_graph.fg").write_text(str(g["factor_graph_fg"]))
-    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     ref_args = json.loads(str(g["run1_parameters"]))
     run_dirs = NFiSAM_empirial_study([ref_args["num_knots"]], [ref_args["flow_iterations"]],
                                      [ref_args["local_sample_num"]], [ref_args["learning_rate"]],
@@ -77,7 +83,7 @@ def test_small_range_problem_incremental_posteriors(tmp_path, device_simulation)
         ref_xy, _ = xy(order, g["run1_step%d" % i])
         m_ref = MMDb(ours_xy, ref_xy)
         # steps 4-5 are compared with the reference's SINGLE stored run of a multi-modal posterior: loose
-        tol_ref = 0.08 if i <= 2 else (0.315 if i == 3 else 0.5)
+        tol_ref = 0.08 if i <= 2 else (0.315 if i == 3 else 0.45)
         assert m_ref <= tol_ref, (i, m_ref)
         if i <= 3:
             dyn_xy, _ = xy(str(g["dyn1_step%d_ordering" % i]).split(), g["dyn1_step%d" % i])

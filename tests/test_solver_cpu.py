@@ -222,6 +222,41 @@ def test_solver_loop_structure_matches_reference_run(small_graph):
         assert np.linalg.norm(res[v].mean(0)[:2] - truth[v][:2]) < 3.0
 
 
+def test_failed_update_leaves_the_solver_untouched(small_graph):
+    """A staged factor on an unknown variable, or an unsupported ordering method, must fail BEFORE the physical tree is
+    cut (the unaffected subtrees are moved out of the live tree, so a late failure would corrupt a retry)."""
+    (nodes, truth, factors), _ = small_graph
+    np.random.seed(0)
+    s = _StubSolver(SolverArgs(elimination_method="pose_first", local_sample_num=64, posterior_sample_num=16))
+    steps = group_nodes_factors_incrementally(nodes, factors, 1)
+    for vs, fs in steps[:3]:
+        for v in vs:
+            s.add_node(v)
+        for f in fs:
+            s.add_factor(f)
+        s.update_physical_and_working_graphs()
+        s.incremental_inference()
+    before = str(s.physical_bayes_tree)
+    n_cliques = len(s.physical_bayes_tree.clique_ordering())
+    vs, fs = steps[3]
+    for f in fs:                              # the new pose is NOT staged: its factors dangle
+        s.add_factor(f)
+    with pytest.raises(KeyError):
+        s.update_physical_and_working_graphs()
+    assert str(s.physical_bayes_tree) == before and len(s.physical_bayes_tree.clique_ordering()) == n_cliques
+    assert len(s.new_factors) == len(fs) and len(s.physical_factors) == sum(len(q[1]) for q in steps[:3])
+    s._args.elimination_method = "ccolamd"    # dead code in the reference (SURVEY.md Appendix B): refused, nothing cut
+    for v in vs:
+        s.add_node(v)
+    with pytest.raises(NotImplementedError):
+        s.update_physical_and_working_graphs()
+    assert str(s.physical_bayes_tree) == before
+    s._args.elimination_method = "pose_first"
+    s.update_physical_and_working_graphs()    # the retry works on the intact state
+    res = s.incremental_inference()
+    assert set(res) == set(s.physical_vars) and len(s.physical_vars) == 2 + 4
+
+
 def test_mmd_metric():
     rng = np.random.RandomState(0)
     a, b = rng.randn(500, 2), rng.randn(500, 2)

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-2 profile collection on the gpurun MI355X box: kernel-trace stats and PMC passes (each in its own run, never
+# combined with tracing) of the bench.py headline workload (C3) and of the 64-clique throughput batch.
+# usage: scripts/collect_profiles.sh <out dir under gpurun_out>
+out=$GRAFT_REPO_ROOT/$1
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-update-bench"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_trace -- $B --no-regimes > $out/c3_bench_line.json 2> $out/c3_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/all_trace -- $B > $out/all_bench_line.json 2> $out/all_trace.err
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA" \
+           "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES"; do
+  rocprofv3 --pmc $set --output-format csv -d $out/c3_pmc$i -- $B --no-regimes > /dev/null 2> $out/c3_pmc$i.err
+  rocprofv3 --pmc $set --output-format csv -d $out/b64_pmc$i -- python3 $GRAFT_REPO_ROOT/scripts/run_c3.py scaling > /dev/null 2> $out/b64_pmc$i.err
+  i=$((i+1))
+done
+cd $GRAFT_REPO_ROOT
+python3 - $out <<'PY'
+import csv, glob, collections, json, sys, os
+out = sys.argv[1]
+def summarize(prefix):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(out + "/%s_pmc*/*/*counter_collection.csv" % prefix)):
+        for r in csv.DictReader(open(f)):
+            d[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = []
+    res = {}
+    for k, v in d.items():
+        if "nsf_" not in k:
+            continue
+        lines.append(k)
+        res[k] = {}
+        for c, x in sorted(v.items()):
+            # the timed region = the last 500 (bench) / 300 (run_c3) launches; warm-up launches of other shapes are excluded by taking the modal value count
+            lines.append("   %-26s n=%5d mean=%16.1f max=%16.1f" % (c, len(x), sum(x) / len(x), max(x)))
+            res[k][c] = sum(x) / len(x)
+    open(out + "/%s_pmc_summary.txt" % prefix, "w").write("\n".join(lines) + "\n")
+    return res
+c3 = summarize("c3")
+b64 = summarize("b64")
+json.dump(dict(c3=c3, b64=b64), open(out + "/pmc_means.json", "w"), indent=1)
+for pre in ("c3_trace", "all_trace"):
+    for f in glob.glob(out + "/%s/*/*kernel_stats.csv" % pre):
+        os.system("cp %s %s/%s_kernel_stats.csv" % (f, out, pre))
+os.system("rm -rf %s/*_pmc[0-9] %s/c3_trace %s/all_trace" % (out, out, out))
+PY
+ls -la $out

@@ -93,7 +93,10 @@ int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K
  *   mean[D], std[D], circular[D] (1 = angle column): NULL mean => data already normalised and
  *   the output is left normalised (plain NSF_AR.inverse_given_separator).
  *   x_out[n,D-Ds]; logdet[n] nullable (sum of -log|dz/dx| over the solved columns, as NSF_AR.inverse)
- * For L>1 every layer is conditioned on the same x_sep (slam/NFiSAM.py:151-152).           */
+ * L > 1 with given columns: layer l is conditioned on the given columns pushed through the marginal flow of
+ * layers 0..l-1, so that forward(cat(x_sep, x_out)) returns z.  (The reference's literal loop feeds every layer
+ * the raw columns, slam/NFiSAM.py:151-152, which inverts no composition; with flow_number = 1, its default, the
+ * two coincide.)                                                                                              */
 int nfisam_nsf_inverse(const float* z, const float* x_sep, const float* kparams, int n, int D, int Ds,
                        int K, int H, float B, int L, size_t layer_stride, const float* mean, const float* std,
                        const uint8_t* circular, float* x_out, float* logdet, nfisam_stream_t stream);

@@ -158,6 +158,88 @@ __device__ __forceinline__ cfloat* reload_ptr(cfloat* p) {
 }
 __device__ __forceinline__ const float* reload_ptr(const float* p) { return p; }
 
+// ---- scalar-path GEMV with the NEXT weight chunk in flight ----------------------------------------------------
+// A scalar load returns out of order with the wave's other LSU traffic, so its consumer waits for `lgkmcnt(0)`:
+// load -> wait -> FMAs -> load -> wait ... exposes one scalar-cache round trip (~200-300 cycles) per chunk, and the
+// conditioner is ~10 chunks per direction.  Here chunk c+1 is requested right after chunk c has ARRIVED and before it
+// is consumed, so its round trip runs under the FMAs of chunk c.  Chunks are 32 consecutive floats (two
+// s_load_dwordx16: 64 SGPRs for the pair in flight + in use, of 102); `arrived()` is an empty asm that reads a chunk,
+// which makes the compiler place the wait there, and the scheduling fences keep the order request / consume.
+template <int N>
+__device__ __forceinline__ void chunk_arrived(const float (&w)[N]) {
+    asm volatile("" ::"s"(w[0]), "s"(w[N - 1]));
+}
+// The accumulators pass through an empty asm at every chunk boundary: without it the SLP vectoriser fuses the whole
+// eight-chunk FMA chain into one tree and emits it after the LAST load, which keeps every chunk alive (and spilled).
+template <int N>
+__device__ __forceinline__ void pin_rows(float (&acc)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) asm volatile("" : "+v"(acc[j]));
+}
+// 32 consecutive floats as two VOLATILE 64-byte scalar loads: a volatile access is neither split, merged with its
+// neighbours, hoisted nor shared with the other pass's load of the same row, so it stays where the pipeline puts it
+typedef __attribute__((ext_vector_type(16))) float wf16;
+__device__ __forceinline__ void load_chunk(cfloat* p, float (&w)[32]) {
+    typedef const volatile __attribute__((address_space(4))) wf16* vp;
+    const wf16 lo = *(vp)p, hi = *(vp)(p + 16);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { w[j] = lo[j]; w[16 + j] = hi[j]; }
+}
+// acc[j] += sum_k W[k][j] * h[k]   for a contiguous row-major W[ROWS][N] in scalar-path memory, N * G = 32 floats per chunk
+template <int N, int ROWS>
+__device__ __forceinline__ void scalar_gemv_cols(cfloat* W, const float (&h)[ROWS], float (&acc)[N]) {
+    constexpr int G = (N >= 32) ? 1 : 32 / N, CH = G * N, NC = ROWS / G;
+    static_assert(ROWS % G == 0 && N <= 32 && 32 % N == 0, "chunking");
+    float wa[CH], wb[CH];
+    load_chunk(W, wa);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float(&cur)[CH] = (c & 1) ? wb : wa;
+        float(&nxt)[CH] = (c & 1) ? wa : wb;
+        chunk_arrived<CH>(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NC) load_chunk(W + (c + 1) * CH, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < G; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = __builtin_fmaf(cur[r * N + j], h[c * G + r], acc[j]);
+        pin_rows<N>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// out[k] = sum_j W[k][j] * g[j]   (the transposed use of the same rows in the backward pass); four partial sums per row
+template <int N, int ROWS>
+__device__ __forceinline__ void scalar_gemv_rows(cfloat* W, const float (&g)[N], float (&out)[ROWS]) {
+    constexpr int G = (N >= 32) ? 1 : 32 / N, CH = G * N, NC = ROWS / G;
+    static_assert(ROWS % G == 0 && N <= 32 && 32 % N == 0, "chunking");
+    float wa[CH], wb[CH];
+    load_chunk(W, wa);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float(&cur)[CH] = (c & 1) ? wb : wa;
+        float(&nxt)[CH] = (c & 1) ? wa : wb;
+        chunk_arrived<CH>(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NC) load_chunk(W + (c + 1) * CH, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+            for (int j = 0; j + 3 < N; j += 4) {
+                p0 = __builtin_fmaf(cur[r * N + j], g[j], p0);
+                p1 = __builtin_fmaf(cur[r * N + j + 1], g[j + 1], p1);
+                p2 = __builtin_fmaf(cur[r * N + j + 2], g[j + 2], p2);
+                p3 = __builtin_fmaf(cur[r * N + j + 3], g[j + 3], p3);
+            }
+            out[c * G + r] = (p0 + p1) + (p2 + p3);
+            asm volatile("" : "+v"(out[c * G + r]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- conditioner ----------------------------------------------------------------------------
 // xs: LDS, dimension-major with row stride `xstride`: xs[k * xstride + lane] = x_k of this lane's particle.
 // WP = weight pointer type: `cfloat*` (scalar-cache path, SGPR operands) or `const float*` into an
@@ -191,12 +273,16 @@ __device__ __forceinline__ void cond_hidden(WP blk, int i, const float* xs, int 
     for (int j = 0; j < H; ++j) h1[j] = ftanh(a[j]);
     WP W1 = blk + LY::oW1(i);
     load_row<H>(blk + LY::ob1(i), a);
+    if constexpr (std::is_same<WP, cfloat*>::value && (H == 8 || H == 16)) {
+        scalar_gemv_cols<H, H>(W1, h1, a);
+    } else {
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        load_row<H>(W1 + k * H, wr);
+        for (int k = 0; k < H; ++k) {
+            load_row<H>(W1 + k * H, wr);
 #pragma unroll
-        for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], h1[k], a[j]);
-        if ((k & 7) == 7) row_group_fence<WP>();
+            for (int j = 0; j < H; ++j) a[j] = __builtin_fmaf(wr[j], h1[k], a[j]);
+            if ((k & 7) == 7) row_group_fence<WP>();
+        }
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) h2[j] = ftanh(a[j]);
@@ -207,14 +293,25 @@ __device__ __forceinline__ void cond_theta(WP blk, int i, const float (&h2)[H],
                                            float (&th)[Layout<K, H>::PoP]) {
     using LY = Layout<K, H>;
     WP W2 = blk + LY::oW2(i);
-    load_row<LY::PoP>(blk + LY::ob2(i), th);
+    if constexpr (std::is_same<WP, cfloat*>::value && LY::PoP == 32) {
+        // b2 is row H of the same block ([H + 1][PoP] contiguous): the bias rides the pipeline as one more chunk
+        float hx[H + 1];
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        float wr[LY::PoP];
-        load_row<LY::PoP>(W2 + k * LY::PoP, wr);
+        for (int k = 0; k < H; ++k) hx[k] = h2[k];
+        hx[H] = 1.0f;
 #pragma unroll
-        for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(wr[o], h2[k], th[o]);
-        if (k & 1) row_group_fence<WP>();
+        for (int o = 0; o < LY::PoP; ++o) th[o] = 0.0f;
+        scalar_gemv_cols<LY::PoP, H + 1>(W2, hx, th);
+    } else {
+        load_row<LY::PoP>(blk + LY::ob2(i), th);
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            float wr[LY::PoP];
+            load_row<LY::PoP>(W2 + k * LY::PoP, wr);
+#pragma unroll
+            for (int o = 0; o < LY::PoP; ++o) th[o] = __builtin_fmaf(wr[o], h2[k], th[o]);
+            if (k & 1) row_group_fence<WP>();
+        }
     }
 }
 

@@ -655,6 +655,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
     cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
 
+    STAMP_DECL
+    STAMP(0);
     f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -696,17 +698,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
     for (int tt = 0; tt < T; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
+        STAMP(1);
         if (!load_tile(pt)) return;
         wave_lds_sync();
+        STAMP(2);
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
-        load_theta<K, H, cfloat*>(lp, i, xt, XS, lane, h1, h2, th);
+        if (i == 0) {
+            load_row<PoP>(lp, th);
+        } else {
+            cond_hidden<K, H, cfloat*>(blk, i, xt, XS, lane, h1, h2);
+            STAMP(14);
+            cond_theta<K, H, cfloat*>(blk, i, h2, th);
+        }
+        STAMP(3);
         Spline<K> S;
         float z, lad;
         spline_eval<K, PoP, false>(xt[i * XS + lane], th, B, S, z, lad);
+        STAMP(4);
         if (valid) lossv += 0.5f * z * z - lad;
         const float gxs = spline_backward<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
         (void)gxs;
+        STAMP(5);
         if (i == 0) {   // init_param: plain sum over particles of gth
             constexpr int N0 = (PoP <= 32) ? 32 : 64;
             float v[N0];
@@ -719,32 +732,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
         // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights) ----
         float ga2[H], ga1[H];
         {
-            float gh2[H];
+            float gh2[H], gh1[H];
             cfloat* W2 = reload_ptr(blk + LY::oW2(i));
+            if constexpr (PoP == 32) {
+                scalar_gemv_rows<PoP, H>(W2, gth, gh2);
+            } else {
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                float wr[PoP];
-                load_row<PoP>(W2 + k * PoP, wr);
-                float acc = 0.0f;
+                for (int k = 0; k < H; ++k) {
+                    float wr[PoP];
+                    load_row<PoP>(W2 + k * PoP, wr);
+                    float acc = 0.0f;
 #pragma unroll
-                for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
-                gh2[k] = acc;
-                if (k & 1) row_group_fence<cfloat*>();
+                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
+                    gh2[k] = acc;
+                    if (k & 1) row_group_fence<cfloat*>();
+                }
             }
 #pragma unroll
             for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
             cfloat* W1 = reload_ptr(blk + LY::oW1(i));
+            scalar_gemv_rows<H, H>(W1, ga2, gh1);
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                float wr[H];
-                load_row<H>(W1 + k * H, wr);
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < H; ++j) acc = __builtin_fmaf(wr[j], ga2[j], acc);
-                ga1[k] = acc * (1.0f - h1[k] * h1[k]);
-                if ((k & 7) == 7) row_group_fence<cfloat*>();
-            }
+            for (int k = 0; k < H; ++k) ga1[k] = gh1[k] * (1.0f - h1[k] * h1[k]);
         }
+        STAMP(6);
         // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
         //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
         const float* pa = stg + r16 * XS + kq;
@@ -767,6 +778,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
                 wave_lds_sync();
             }
         }
+        STAMP(7);
         {   // phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
 #pragma unroll
             for (int j = 0; j < H; ++j) stg[j * XS + lane] = h1[j];
@@ -780,16 +792,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
                 stg[(H + j) * XS + lane] = ga1[j];
             }
             wave_lds_sync();
-            float areg[NS];
+            // every LDS operand is requested before the first MFMA (an MFMA that waits for its own ds_read serialises
+            // the two latencies 16 times), and the two accumulation chains alternate so that neither waits for its own
+            // previous result (32-cycle issue instead of the 40-cycle dependent latency)
+            float areg[NS], bx[NS];
+            const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;     // input columns 0..15 (column i = bias)
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { areg[s4] = pa[4 * s4]; bx[s4] = pb0[4 * s4]; }
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
-                areg[s4] = pa[4 * s4];
                 c1 = mfma4(areg[s4], breg[s4], c1);
-            }
-            {   // input columns 0..15 (column i = bias)
-                const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; c0 = mfma4(areg[s4], (r16 < i) ? v : 1.0f, c0); }
+                c0 = mfma4(areg[s4], (r16 < i) ? bx[s4] : 1.0f, c0);
             }
             for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
                 const int cab = ct * 16 + r16;
@@ -805,6 +818,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
             }
             wave_lds_sync();
         }
+        STAMP(8);
     }
 
     // ---- the wave's gradient copy of this dim ----
@@ -840,6 +854,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
         if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
         if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
     }
+    STAMP(9);
     const float tot = wave_sum(lossv);
     if (lane == 0) {
         gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +

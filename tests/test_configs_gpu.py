@@ -231,7 +231,7 @@ MANHATTAN_ARGS = dict(num_knots=9, flow_iterations=500, local_sample_num=2000, l
 
 
 @pytest.mark.parametrize("dataset,args,n_updates,rmse_each,rmse_median",
-                         [("Plaza1EFG", PLAZA_ARGS, 10, 7.0, 3.2),
+                         [("Plaza1EFG", PLAZA_ARGS, 10, 7.0, 4.0),
                           ("Manhattan200", MANHATTAN_ARGS, 12, 3.5, 2.2)],
                          ids=["plaza1-first-10-updates", "manhattan200-first-12-updates"])
 def test_dataset_first_updates_end_to_end(tmp_path, dataset, args, n_updates, rmse_each, rmse_median):
@@ -240,7 +240,8 @@ def test_dataset_first_updates_end_to_end(tmp_path, dataset, args, n_updates, rm
     posterior means stays below `rmse_each` metres and the median below `rmse_median`.  Calibration (8 seeds on
     MI355X, gpurun_out/r2c): Plaza1 after 10 updates (50 poses) 0.5-4.5 m, median 2.1 m -- the landmarks are still
     unresolved there, so the trajectory is odometry-bound: dead reckoning alone is 1.55 m off the GPS truth over
-    these poses; a mirrored-mode failure shows as > 10 m.  Manhattan-200 after 12 updates: 1.3-2.2 m, median 1.4 m."""
+    these poses; a mirrored-mode failure shows as > 10 m (the median of 3 draws from that spread moves with every
+    change of kernel rounding: 2.1-3.3 m seen, hence 4.0).  Manhattan-200 after 12 updates: 1.3-2.2 m, median 1.4 m."""
     rmses = []
     for seed in range(3):
         sub = tmp_path / ("seed%d" % seed)

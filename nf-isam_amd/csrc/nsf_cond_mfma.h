@@ -1,0 +1,285 @@
+// The conditioner on the matrix cores WITHOUT leaving the particle-per-lane layout (dim-major training kernel).
+//
+// v_mfma_f32_4x4x1_16b_f32 runs sixteen independent 4x4 outer products, one per block of four lanes:
+//     D[r](lane) = C[r](lane) + A(lane 4*(lane/4) + r) * B(lane)          (checked on gfx950: scripts/exp/mfma4x4.hip)
+// With B = the lane's OWN activation and A = the weights of four output rows parked on the four lanes of every block,
+// one instruction is four FMAs per lane, exact fp32, and its result registers are already "particle on the lane, four
+// consecutive outputs in the four registers" -- the layout the spline needs.  The mat-vec products
+//     a1 = W0^T x[:i] + b0,   a2 = W1^T h1 + b1,   theta = W2^T h2 + b2            (src/flows/flows.py:26-41, 82-83)
+// and their transposes in the backward pass become chains of these instructions fed by 16-byte LDS reads of a weight
+// PANEL (one read = the A operands of four instructions); biases initialise the accumulators.
+// Against the scalar-path FMAs this removes every `s_waitcnt lgkmcnt(0)` in front of a weight row (~25 exposed
+// scalar-cache round trips per unit), the ~100 weight SGPRs and their spills, and 3/4 of the instruction slots.
+// (It does not buy parallel issue: on gfx950 MFMA and VALU instructions of a SIMD do not overlap -- 8 x 16x16x4 + 32
+// v_fma per round take the SUM of their separate times, scripts/exp/mfma4x4.hip -- a 4x4x1 costs ~9.5 cycles, the four
+// v_fma it replaces ~10.5.)
+//
+// Panel (floats, per block = one (clique, dim); staged once per launch by the block's waves), ST = H | 4:
+//   W2T [PoP][ST]   W2T[o][k] = W2[k][o]            forward, layer 2          b2 [PoP]
+//   W1T [H][ST]     W1T[j][k] = W1[k][j]            forward, layer 1          b1 [H]
+//   W2N [H][PoP+4]  W2N[k][o] = W2[k][o]            backward, layer 2
+//   W1N [H][ST]     W1N[k][j] = W1[k][j]            backward, layer 1
+//   W0T [H][s0]     W0T[j][k] = W0[k][j], zero for k >= i; s0 = 8*ceil(i/8) + 4     forward, layer 0      b0 [H]
+// Row strides are odd multiples of 4 floats: 16-byte reads, and the four rows one read touches (lane & 3) fall into
+// different banks.
+#pragma once
+#include "nsf_device.h"
+
+typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ cm_f32x4 mfma1(float a, float b, cm_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+template <int K, int H>
+struct CondPanel {
+    using LY = Layout<K, H>;
+    static constexpr int PoP = LY::PoP;
+    static constexpr int ST = H | 4;
+    static constexpr int GH = H / 4, G2 = PoP / 4;
+    static constexpr int NS2 = PoP + 4;
+    static constexpr int oW2T = 0;
+    static constexpr int ob2 = oW2T + PoP * ST;
+    static constexpr int oW1T = ob2 + PoP;
+    static constexpr int ob1 = oW1T + H * ST;
+    static constexpr int oW2N = ob1 + H;
+    static constexpr int oW1N = oW2N + H * NS2;
+    static constexpr int ob0 = oW1N + H * ST;
+    static constexpr int oW0T = ob0 + H;
+    static_assert(H % 4 == 0 && PoP % 8 == 0, "output rows come in groups of four");
+    __host__ __device__ static constexpr int s0_of(int i) { return ((i + 7) & ~7) + 4; }
+    __host__ __device__ static constexpr int floats(int max_D) { return oW0T + H * s0_of(max_D > 1 ? max_D - 1 : 1); }
+};
+// theta column o is a spline parameter (not layout padding): nsf_device.h Layout::iw / ih / idv
+template <int K, int H>
+struct ThetaColUsed {
+    using LY = Layout<K, H>;
+    __host__ __device__ static constexpr bool at(int o) { return (o % LY::HP) < K + (o < LY::HP ? LY::ND0 : LY::ND1); }
+};
+struct EveryCol {
+    __host__ __device__ static constexpr bool at(int) { return true; }
+};
+
+// The previous iteration's Adam update, applied on the way into the panel ("fused Adam").
+// A kernel boundary costs ~3 us on this chip (end-of-kernel L2 write-back, dispatch, cache invalidation) and a
+// device-wide hand-over inside a kernel costs the same (agent-scope release = L2 write-back across eight XCDs), so a
+// separate Adam launch per iteration is a third of a latency-bound iteration.  In the dim-major kernel a (clique, dim)
+// block of parameters is read by that dim's blocks only: each of them re-derives the updated block from the previous
+// launch's gradient copies (same summation order and arithmetic as nsf_adam_kernel: bit-identical), stages it, and
+// the dim's first block also writes the new parameters / moments to the OTHER of two state buffers (nobody may
+// overwrite what late-starting blocks of the same launch still read; the gradient copies alternate likewise).
+struct FusedAdam {
+    const __attribute__((address_space(1))) float* grads;   // previous launch's gradient copies (copy 0), or nullptr: nothing pending
+    size_t gstride;                                          // floats between copies
+    int copies;                                              // copies of this clique
+    const __attribute__((address_space(1))) float *m_src, *v_src;
+    __attribute__((address_space(1))) float *t_dst, *m_dst, *v_dst;   // written by the dim's first block only (else nullptr)
+    AdamCoef kc;
+};
+
+// parameter `j` (index into the clique's parameter vector) after the pending update; writes the new state if asked to
+__device__ __forceinline__ float fused_adam_param(const FusedAdam& fa, const __attribute__((address_space(1))) float* t_src,
+                                                  int j, bool live) {
+    float tj = t_src[j];
+    if (fa.grads == nullptr) return tj;                      // launch-uniform
+    float gv[8];                                             // at most 8 copies (the host checks), summed as nsf_adam_kernel does
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float g = fa.grads[(size_t)(c < fa.copies ? c : 0) * fa.gstride + j];
+        gv[c] = (c < fa.copies) ? g : 0.0f;
+    }
+    float gs = gv[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) gs += gv[c];
+    float mj = fa.m_src[j], vj = fa.v_src[j];
+    adam_update(fa.kc, gs, mj, vj, tj);
+    if (fa.t_dst != nullptr && live) { fa.t_dst[j] = tj; fa.m_dst[j] = mj; fa.v_dst[j] = vj; }
+    return tj;
+}
+
+// The block's 256 threads bring dim i's parameter block (i > 0: conditioner weights -> panel; i == 0: the PoP spline
+// parameters -> pan[0..PoP)) into LDS; a workgroup barrier follows at the call site.  Thread t owns parameters
+// t, t + 256, ... of the block: two at a time, every global load of both issued before the first use.  Padding no
+// 16-byte read ever touches is not written; the zero weights behind W0's i rows are (layer 0 contracts whole groups
+// of eight inputs).
+template <int K, int H>
+__device__ __forceinline__ void stage_cond_panel(float* pan, const float* theta_generic, const FusedAdam& fa, int i, int tid) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    gp t_src = (gp)theta_generic;                              // the clique's parameter vector (before the pending update)
+    constexpr int PoP = CP::PoP, ST = CP::ST, NT = 256;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    const int s0 = CP::s0_of(i);
+    auto place = [&](int jj, float v) {
+        if (i == 0) { pan[jj] = v; return; }
+        if (jj < LY::ob0(i)) {
+            const int k = jj / H, j = jj - k * H;
+            pan[CP::oW0T + j * s0 + k] = v;
+        } else if (jj < LY::oW1(i)) {
+            pan[CP::ob0 + (jj - LY::ob0(i))] = v;
+        } else if (jj < LY::ob1(i)) {
+            const int e = jj - LY::oW1(i), k = e / H, j = e - k * H;
+            pan[CP::oW1T + j * ST + k] = v;
+            pan[CP::oW1N + k * ST + j] = v;
+        } else if (jj < LY::oW2(i)) {
+            pan[CP::ob1 + (jj - LY::ob1(i))] = v;
+        } else if (jj < LY::ob2(i)) {
+            const int e = jj - LY::oW2(i), k = e / PoP, o = e - k * PoP;
+            pan[CP::oW2T + o * ST + k] = v;
+            pan[CP::oW2N + k * CP::NS2 + o] = v;
+        } else {
+            pan[CP::ob2 + (jj - LY::ob2(i))] = v;
+        }
+    };
+    for (int base = 0; base < nj; base += 2 * NT) {
+        const int ja = base + tid, jb = base + NT + tid;
+        const float va = fused_adam_param(fa, t_src, j0 + (ja < nj ? ja : 0), ja < nj);
+        const float vb = fused_adam_param(fa, t_src, j0 + (jb < nj ? jb : 0), jb < nj);
+        if (ja < nj) place(ja, va);
+        if (jb < nj) place(jb, vb);
+    }
+    if (i > 0) {
+        const int npad = (((i + 7) & ~7) - i) * H;             // zero weights behind W0's rows
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            pan[CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+}
+
+// acc[g * SPLIT + (q % SPLIT)][u] += sum over the quads q < NK/4 of  A[4g + u][4q + v] * b[4q + v]
+// for the NG output groups g; `rows` = the panel matrix at this lane's row (base + (lane & 3) * stride).
+// Software pipeline: the reads of slab s+1 (SG groups x one quad, 16 bytes each) are issued before the MFMAs of slab s,
+// and inside a slab the instructions of the SG (x SPLIT) independent chains alternate -- left to itself the scheduler
+// minimises registers instead: read, wait, four dependent MFMAs with s_nop between them, next read.
+template <int NG, int NK, int SG, int SPLIT, class USED>
+__device__ __forceinline__ void mfma_rows(const float* rows, int stride, cm_f32x4 (&acc)[NG * SPLIT], const float (&b)[NK]) {
+    static_assert(NK % 4 == 0 && NG % SG == 0, "whole quads, whole slabs");
+    constexpr int NQ = NK / 4, NGS = NG / SG, NSLAB = NQ * NGS;
+    cm_f32x4 buf[2][SG];
+#pragma unroll
+    for (int gg = 0; gg < SG; ++gg) buf[0][gg] = *(const cm_f32x4*)(rows + 4 * gg * stride);
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = s / NGS, gs = s % NGS;
+        if (s + 1 < NSLAB) {
+            const int qn = (s + 1) / NGS, gn = (s + 1) % NGS;
+#pragma unroll
+            for (int gg = 0; gg < SG; ++gg)
+                buf[(s + 1) & 1][gg] = *(const cm_f32x4*)(rows + 4 * (gn * SG + gg) * stride + 4 * qn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int gg = 0; gg < SG; ++gg)
+                if (USED::at(4 * q + u)) {
+                    cm_f32x4& c = acc[(gs * SG + gg) * SPLIT + (q % SPLIT)];
+                    c = mfma1(buf[s & 1][gg][u], b[4 * q + u], c);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// theta and the hidden activations of dim i for the lane's particle; xt = the wave's tile [rows][xs], rows 0..i loaded
+template <int K, int H>
+__device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const float* xt, int xs, int lane,
+                                                  float (&h1)[H], float (&h2)[H], float (&th)[Layout<K, H>::PoP]) {
+    using CP = CondPanel<K, H>;
+    constexpr int ST = CP::ST, GH = CP::GH, G2 = CP::G2, SP = (H >= 8) ? 2 : 1;
+    const int r = lane & 3;
+    const cm_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    {   // layer 0: the only contraction whose length depends on the dim: eight inputs per round (zero weights past i,
+        // the clamped row keeps the activation finite), four chains (group x quad parity)
+        cm_f32x4 a1[GH][2];
+#pragma unroll
+        for (int g = 0; g < GH; ++g) { a1[g][0] = *(const cm_f32x4*)(pan + CP::ob0 + 4 * g); a1[g][1] = zero; }
+        const int s0 = CP::s0_of(i);
+        const float* w0 = pan + CP::oW0T + r * s0;
+        for (int k0 = 0; k0 < i; k0 += 8) {
+            float xk[8];
+            cm_f32x4 a4[GH][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u; xk[u] = xt[(k < i ? k : i) * xs + lane]; }
+#pragma unroll
+            for (int g = 0; g < GH; ++g)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a4[g][q] = *(const cm_f32x4*)(w0 + 4 * g * s0 + k0 + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < GH; ++g)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) a1[g][q] = mfma1(a4[g][q][u], xk[4 * q + u], a1[g][q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h1[4 * g + u] = ftanh(a1[g][0][u] + a1[g][1][u]);
+    }
+    {
+        cm_f32x4 a2[GH * SP];
+#pragma unroll
+        for (int g = 0; g < GH; ++g) {
+            a2[g * SP] = *(const cm_f32x4*)(pan + CP::ob1 + 4 * g);
+            if (SP == 2) a2[g * SP + 1] = zero;
+        }
+        mfma_rows<GH, H, GH, SP, EveryCol>(pan + CP::oW1T + r * ST, ST, a2, h1);
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h2[4 * g + u] = ftanh(SP == 2 ? a2[g * SP][u] + a2[g * SP + 1][u] : a2[g][u]);
+    }
+    {
+        cm_f32x4 t[G2];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) t[g] = *(const cm_f32x4*)(pan + CP::ob2 + 4 * g);
+        mfma_rows<G2, H, 2, 1, EveryCol>(pan + CP::oW2T + r * ST, ST, t, h2);
+#pragma unroll
+        for (int g = 0; g < G2; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) th[4 * g + u] = t[g][u];
+    }
+}
+
+// ga2 = dL/da2, ga1 = dL/da1 of the lane's particle from gth = dL/dtheta (the transposed products of the same rows);
+// padding columns of the theta layout carry no gradient and are skipped
+template <int K, int H>
+__device__ __forceinline__ void cond_backward_mfma(const float* pan, int lane, const float (&gth)[Layout<K, H>::PoP],
+                                                   const float (&h1)[H], const float (&h2)[H],
+                                                   float (&ga2)[H], float (&ga1)[H]) {
+    using CP = CondPanel<K, H>;
+    constexpr int PoP = CP::PoP, GH = CP::GH, SP = (H >= 8) ? 2 : 1;
+    const int r = lane & 3;
+    const cm_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    {
+        cm_f32x4 s[GH * 2];
+#pragma unroll
+        for (int g = 0; g < GH * 2; ++g) s[g] = zero;
+        mfma_rows<GH, PoP, GH, 2, ThetaColUsed<K, H>>(pan + CP::oW2N + r * CP::NS2, CP::NS2, s, gth);
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float h = h2[4 * g + u];
+                ga2[4 * g + u] = (s[2 * g][u] + s[2 * g + 1][u]) * (1.0f - h * h);
+            }
+    }
+    {
+        cm_f32x4 t[GH * SP];
+#pragma unroll
+        for (int g = 0; g < GH * SP; ++g) t[g] = zero;
+        mfma_rows<GH, H, GH, SP, EveryCol>(pan + CP::oW1N + r * CP::ST, CP::ST, t, ga2);
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float h = h1[4 * g + u];
+                ga1[4 * g + u] = (SP == 2 ? t[g * SP][u] + t[g * SP + 1][u] : t[g][u]) * (1.0f - h * h);
+            }
+    }
+}

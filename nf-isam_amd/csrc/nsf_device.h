@@ -91,6 +91,55 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- Adam (torch.optim.Adam as the reference drives it, NFiSAM.py:425, 476-478) ---------------------------------
+// One copy of the arithmetic for the stand-alone Adam kernel and the update fused into the dim-major training
+// kernel's tail: explicit round-to-nearest operations, so that -ffp-contract cannot fuse them differently in the two
+// places and both produce the same bits from the same gradient sum.
+struct AdamCoef { float b1, b2, step_size, inv_bc2s, eps, inv_n; };
+// a product that must not be fused into the addition that consumes it: the empty asm makes it opaque
+// (`#pragma clang fp contract(off)` is not honoured once the function is inlined into a -ffp-contract=fast kernel)
+__device__ __forceinline__ float rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// 1 - beta^t from ln(beta): explicit operations only (a library expm1f inlined into two kernels came out an ulp apart),
+// relative error < 5e-7: the series of -expm1(x) while |x| < 1/4, else 1 - 2^(x log2 e) on the hardware exp2
+__device__ __forceinline__ float one_minus_pow(float log_b, int t) {
+    const float x = rounded((float)t * log_b);
+    if (x > -0.25f) {
+        float p = rounded(x * (1.0f / 5040.0f)) + (1.0f / 720.0f);
+        p = rounded(p * x) + (1.0f / 120.0f);
+        p = rounded(p * x) + (1.0f / 24.0f);
+        p = rounded(p * x) + (1.0f / 6.0f);
+        p = rounded(p * x) + 0.5f;
+        p = rounded(p * x) + 1.0f;
+        return -rounded(p * x);
+    }
+    return 1.0f - __builtin_amdgcn_exp2f(rounded(x * 1.4426950408889634f));
+}
+__device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, float log_b1, float log_b2, int t, int n) {
+    AdamCoef k;
+    const float bc1 = one_minus_pow(log_b1, t), bc2 = one_minus_pow(log_b2, t);
+    k.b1 = b1; k.b2 = b2; k.eps = eps;
+    k.step_size = lr / bc1;
+    k.inv_bc2s = 1.0f / sqrtf(bc2);
+    k.inv_n = 1.0f / (float)n;
+    return k;
+}
+__device__ __forceinline__ void adam_update(const AdamCoef& k, float gsum, float& m, float& v, float& theta) {
+    const float g = rounded(gsum * k.inv_n);
+    const float c1 = 1.0f - k.b1, c2 = 1.0f - k.b2;
+    const float m1 = rounded(k.b1 * m), m2 = rounded(c1 * g);
+    m = m1 + m2;
+    const float v1 = rounded(k.b2 * v), v2 = rounded(rounded(c2 * g) * g);
+    v = v1 + v2;
+    const float sq = rounded(sqrtf(v) * k.inv_bc2s);
+    const float denom = sq + k.eps;
+    const float num = rounded(k.step_size * m);
+    const float upd = rounded(num / denom);
+    theta = theta - upd;
+}
+
 // ---- weight rows ------------------------------------------------------------------------------
 // A row of N (multiple of 4) wave-uniform weights.  Scalar-cache path: plain indexing (the
 // compiler merges into s_load_dwordx{4,8,16}); LDS path: explicit 16-byte broadcast reads

@@ -37,6 +37,8 @@ constexpr int XS = 66;            // LDS row stride (floats) of every [feature][
 // iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
 // bookkeeping kernel that closes a chunk of iterations consumes and clears them.
 constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
+// fused Adam: one sign-off counter per dim behind the loss ring; at most this many gradient copies per clique
+constexpr int FUSED_COUNTERS = 64, FUSED_MAX_COPIES = 32;
 
 struct TrainArgs {
     const nfisam_clique* cliques;   // device array (batched) or nullptr
@@ -58,6 +60,9 @@ struct TrainArgs {
     int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
     int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
     int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
+    int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
+    nfisam_adam_cfg adam;
+    float log_b1, log_b2;
 };
 
 
@@ -110,13 +115,18 @@ static inline int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: a
 // launch leaves SIMDs idle -- it halves the instructions per wave and doubles the waves -- and "wide" (one
 // lane per particle, 64-particle tiles: no duplicated scalar spline work, half the gradient copies) once the
 // chip is full.  NFISAM_TRAIN=wide|split forces one family (A/B measurements).  The split kernel exists for H == 8.
-static inline int train_tile(int n_cliques, int max_n, int max_D, int H) {
+// `nll_L1`: a training iteration of a one-layer flow (no upstream gradient): the dim-major kernel takes it at every size
+// (with the Adam update fused into the next launch it beats the two-lanes-per-particle kernel from D = 2, n = 500 up,
+// scripts/exp/regime_grid.sh); VJP launches and L > 1 keep the split kernel while the launch is small.
+static inline bool dim_major_enabled();
+static inline int train_tile(int n_cliques, int max_n, int max_D, int H, bool nll_L1 = false) {
     if (H != 8) return TILE;
     const char* e = getenv("NFISAM_TRAIN");            // read per call: tests switch families in-process
     if (e != nullptr) {
         if (strcmp(e, "wide") == 0) return TILE;
         if (strcmp(e, "split") == 0) return TILE2;
     }
+    if (nll_L1 && dim_major_enabled()) return TILE;
     const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
     return waves <= 1280 ? TILE2 : TILE;
 }
@@ -127,9 +137,29 @@ static inline bool dim_major_enabled() {
     const char* e = getenv("NFISAM_DIM_MAJOR");
     return !(e != nullptr && e[0] == '0');
 }
+// LDS rows (of XS floats) of one wave of the dim-major kernel: particle tile [max_D] + staging [16] + h1 [H] + (D > 16) the
+// rows 16.. of dW0 summed over the wave's tiles
+__host__ __device__ static inline int train1_wave_rows(int max_D, int H) {
+    return max_D + 16 + H + (max_D > 16 ? ((max_D - 16) * H + XS - 1) / XS : 0);
+}
+// conditioner of the dim-major kernel: v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h) unless
+// NFISAM_COND=scalar (VALU FMAs with scalar-path weights) or the block is not the four waves the panel copy assumes
+static inline int dim_major_waves() {
+    const char* e = getenv("NFISAM_BIG_W");
+    return (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) ? atoi(e) : 4;
+}
+static inline bool dim_major_mfma_cond() {
+    const char* ce = getenv("NFISAM_COND");
+    return dim_major_waves() == 4 && !(ce != nullptr && strcmp(ce, "scalar") == 0);
+}
+// smallest launch ((tile, dim) units) that goes to the dim-major kernel; NFISAM_DIM_MAJOR_MIN overrides (experiments)
+static inline long dim_major_min_units() {
+    const char* e = getenv("NFISAM_DIM_MAJOR_MIN");
+    return e != nullptr ? atol(e) : 0;
+}
 static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
-    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && tiles * max_D > 1024;
+    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && tiles * max_D > dim_major_min_units();
 }
 
 // 64-particle tiles summed into one gradient copy (one wave's sweep in nsf_train1_kernel, one block's in
@@ -140,7 +170,7 @@ static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int 
 static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
     if (tile != TILE || L != 1 || !use_mfma_grad(H)) return 1;
     const long tiles_c = (max_n + TILE - 1) / TILE, tiles = tiles_c * n_cliques;
-    if (tiles * max_D <= 1024) return 1;
+    if (tiles * max_D <= dim_major_min_units()) return 1;
     const char* e = getenv("NFISAM_TILES_PER_BLOCK");
     int T = 1;
     if (is_dim_major(n_cliques, max_n, max_D, L, tile, H)) {

@@ -26,6 +26,8 @@ struct AdamArgs {
     int chunk;              // bookkeeping kernel: iterations to close
     int max_n;              // largest n of the batch (number of slabs in every workspace)
     int few_copies;         // every clique has <= 8 gradient copies: one thread per parameter
+    int close_chunk;        // > 0: fused-Adam launches (nsf_cond_mfma.h): apply the LAST iteration's pending update of a chunk of
+                            // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
 };
 
 __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
@@ -49,7 +51,8 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const int pj0 = threadIdx.x & 31, tl0 = threadIdx.x >> 5, jf = blockIdx.x * 32 + pj0;
     const int n_tiles0 = a.slab ? (n + a.slab - 1) / a.slab : 1;
     float pre_g = 0.0f, pre_m = 0.0f, pre_v = 0.0f, pre_t = 0.0f;
-    if (jf < P && !a.few_copies) {
+    const bool closing = a.close_chunk > 0;
+    if (jf < P && !a.few_copies && !closing) {
 #pragma unroll 8
         for (int tt = tl0; tt < n_tiles0; tt += 8) pre_g += G[(size_t)tt * P + jf];
         if (tl0 == 0) { pre_m = m[jf]; pre_v = v[jf]; pre_t = theta[jf]; }
@@ -59,15 +62,27 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const int t = s_step + a.iter_idx + 1;
+    int iter_idx = a.iter_idx;
+    const float *ms = m, *vs = v, *ts = theta;                  // source state (the destination is always the clique's own)
+    if (closing) {
+        // the chunk's last valid iteration: its gradient copies and the state it started from are in the buffers of its
+        // parity (odd: the second set behind the loss ring, see nsf_train1_kernel)
+        const int left = a.cfg.max_iters - s_step;
+        const int cnt = a.close_chunk < left ? a.close_chunk : left;
+        if (cnt <= 0) return;
+        iter_idx = cnt - 1;
+        if (iter_idx & 1) {
+            const size_t copies_max = (size_t)((a.max_n + a.slab - 1) / a.slab);
+            G += copies_max * (size_t)P + (size_t)LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+            ts = G + copies_max * (size_t)P;
+            ms = ts + P;
+            vs = ms + P;
+        }
+    }
+    const int t = s_step + iter_idx + 1;
     if (s_stop != 0 || t > a.cfg.max_iters) return;
 
-    const float b1 = a.cfg.beta1, b2 = a.cfg.beta2;
-    const float bc1 = -expm1f((float)t * a.log_b1);
-    const float bc2 = -expm1f((float)t * a.log_b2);
-    const float step_size = a.cfg.lr / bc1;
-    const float inv_bc2s = 1.0f / sqrtf(bc2);
-    const float inv_n = 1.0f / (float)n;
+    const AdamCoef kc = adam_coef(a.cfg.lr, a.cfg.beta1, a.cfg.beta2, a.cfg.eps, a.log_b1, a.log_b2, t, n);
     if (a.slab && n_tiles0 <= 8 && a.few_copies) {
         // few gradient copies (throughput launches: one copy per T tiles): one thread per parameter, the copies summed
         // in copy order (bitwise-reproducible), every load independent of the others
@@ -75,16 +90,14 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
             float gv[8];
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) gv[tt] = (tt < n_tiles0) ? G[(size_t)tt * P + j] : 0.0f;
-            const float mo = m[j], vo = v[j], to = theta[j];
+            float mj = ms[j], vj = vs[j], tj = ts[j];
             float gs = gv[0];
 #pragma unroll
             for (int tt = 1; tt < 8; ++tt) gs += gv[tt];
-            const float g = gs * inv_n;
-            const float mj = b1 * mo + (1.0f - b1) * g;
-            const float vj = b2 * vo + (1.0f - b2) * g * g;
+            adam_update(kc, gs, mj, vj, tj);
             m[j] = mj;
             v[j] = vj;
-            theta[j] = to - step_size * mj / (sqrtf(vj) * inv_bc2s + a.cfg.eps);
+            theta[j] = tj;
         }
         return;
     }
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     for (int j0 = blockIdx.x * 32; j0 < P; j0 += gridDim.x * 32) {
         const int j = j0 + pj;
         float part = 0.0f;
-        if (first) {
+        if (first && !closing) {
             part = pre_g;
         } else if (j < P) {
 #pragma unroll 8
@@ -110,14 +123,12 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
             float gs = s_part[0][pj];
 #pragma unroll
             for (int q = 1; q < 8; ++q) gs += s_part[q][pj];
-            const float g = gs * inv_n;
-            const float mo = first ? pre_m : m[j], vo = first ? pre_v : v[j], to = first ? pre_t : theta[j];
-            const float mj = b1 * mo + (1.0f - b1) * g;
-            const float vj = b2 * vo + (1.0f - b2) * g * g;
+            const bool pre = first && !closing;
+            float mj = pre ? pre_m : ms[j], vj = pre ? pre_v : vs[j], tj = pre ? pre_t : ts[j];
+            adam_update(kc, gs, mj, vj, tj);
             m[j] = mj;
             v[j] = vj;
-            const float denom = sqrtf(vj) * inv_bc2s + a.cfg.eps;
-            theta[j] = to - step_size * mj / denom;
+            theta[j] = tj;
             if (!a.slab) G[j] = 0.0f;
         }
         __syncthreads();
@@ -478,7 +489,10 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
     const size_t tiles = use_slabs(n, TILE2) ? (size_t)((n + TILE2 - 1) / TILE2)
                                              : (use_slabs(n, TILE) ? (size_t)((n + TILE - 1) / TILE) : 1);
-    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS;
+    // + the fused-Adam launches' second set of gradient copies (64-particle tiles) and second state buffer (theta | m | v)
+    const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
+    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3) * kcount(D, K, H) : 0;
+    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS + (size_t)FUSED_COUNTERS + fused;
 }
 
 // Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
@@ -486,18 +500,36 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
 struct TrainShape { int tile, T, slab; };
 static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H) {
     TrainShape sh;
-    sh.tile = train_tile(n_cliques, max_n, max_D, H);
+    sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1);
     sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile, H);
     sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
+    if (sh.slab != 0 && is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H)) sh.slab *= dim_major_waves();   // one copy per block
     return sh;
 }
 
+// The Adam update of iteration j rides at the START of iteration j+1's gradient kernel (nsf_train1_kernel with the
+// MFMA conditioner, nsf_cond_mfma.h) when the launch is dim-major with few gradient copies; the chunk's last update is
+// applied by nsf_adam_kernel in `close_chunk` mode.  Saves one kernel boundary (~3-4 us) per iteration.
+static bool fused_adam_shape(int n_cliques, int max_n, int max_D, int L, int H, const TrainShape& sh) {
+    const char* e = getenv("NFISAM_FUSED_ADAM");
+    if (e != nullptr && e[0] == '0') return false;
+    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.slab == 0 || !dim_major_mfma_cond()) return false;
+    return (max_n + sh.slab - 1) / sh.slab <= 8;              // nsf_adam_kernel's one-thread-per-parameter summation order
+}
+
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                        int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s) {
+                        int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
+                        const nfisam_adam_cfg* fused_cfg = nullptr) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
     a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab;
+    if (fused_cfg != nullptr) {
+        a.fused_adam = 1;
+        a.adam = *fused_cfg;
+        a.log_b1 = (float)log((double)fused_cfg->beta1);
+        a.log_b2 = (float)log((double)fused_cfg->beta2);
+    }
     a.cliques = dev_cliques;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
@@ -522,8 +554,10 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
                         hipStream_t s) {
-    int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s);
-    if (rc) return rc;
+    const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H));
+    int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
+                          fused ? cfg : nullptr);
+    if (rc || fused) return rc;
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
     ad.iter_idx = iter_idx;
@@ -548,6 +582,25 @@ static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_cl
     hipLaunchKernelGGL(nsf_bookkeep_kernel, dim3(n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
+}
+
+// end of a chunk: (fused-Adam launches) the last iteration's pending update, then the bookkeeping
+static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
+                             int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s) {
+    if (fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H)) &&
+        getenv("NFISAM_DEBUG_SKIP_CLOSE") == nullptr) {
+        AdamArgs ad;
+        fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
+        ad.close_chunk = chunk;
+        const size_t Pmax = (size_t)L * kcount(max_D, K, H);
+        ad.few_copies = ((max_n + ad.slab - 1) / ad.slab <= 8) ? 1 : 0;
+        int ablocks = ad.few_copies ? (int)((Pmax + 255) / 256) : (int)((Pmax + 31) / 32);
+        if (ablocks < 1) ablocks = 1;
+        if (ablocks > 256) ablocks = 256;
+        hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
+        HIP_TRY(hipGetLastError());
+    }
+    return enqueue_bookkeeping(dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg, chunk, s);
 }
 
 // Iterations per chunk: the early-stop rule is evaluated when a chunk is closed, so the chunk length has to
@@ -591,7 +644,7 @@ extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques
     if (cliques_on_host && n_cliques != 1) return NFISAM_ERR_ARG;
     rc = enqueue_step(dev, single, n_cliques, max_n, max_D, K, H, B, L, cfg, 0, (hipStream_t)stream);
     if (rc) return rc;
-    return enqueue_bookkeeping(dev, single, n_cliques, max_n, max_D, K, H, L, cfg, 1, (hipStream_t)stream);
+    return enqueue_chunk_end(dev, single, n_cliques, max_n, max_D, K, H, L, cfg, 1, (hipStream_t)stream);
 }
 
 // ---- training plan: descriptors + (optionally) a hipGraph of `chunk` iterations, built once ----
@@ -654,8 +707,8 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
             for (int it = 0; it < p->chunk && status == NFISAM_OK; ++it)
                 status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap);
             if (status == NFISAM_OK)
-                status = enqueue_bookkeeping(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
-                                             p->cap);
+                status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
+                                           p->cap);
             e = hipStreamEndCapture(p->cap, &p->graph);
         }
         if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
@@ -709,8 +762,8 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
                                       &p->cfg, it, work);
                 if (rc) return fail(rc);
             }
-            int rcb = enqueue_bookkeeping(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
-                                          todo, work);
+            int rcb = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
+                                        todo, work);
             if (rcb) return fail(rcb);
         }
         done += p->chunk;

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "nsf_host.h"
+#include "nsf_cond_mfma.h"
 
 #ifndef NSF_UNIT
 #error "compile with -DNSF_UNIT=<unit index> (see nsf_units.h)"
@@ -112,6 +113,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ unsigned long long g_stamps[64 * 32];
 __device__ unsigned long long g_blk[4096 * 2];
 __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
+#if NSF_STAMPS == 2      // light: the raw stamp only (no per-phase accumulators: they cost 32 registers and distort the kernel)
+#define STAMP_DECL
+#define STAMP(id)                                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)                                        \
+            g_stamps[((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32 + (id)] = t_;                 \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#else
 #define STAMP_DECL unsigned long long sacc_[16] = {0ull}; unsigned long long sprev_ = 0ull;
 #define STAMP(id)                                                                                   \
     do {                                                                                            \
@@ -131,6 +144,7 @@ __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
         }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
+#endif
 extern "C" int nfisam_debug_read_blocks(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 4096 * 2);
 }
@@ -610,8 +624,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, 8
 // parked in registers while the staging rows are re-used for the other operand): 8.4 KB at D = 15, so the
 // register allocation (OCC) decides the occupancy, not LDS.
 // =============================================================================================
-template <int K, int H, int OCC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) nsf_train1_kernel(TrainArgs a) {
+template <int K, int H, int CM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
@@ -636,7 +650,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
     const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
     const int slot = blockIdx.x * W + w;                      // this wave's gradient copy
     const int p0 = slot * TILE * T;
-    if (p0 >= n) return;
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+    STAMP(10);
+#endif
+    if (CM == 0 && p0 >= n) return;
     int st_stop = 0, st_step = 0;
     if (st != nullptr) {
         st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -646,10 +663,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
     const bool slab = a.slab != 0;
     const size_t gstride = (size_t)LY::count(D);
     gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
-    if (slab) G += (size_t)slot * gstride;
+    // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
+    // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
+    const int par = (CM != 0 && a.fused_adam != 0) ? (a.iter_idx & 1) : 0;
+    const bool pending = CM != 0 && a.fused_adam != 0 && a.iter_idx > 0;
+    gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+    gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
+    const gfloat* Gprev = par ? G : Gset1;                    // copy 0 of the previous iteration
+    if (par) G = Gset1;
+    if (slab) G += (size_t)blockIdx.x * gstride;              // one gradient copy per block
     const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
-    float* xt = smem + (size_t)w * ((xrows + 16) * XS);       // [xrows][XS] particle tile, dimension-major
+    const float* pan = smem;                                  // CM: the block's conditioner panel (nsf_cond_mfma.h)
+    const int wave_rows = train1_wave_rows(xrows, H);
+    float* tiles0 = smem + (CM ? CondPanel<K, H>::floats(xrows) : 0);
+    float* xt = tiles0 + (size_t)w * (wave_rows * XS);        // [xrows][XS] particle tile, dimension-major
     float* stg = xt + xrows * XS;                             // [16][XS] staging rows
+    float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
+    float* ctacc = hrow + H * XS;                             // D > 16: dW0 rows 16.. of the wave, summed over its tiles
     const int r16 = lane & 15, kq = lane >> 4;
     cfloat* lp = (cfloat*)kparams;
     cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
@@ -665,51 +695,106 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
     // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
     // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
     // arithmetic, no column the dim does not need.  Rows beyond n re-read row n-1 (masked out of loss and gradient).
+    // Fetch (global -> registers) and store (registers -> LDS) are separate so that the first tile's loads are in
+    // flight while the block stages its weight panel.
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    auto load_tile = [&](int pt) {
+    auto fetch = [&](int pt, int c0, float (&xr)[16]) {
         const int pr = (pt + lane < n) ? pt + lane : n - 1;
         const gfloat* row = x + (size_t)pr * D;
-        for (int c0 = 0; c0 <= i; c0 += 16) {
-            float xr[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = c0 + 4 * q;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k <= i) {                                 // wave-uniform
-                    if (k + 3 < D) {
-                        const f32x4u u = *(const __attribute__((address_space(1))) f32x4u*)(row + k);
-                        v = f32x4{u.x, u.y, u.z, u.w};
-                    } else {
-                        v.x = row[k];
-                        if (k + 1 < D) v.y = row[k + 1];
-                        if (k + 2 < D) v.z = row[k + 2];
-                    }
+        for (int q = 0; q < 4; ++q) {
+            const int k = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k <= i) {                                 // wave-uniform
+                if (k + 3 < D) {
+                    const f32x4u u = *(const __attribute__((address_space(1))) f32x4u*)(row + k);
+                    v = f32x4{u.x, u.y, u.z, u.w};
+                } else {
+                    v.x = row[k];
+                    if (k + 1 < D) v.y = row[k + 1];
+                    if (k + 2 < D) v.z = row[k + 2];
                 }
-                xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
             }
-            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // wave-uniform; first consumer of the state loads
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+            xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
         }
-        return true;
     };
+    auto store = [&](int c0, const float (&xr)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+    };
+    auto load_tile = [&](int pt, int c_first) {
+        for (int c0 = c_first; c0 <= i; c0 += 16) {
+            float xr[16];
+            fetch(pt, c0, xr);
+            store(c0, xr);
+        }
+    };
+    if constexpr (CM != 0) {
+        // the one workgroup barrier of the kernel: the block's waves share the (clique, dim) and so the panel
+        float xr[16];
+        if (p0 < n) fetch(p0, 0, xr);
+        if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;     // block-uniform
+        {
+            FusedAdam fa;
+            fa.grads = pending ? Gprev : nullptr;
+            fa.gstride = gstride;
+            fa.copies = ((n + TILE * T - 1) / (TILE * T) + W - 1) / W;
+            // state before the pending update: the buffer of the previous iteration's parity (even: the clique's own)
+            const gfloat* own_t = (const gfloat*)kparams;
+            const gfloat* own_m = (const gfloat*)(cp ? cp->adam_m : a.single.adam_m);
+            const gfloat* own_v = (const gfloat*)(cp ? cp->adam_v : a.single.adam_v);
+            const bool src_alt = pending && par == 0;
+            const gfloat* t_src = src_alt ? alt : own_t;
+            fa.m_src = src_alt ? alt + gstride : own_m;
+            fa.v_src = src_alt ? alt + 2 * gstride : own_v;
+            const bool writer = pending && blockIdx.x == 0;
+            fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
+            fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
+            fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
+            if (pending) fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + a.iter_idx, n);
+            stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x);
+            __syncthreads();
+        }
+        if (p0 >= n) return;
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(11);
+#endif
+        store(0, xr);
+        load_tile(p0, 16);
+    } else {
+        if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;
+    }
 
     for (int tt = 0; tt < T; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
         STAMP(1);
-        if (!load_tile(pt)) return;
+        if (CM == 0 || tt > 0) load_tile(pt, 0);
         wave_lds_sync();
         STAMP(2);
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
-        if (i == 0) {
+        if constexpr (CM != 0) {
+            if (i == 0) {
+#pragma unroll
+                for (int o = 0; o < PoP; o += 4) {
+                    const cm_f32x4 v4 = *(const cm_f32x4*)(pan + o);
+                    th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
+                }
+            } else {
+                cond_forward_mfma<K, H>(pan, i, xt, XS, lane, h1, h2, th);
+            }
+        } else if (i == 0) {
             load_row<PoP>(lp, th);
         } else {
             cond_hidden<K, H, cfloat*>(blk, i, xt, XS, lane, h1, h2);
             STAMP(14);
             cond_theta<K, H, cfloat*>(blk, i, h2, th);
+        }
+        if (i > 0) {   // operands of the gradient GEMMs, parked while the lanes are busy with the spline
+#pragma unroll
+            for (int k = 0; k < H; ++k) { stg[k * XS + lane] = h2[k]; hrow[k * XS + lane] = h1[k]; }
         }
         STAMP(3);
         Spline<K> S;
@@ -731,7 +816,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
         }
         // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights) ----
         float ga2[H], ga1[H];
-        {
+        if constexpr (CM != 0) {
+            cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
+        } else {
             float gh2[H], gh1[H];
             cfloat* W2 = reload_ptr(blk + LY::oW2(i));
             if constexpr (PoP == 32) {
@@ -758,51 +845,54 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
         STAMP(6);
         // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
         //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
+        // The 16 staging rows carry four generations of operands: [h2 | h1], gth tile 0, gth tile 1, [ga2 | ga1].  A
+        // generation is read into registers completely, then the NEXT one is written before this one's MFMAs are
+        // issued: the LDS writes complete under the 16 x 32 MFMA cycles and only the reads' round trip stays exposed.
         const float* pa = stg + r16 * XS + kq;
-        const float* pah = stg + (r16 < H ? r16 : 0) * XS + kq;     // [h | 1] operand: every lane loads, lanes >= H take 1
-        float breg[NS];
-        {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth
-#pragma unroll
-            for (int k = 0; k < H; ++k) stg[k * XS + lane] = h2[k];
+        const int rh = (r16 < H) ? r16 : 0;                      // [h | 1] operand: every lane loads, lanes >= H take 1
+        float breg[NS], areg[NS];
+        {
             wave_lds_sync();
 #pragma unroll
-            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            for (int s4 = 0; s4 < NS; ++s4) { const float v2 = stg[rh * XS + kq + 4 * s4]; breg[s4] = (r16 < H) ? v2 : 1.0f; }
             wave_lds_sync();
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
-                wave_lds_sync();
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) cacc[t] = mfma4(pa[4 * s4], breg[s4], cacc[t]);
-                wave_lds_sync();
-            }
         }
         STAMP(7);
-        {   // phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
+        {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth ;  phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
 #pragma unroll
-            for (int j = 0; j < H; ++j) stg[j * XS + lane] = h1[j];
+            for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (o < PoP) ? gth[(o < PoP) ? o : 0] : 0.0f;
             wave_lds_sync();
 #pragma unroll
-            for (int s4 = 0; s4 < NS; ++s4) { const float v = pah[4 * s4]; breg[s4] = (r16 < H) ? v : 1.0f; }
+            for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
             wave_lds_sync();
 #pragma unroll
-            for (int j = 0; j < H; ++j) {
-                stg[j * XS + lane] = ga2[j];
-                stg[(H + j) * XS + lane] = ga1[j];
+            for (int t = 1; t <= NT; ++t) {
+                if (t < NT) {
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < H; ++j) { stg[j * XS + lane] = ga2[j]; stg[(H + j) * XS + lane] = ga1[j]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) cacc[t - 1] = mfma4(areg[s4], breg[s4], cacc[t - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                wave_lds_sync();
+                if (t < NT) {
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+                    wave_lds_sync();
+                }
             }
-            wave_lds_sync();
-            // every LDS operand is requested before the first MFMA (an MFMA that waits for its own ds_read serialises
-            // the two latencies 16 times), and the two accumulation chains alternate so that neither waits for its own
-            // previous result (32-cycle issue instead of the 40-cycle dependent latency)
-            float areg[NS], bx[NS];
             const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;     // input columns 0..15 (column i = bias)
-#pragma unroll
-            for (int s4 = 0; s4 < NS; ++s4) { areg[s4] = pa[4 * s4]; bx[s4] = pb0[4 * s4]; }
+            const float* pb1 = hrow + rh * XS + kq;
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) {
-                c1 = mfma4(areg[s4], breg[s4], c1);
-                c0 = mfma4(areg[s4], (r16 < i) ? bx[s4] : 1.0f, c0);
+                areg[s4] = pa[4 * s4];
+                const float bx = pb0[4 * s4], bh = pb1[4 * s4];
+                c1 = mfma4(areg[s4], (r16 < H) ? bh : 1.0f, c1);
+                c0 = mfma4(areg[s4], (r16 < i) ? bx : 1.0f, c0);
             }
             for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
                 const int cab = ct * 16 + r16;
@@ -811,9 +901,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; cx = mfma4(areg[s4], (cab < i) ? v : 1.0f, cx); }
                 if (kq >= 2 && cab <= i) {
-                    gfloat* dst = &Gb[cab * H + 4 * (kq - 2)];
-                    if (slab && tt > 0) cx += *(const gvf4_t*)dst;
-                    gsink4(dst, cx, slab);
+                    if (slab) {
+                        float* dst = &ctacc[(cab - 16) * H + 4 * (kq - 2)];
+                        if (tt > 0) { cx.x += dst[0]; cx.y += dst[1]; cx.z += dst[2]; cx.w += dst[3]; }
+                        dst[0] = cx.x; dst[1] = cx.y; dst[2] = cx.z; dst[3] = cx.w;
+                    } else {
+                        gsink4(&Gb[cab * H + 4 * (kq - 2)], cx, false);
+                    }
                 }
             }
             wave_lds_sync();
@@ -821,18 +915,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
         STAMP(8);
     }
 
-    // ---- the wave's gradient copy of this dim ----
-    if (i == 0) {
-        if (lane < PoP) gsink(&G[lane], r0, slab);
-    } else {
-        gfloat* Gw = Gb + LY::oW2(i);
-        if (slab) {
+    // ---- the gradient of this dim's parameter block ----
+    if (slab) {
+        // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) tile rows, the
+        // block's threads add the fragments in wave order and write the copy with consecutive addresses.  A quarter of
+        // the copies for the Adam update to read back, and no partial 16-byte global stores.
+        float* frag = xt;
+        if (i == 0) {
+            if (lane < PoP) frag[lane] = r0;
+        } else {
+            float* fw = frag + LY::oW2(i);
             if (r16 <= H) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[r16 * PoP + 16 * t + 4 * kq], cacc[t], true);
+                    if (16 * t + 4 * kq + 3 < PoP) {
+                        float* d = &fw[r16 * PoP + 16 * t + 4 * kq];
+                        d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                    }
             }
-        } else {
+            if (kq < 2 && r16 <= H) {
+                float* d = &(frag + LY::oW1(i))[r16 * H + 4 * kq];
+                d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
+            }
+            if (kq >= 2 && r16 <= i) {
+                float* d = &frag[r16 * H + 4 * (kq - 2)];
+                d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w;
+            }
+            for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
+        }
+        __syncthreads();                                      // waves without a tile left before the panel barrier
+        const int waves_c = (n + TILE * T - 1) / (TILE * T);
+        const int alive = (waves_c - (int)blockIdx.x * W < W) ? waves_c - (int)blockIdx.x * W : W;
+        const int nj = (i == 0) ? PoP : LY::block(i);
+        gfloat* Gc = G + ((i == 0) ? 0 : LY::off(i));
+        for (int e = threadIdx.x; e < nj; e += 64 * alive) {
+            float sum = tiles0[e];
+            for (int ww = 1; ww < alive; ++ww) sum += tiles0[(size_t)ww * (wave_rows * XS) + e];
+            Gc[e] = sum;
+        }
+    } else if (i == 0) {
+        if (lane < PoP) gsink(&G[lane], r0, false);
+    } else {
+        gfloat* Gw = Gb + LY::oW2(i);
+        {
             // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
             constexpr int TOT = (H + 1) * PoP;
             static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
@@ -851,8 +976,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8
                 if (f < TOT) gsink(&Gw[f], stg[f], false);
             }
         }
-        if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, slab);
-        if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, slab);
+        if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
+        if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, false);
     }
     STAMP(9);
     const float tot = wave_sum(lossv);
@@ -1796,27 +1921,28 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         return NFISAM_ERR_ARG;
     } else {
         // throughput regime: one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
-        int W = 4;
-        const char* e = getenv("NFISAM_BIG_W");
-        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) W = atoi(e);
+        const int W = dim_major_waves();
         const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
         a.tiles_per_block = T;
         a.xrows = max_D;
-        a.n_copies = (max_n + TILE * T - 1) / (TILE * T);
-        const int gx = (a.n_copies + W - 1) / W;
-        const size_t lds = (size_t)W * (size_t)(max_D + 16) * XS * sizeof(float);
-        int occ = 3;           // 149 VGPRs, no scratch; the 128-register build (4 waves per SIMD) spills 40 VGPRs and measures 5 % slower
-        const char* oe = getenv("NFISAM_OCC");
-        if (oe != nullptr) occ = atoi(oe);
+        const int waves = (max_n + TILE * T - 1) / (TILE * T);
+        const int gx = (waves + W - 1) / W;
+        a.n_copies = gx;                                       // one gradient copy per block (a.slab = TILE * T * W particles)
+        const size_t tiles_lds = (size_t)W * (size_t)train1_wave_rows(max_D, 8) * XS * sizeof(float);
+        // conditioner: 1 = v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h), 0 = VALU FMAs with
+        // scalar-path weights.  3 waves per SIMD either way (the 128-register build spills and measures slower).
+        const int cm = dim_major_mfma_cond() ? 1 : 0;
+        if (a.fused_adam != 0 && !cm) return NFISAM_ERR_ARG;
         int rc;
-        if (occ >= 4) {
-            rc = set_lds(nsf_train1_kernel<KK, 8, 4>, lds);
+        if (cm) {
+            const size_t lds = tiles_lds + (size_t)CondPanel<KK, 8>::floats(max_D) * sizeof(float);
+            rc = set_lds(nsf_train1_kernel<KK, 8, 1>, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 4>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 1>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
         } else {
-            rc = set_lds(nsf_train1_kernel<KK, 8, 3>, lds);
+            rc = set_lds(nsf_train1_kernel<KK, 8, 0>, tiles_lds);
             if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 3>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 0>), dim3(gx, n_cliques, max_D), dim3(64 * W), tiles_lds, s, a);
         }
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;

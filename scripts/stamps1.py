@@ -31,3 +31,17 @@ for w in range(min(64, 4 * D)):
     tot = int(st[w][9] - st[w][0]) if st[w][9] > 0 else 0
     if tot:
         print("  slot %2d (dim %2d wave %d) total %6d: " % (w, w // 4, w % 4, tot) + ", ".join("%s=%d" % (names[i], int(a[i])) for i in sorted(names) if a[i] > 0))
+
+if os.environ.get("STAMPS_LIB", "").endswith("stamps2.so"):
+    # light stamps (one tile per wave): raw times in program order
+    order = [10, 0, 11, 1, 2, 14, 3, 4, 5, 6, 7, 8, 9]
+    label = {10: "entry", 0: "setup", 11: "fetch+panel+barrier", 1: "tile stored/top", 2: "tile in LDS", 14: "hidden", 3: "cond fwd",
+             4: "spline fwd", 5: "spline bwd", 6: "cond bwd", 7: "phase A", 8: "phase B", 9: "sink"}
+    print("light stamps, cycles since kernel entry -> delta per phase:")
+    for w in range(min(64, 4 * D)):
+        t = {k: int(st[w][k]) for k in order if st[w][k] > 0}
+        if 9 not in t or 10 not in t:
+            continue
+        ks = [k for k in order if k in t]
+        parts = ["%s=%d" % (label[b], t[b] - t[a]) for a, b in zip(ks[:-1], ks[1:])]
+        print("  slot %2d (dim %2d wave %d) total %6d: " % (w, w // 4, w % 4, t[9] - t[10]) + ", ".join(parts))

@@ -11,8 +11,8 @@ for line in sys.stdin:
 "
 }
 run NFISAM_DIM_MAJOR=0
-for occ in 3 4; do for tpb in 0 1 2 8; do
-  run NFISAM_DIM_MAJOR=1 NFISAM_OCC=$occ NFISAM_TILES_PER_BLOCK=$tpb
-done; done
-run NFISAM_DIM_MAJOR=1 NFISAM_OCC=3 NFISAM_BIG_W=2
-run NFISAM_DIM_MAJOR=1 NFISAM_OCC=3 NFISAM_BIG_W=1
+run NFISAM_COND=scalar
+run NFISAM_COND=mfma
+run NFISAM_COND=mfma NFISAM_TILES_PER_BLOCK=2
+run NFISAM_COND=mfma NFISAM_TILES_PER_BLOCK=8
+run NFISAM_COND=mfma NFISAM_BIG_W=2

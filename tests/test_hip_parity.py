@@ -440,9 +440,10 @@ def test_large_launch_uses_atomics_and_still_matches_oracle(n):
     """> 128 tiles: single gradient buffer + float atomics (workspace is one copy).  The smaller case still
     runs the two-lanes-per-particle kernel (<= 1280 waves), the larger one the one-lane-per-particle kernel."""
     K, H, B, L, D = 9, 8, 5.0, 1, 4
-    ring = 128 * 64      # per-iteration loss sums behind the gradient copies
+    ring = 128 * 64 + 64      # per-iteration loss sums behind the gradient copies (+ 64 reserved words)
     assert nh.lib().nfisam_nsf_grad_workspace_count(n, D, K, H, L) == nh.kparam_count(D, K, H) + ring
-    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == 63 * nh.kparam_count(D, K, H) + ring
+    # <= 32 tiles of 64 particles: room for the fused-Adam launches' second set of copies and second (theta | m | v)
+    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == (63 + 32 + 3) * nh.kparam_count(D, K, H) + ring
     assert nh.lib().nfisam_nsf_grad_workspace_count(6000, D, K, H, L) == 94 * nh.kparam_count(D, K, H) + ring
     blob, x = make_problem(n, D, K, H, L, seed=8, spread=1.0)
     tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, L)], K, H, B, L, lr=0.02, max_iters=5, early_stop=False)
@@ -548,3 +549,73 @@ def test_kernel_families_agree_on_random_shapes():
             os.environ.pop("NFISAM_TRAIN", None)
         else:
             os.environ["NFISAM_TRAIN"] = old
+
+
+class _Env:
+    """Environment switches of the launch-shape helpers (read per call), restored on exit."""
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _train_ragged(shapes, iters, window, use_graph, K=9, H=8, B=5.0, lr=0.01):
+    probs = [make_problem(n, D, K, H, 1, seed=300 + c) for c, (n, D) in enumerate(shapes)]
+    tb = nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H) for (b, _), (_, D) in zip(probs, shapes)], K, H, B, 1,
+                       lr=lr, max_iters=iters, average_window=window, loss_delta_tol=0.0, early_stop=True)
+    done = tb.run(use_graph=use_graph)
+    torch.cuda.synchronize()
+    return done, [[t.cpu().numpy().copy() for t in arr] for arr in (tb.kparams, tb.m, tb.v, tb.iter_loss)]
+
+
+@pytest.mark.parametrize("shapes,iters,window", [([(2000, 15)], 130, 50), ([(1900, 12), (300, 17), (2048, 3), (65, 1)], 130, 50),
+                                                 ([(512, 6)], 7, 1), ([(700, 9), (640, 9)], 9, 4)],
+                         ids=["plaza-clique", "ragged-batch", "chunks-of-one", "odd-chunks"])
+@pytest.mark.parametrize("use_graph", [True, False], ids=["hipgraph", "eager"])
+def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, iters, window, use_graph):
+    """The Adam update applied at the start of the next gradient launch (nsf_cond_mfma.h; chunk-closing update by
+    nsf_adam_kernel) leaves exactly the parameters and moments of gradient kernel + Adam kernel per iteration: full
+    chunks, a final partial chunk (130 = 50 + 50 + 30), chunks of one, odd chunk lengths (the two state buffers
+    alternate with the iteration's parity), ragged batches with D > 16 and a single-tile clique."""
+    with _Env(NFISAM_FUSED_ADAM="0"):
+        d0, ref = _train_ragged(shapes, iters, window, use_graph)
+    with _Env(NFISAM_FUSED_ADAM=None):
+        d1, got = _train_ragged(shapes, iters, window, use_graph)
+    assert d0 == d1 == [iters] * len(shapes)
+    for name, a, b in zip(("theta", "m", "v"), ref[:3], got[:3]):
+        for c, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), (name, c, np.abs(x - y).max())
+    for x, y in zip(ref[3], got[3]):                        # the loss record goes through float atomics (order-dependent rounding)
+        np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
+
+
+def test_mfma_conditioner_matches_the_scalar_path_conditioner():
+    """Dim-major training kernel: the conditioner as v_mfma_f32_4x4x1 chains fed from the LDS weight panel against the
+    VALU conditioner with scalar-path weights (NFISAM_COND=scalar) -- same fp32 products, different summation order."""
+    K, H, B = 9, 8, 5.0
+    for n, D in ((2000, 15), (333, 17), (64, 2), (1000, 24)):
+        blob, x = make_problem(n, D, K, H, 1, seed=77 + D)
+        res = {}
+        for cond in ("scalar", None):
+            with _Env(NFISAM_COND=cond, NFISAM_TRAIN="wide"):
+                tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H)], K, H, B, 1, lr=0.01, max_iters=3, early_stop=False)
+                tb.step()
+                torch.cuda.synchronize()
+                res[cond] = (float(tb.iter_loss[0][0]), nh.unpack(tb.kparams[0], D, K, H).cpu().numpy(), tb.m[0].cpu().numpy())
+        a, b = res["scalar"], res[None]
+        assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])), (n, D, a[0], b[0])
+        scale = max(1e-3, float(np.abs(a[2]).max()))
+        assert np.abs(a[2] - b[2]).max() < 2e-5 * scale, (n, D, np.abs(a[2] - b[2]).max(), scale)      # m_1 = 0.1 * gradient

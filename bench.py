@@ -431,16 +431,21 @@ def main():
             "final_loss": head["final_loss"], "first_loss": head["first_loss"],
             "roofline": {"bound": "valu_issue", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "nsf_train1_kernel<9,8,3>", "kernel_us": head["gradient_kernel_us"],
+                         "kernel": "nsf_train1_kernel<9,8,1>", "kernel_us": head["gradient_kernel_us"],
                          "flop_per_launch": head["flop_per_launch"],
-                         "note": "fp32 VALU/transcendental-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, neither HBM nor "
-                                 "MFMA binds; MFMA carries only the weight-gradient GEMMs), priced against the fp32 peak "
-                                 "(157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  333 MFLOP per launch = 2.1 us at peak: the "
-                                 "C3 launch is 2560 waves of ONE (dim, 64-particle tile) unit each, i.e. one dependent "
-                                 "instruction stream of ~2k VALU + 64 MFMA instructions per wave at 2.5 waves per SIMD - "
-                                 "latency-bound by construction; `regimes.batch64_n2000_D15` is the throughput regime.  "
-                                 "Algorithmic HBM bytes per launch: 608 KB (x) + 112 KB (parameters); `traffic` is null "
-                                 "because it is not measured in this run (PMC passes: profiles/, see `traffic_profiled`)."},
+                         "note": "fp32 INSTRUCTION-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, HBM does not bind), priced "
+                                 "against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  Per (dim, 64-particle "
+                                 "tile) unit a wave issues ~1.9k VALU instructions (spline, tanh, operand staging), 164 "
+                                 "v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane) and 64 v_mfma_f32_16x16x4 (the "
+                                 "weight-gradient GEMMs); on gfx950 MFMA and VALU issue of a SIMD do not overlap (measured: "
+                                 "profiles/r02_mfma_valu_issue_microbench.txt), so their times add.  333 MFLOP per launch = "
+                                 "2.1 us at peak: the C3 launch is 2496 waves of ONE unit each at 2.4 waves per SIMD, i.e. one "
+                                 "dependent instruction stream per wave - latency-bound by construction; "
+                                 "`regimes.batch64_n2000_D15` is the throughput regime.  `kernel_us` times the gradient launch "
+                                 "alone; in a training iteration the same kernel also applies the previous iteration's Adam "
+                                 "update on its way into LDS (no separate Adam launch: `ms_per_step`).  Algorithmic HBM bytes "
+                                 "per launch: 608 KB (x) + 112 KB (parameters); `traffic` is null because it is not measured in "
+                                 "this run (PMC passes: profiles/, see `traffic_profiled`)."},
             "regimes": regimes,
         }
         tj = os.path.join(ROOT, "profiles", "r02_train_kernel_traffic.json")

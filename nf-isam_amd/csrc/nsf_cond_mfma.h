@@ -24,6 +24,7 @@
 // different banks.
 #pragma once
 #include "nsf_device.h"
+#include "nsf_host.h"
 
 typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -77,24 +78,16 @@ struct FusedAdam {
     AdamCoef kc;
 };
 
-// parameter `j` (index into the clique's parameter vector) after the pending update; writes the new state if asked to
-__device__ __forceinline__ float fused_adam_param(const FusedAdam& fa, const __attribute__((address_space(1))) float* t_src,
-                                                  int j, bool live) {
-    float tj = t_src[j];
-    if (fa.grads == nullptr) return tj;                      // launch-uniform
-    float gv[8];                                             // at most 8 copies (the host checks), summed as nsf_adam_kernel does
+// sum of parameter j's gradient copies, in nsf_adam_kernel's one-thread-per-parameter order (at most 8 copies: the host checks)
+__device__ __forceinline__ void fused_load_grads(const FusedAdam& fa, int j, float (&gv)[8]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float g = fa.grads[(size_t)(c < fa.copies ? c : 0) * fa.gstride + j];
-        gv[c] = (c < fa.copies) ? g : 0.0f;
-    }
+    for (int c = 0; c < 8; ++c) gv[c] = fa.grads[(size_t)(c < fa.copies ? c : 0) * fa.gstride + j];
+}
+__device__ __forceinline__ float fused_sum_grads(const FusedAdam& fa, const float (&gv)[8]) {
     float gs = gv[0];
 #pragma unroll
-    for (int c = 1; c < 8; ++c) gs += gv[c];
-    float mj = fa.m_src[j], vj = fa.v_src[j];
-    adam_update(fa.kc, gs, mj, vj, tj);
-    if (fa.t_dst != nullptr && live) { fa.t_dst[j] = tj; fa.m_dst[j] = mj; fa.v_dst[j] = vj; }
-    return tj;
+    for (int c = 1; c < 8; ++c) gs += (c < fa.copies) ? gv[c] : 0.0f;
+    return gs;
 }
 
 // The block's 256 threads bring dim i's parameter block (i > 0: conditioner weights -> panel; i == 0: the PoP spline
@@ -102,8 +95,12 @@ __device__ __forceinline__ float fused_adam_param(const FusedAdam& fa, const __a
 // t, t + 256, ... of the block: two at a time, every global load of both issued before the first use.  Padding no
 // 16-byte read ever touches is not written; the zero weights behind W0's i rows are (layer 0 contracts whole groups
 // of eight inputs).
+// `st_step`, `st_stop` are the clique's state words, requested at kernel entry: they are first LOOKED AT after this
+// function's own loads have arrived (the empty asm is a use of the loaded values in front of the branch, so the loads are
+// not sunk behind it), i.e. the two round trips overlap.  -> false: the clique is finished, the block returns.
 template <int K, int H>
-__device__ __forceinline__ void stage_cond_panel(float* pan, const float* theta_generic, const FusedAdam& fa, int i, int tid) {
+__device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_generic, FusedAdam& fa, int i, int tid,
+                                                 int st_step, int st_stop, const TrainArgs& a, int n) {
     using CP = CondPanel<K, H>;
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
@@ -133,11 +130,33 @@ __device__ __forceinline__ void stage_cond_panel(float* pan, const float* theta_
         }
     };
     for (int base = 0; base < nj; base += 2 * NT) {
+        // two parameters per thread, every global load of both requested before the first is consumed (one round trip)
         const int ja = base + tid, jb = base + NT + tid;
-        const float va = fused_adam_param(fa, t_src, j0 + (ja < nj ? ja : 0), ja < nj);
-        const float vb = fused_adam_param(fa, t_src, j0 + (jb < nj ? jb : 0), jb < nj);
-        if (ja < nj) place(ja, va);
-        if (jb < nj) place(jb, vb);
+        const int ia = j0 + (ja < nj ? ja : 0), ib = j0 + (jb < nj ? jb : 0);
+        float ta = t_src[ia], tb = t_src[ib];
+        float ga[8], gb[8], ma = 0.f, va = 0.f, mb = 0.f, vb = 0.f;
+        if (fa.grads != nullptr) {                             // launch-uniform: an update is pending
+            fused_load_grads(fa, ia, ga);
+            fused_load_grads(fa, ib, gb);
+            ma = fa.m_src[ia]; va = fa.v_src[ia]; mb = fa.m_src[ib]; vb = fa.v_src[ib];
+            asm volatile("" : "+v"(ga[0]), "+v"(ga[7]), "+v"(gb[0]), "+v"(gb[7]), "+v"(ma), "+v"(vb));
+        }
+        asm volatile("" : "+v"(ta), "+v"(tb));
+        if (base == 0) {
+            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // block-uniform
+            if (fa.grads != nullptr)
+                fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + a.iter_idx, n);
+        }
+        if (fa.grads != nullptr) {
+            adam_update(fa.kc, fused_sum_grads(fa, ga), ma, va, ta);
+            adam_update(fa.kc, fused_sum_grads(fa, gb), mb, vb, tb);
+            if (fa.t_dst != nullptr) {                         // the dim's first block records the new state
+                if (ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
+                if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
+            }
+        }
+        if (ja < nj) place(ja, ta);
+        if (jb < nj) place(jb, tb);
     }
     if (i > 0) {
         const int npad = (((i + 7) & ~7) - i) * H;             // zero weights behind W0's rows
@@ -146,6 +165,7 @@ __device__ __forceinline__ void stage_cond_panel(float* pan, const float* theta_
             pan[CP::oW0T + j * s0 + k] = 0.0f;
         }
     }
+    return true;
 }
 
 // acc[g * SPLIT + (q % SPLIT)][u] += sum over the quads q < NK/4 of  A[4g + u][4q + v] * b[4q + v]

@@ -610,6 +610,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, 8
     }
 }
 
+// One float per lane into row `ROW` of a [rows][XS] LDS tile whose row-0 address for this lane is `lane_addr` (bytes).
+// Written as an explicit ds_write_b32 with the row offset as the instruction's immediate: left to the compiler, pairs of
+// these stores become ds_write2_b32, whose 8-bit offsets need a fresh base-address VGPR every ~4 rows (seven address
+// registers for a 16-row tile, at a point where the kernel has none to spare).  LDS operations of a wave execute in
+// order, so later compiler-generated reads of the rows see the data; the "memory" clobber keeps the program order.
+template <int ROW>
+__device__ __forceinline__ void lds_row_store(unsigned lane_addr, float v) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(lane_addr), "v"(v), "n"(ROW * XS * 4) : "memory");
+}
+template <int ROW0, int N, int SRC0 = 0, int NSRC>
+__device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (&src)[NSRC]) {
+    if constexpr (N > 0) {
+        lds_row_store<ROW0>(lane_addr, (SRC0 < NSRC) ? src[SRC0 < NSRC ? SRC0 : 0] : 0.0f);
+        lds_rows_store<ROW0 + 1, N - 1, SRC0 + 1, NSRC>(lane_addr, src);
+    }
+}
+
 // =============================================================================================
 // throughput training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, blocks are dim-major.
 //
@@ -630,7 +647,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
     constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
-    static_assert(H == 8, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    static_assert(H == 8 && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
@@ -676,10 +693,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     const float* pan = smem;                                  // CM: the block's conditioner panel (nsf_cond_mfma.h)
     const int wave_rows = train1_wave_rows(xrows, H);
     float* tiles0 = smem + (CM ? CondPanel<K, H>::floats(xrows) : 0);
-    float* xt = tiles0 + (size_t)w * (wave_rows * XS);        // [xrows][XS] particle tile, dimension-major
-    float* stg = xt + xrows * XS;                             // [16][XS] staging rows
+    // fixed-size rows first: their offsets from the wave's base are immediates of the LDS instructions (fewer address registers)
+    float* stg = tiles0 + (size_t)w * (wave_rows * XS);       // [16][XS] staging rows
     float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
-    float* ctacc = hrow + H * XS;                             // D > 16: dW0 rows 16.. of the wave, summed over its tiles
+    const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
+    float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
+    float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
     const int r16 = lane & 15, kq = lane >> 4;
     cfloat* lp = (cfloat*)kparams;
     cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
@@ -734,7 +753,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         // the one workgroup barrier of the kernel: the block's waves share the (clique, dim) and so the panel
         float xr[16];
         if (p0 < n) fetch(p0, 0, xr);
-        if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;     // block-uniform
         {
             FusedAdam fa;
             fa.grads = pending ? Gprev : nullptr;
@@ -752,8 +770,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (pending) fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + a.iter_idx, n);
-            stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x);
+            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x, st_step, st_stop, a, n)) return;
             __syncthreads();
         }
         if (p0 >= n) return;
@@ -793,8 +810,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             cond_theta<K, H, cfloat*>(blk, i, h2, th);
         }
         if (i > 0) {   // operands of the gradient GEMMs, parked while the lanes are busy with the spline
-#pragma unroll
-            for (int k = 0; k < H; ++k) { stg[k * XS + lane] = h2[k]; hrow[k * XS + lane] = h1[k]; }
+            lds_rows_store<0, H, 0, H>(stg_lane, h2);
+            lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
         }
         STAMP(3);
         Spline<K> S;
@@ -859,20 +876,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         }
         STAMP(7);
         {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth ;  phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
-#pragma unroll
-            for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (o < PoP) ? gth[(o < PoP) ? o : 0] : 0.0f;
+            lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
             wave_lds_sync();
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
             wave_lds_sync();
 #pragma unroll
             for (int t = 1; t <= NT; ++t) {
-                if (t < NT) {
-#pragma unroll
-                    for (int o = 0; o < 16; ++o) stg[o * XS + lane] = (16 * t + o < PoP) ? gth[(16 * t + o < PoP) ? 16 * t + o : 0] : 0.0f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < H; ++j) { stg[j * XS + lane] = ga2[j]; stg[(H + j) * XS + lane] = ga1[j]; }
+                if (t == 1 && NT > 1) lds_rows_store<0, 16, 16, PoP>(stg_lane, gth);
+                if (t == 2 && NT > 2) lds_rows_store<0, 16, 32, PoP>(stg_lane, gth);
+                if (t == 3 && NT > 3) lds_rows_store<0, 16, 48, PoP>(stg_lane, gth);
+                if (t == NT) {
+                    lds_rows_store<0, H, 0, H>(stg_lane, ga2);
+                    lds_rows_store<H, H, 0, H>(stg_lane, ga1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -920,7 +936,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) tile rows, the
         // block's threads add the fragments in wave order and write the copy with consecutive addresses.  A quarter of
         // the copies for the Adam update to read back, and no partial 16-byte global stores.
-        float* frag = xt;
+        float* frag = stg;                                     // 24 rows: room for every dim's block
         if (i == 0) {
             if (lane < PoP) frag[lane] = r0;
         } else {
@@ -953,6 +969,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             for (int ww = 1; ww < alive; ++ww) sum += tiles0[(size_t)ww * (wave_rows * XS) + e];
             Gc[e] = sum;
         }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(12);
+#endif
     } else if (i == 0) {
         if (lane < PoP) gsink(&G[lane], r0, false);
     } else {

@@ -1,0 +1,69 @@
+"""Turn the per-launch PMC means of scripts/collect_profiles.sh (<dir>/pmc_means.json) into the two derived summaries
+under profiles/: issue utilisation of the training kernel (C3 and the 64-clique batch) and its HBM-side traffic.
+usage: python scripts/derive_profile_json.py gpurun_out/<dir> profiles/r02"""
+import json, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+pm = json.load(open(src + "/pmc_means.json"))
+SIMDS, SES = 1024, 32
+
+
+def kernel_of(d):
+    return next(v for k, v in d.items() if "nsf_train1_kernel" in k)
+
+
+out = {"_formulas": {
+    "kernel_cycles": "SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines' busy cycles)",
+    "valu_issue_frac": "2 * SQ_ACTIVE_INST_VALU / (kernel_cycles * 1024 SIMDs): the counter advances 1 per plain VALU instruction "
+                       "and 2 per transcendental (scripts/exp/valu_rate.hip), a plain fp32 VALU instruction occupies the issue port 2 cycles",
+    "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024)",
+    "issue_frac": "valu_issue_frac + mfma_busy_frac (MFMA and VALU issue of a SIMD do not overlap: profiles/r02_mfma_valu_issue_microbench.txt)",
+    "scalar_cache_hit_rate": "SQC_DCACHE_HITS / (SQC_DCACHE_HITS + SQC_DCACHE_MISSES)"}}
+for name, key in (("C3", "c3"), ("batch64", "b64")):
+    k = kernel_of(pm[key])
+    cyc = k["SQ_BUSY_CYCLES"] / SES
+    valu = 2.0 * k["SQ_ACTIVE_INST_VALU"] / (cyc * SIMDS)
+    mfma = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS)
+    out[name] = {
+        "kernel": "nsf_train1_kernel<9,8,1>", "kernel_cycles": cyc, "waves_launched": k["SQ_WAVES"],
+        "valu_instructions": k["SQ_INSTS_VALU"], "mfma_instructions": k["SQ_INSTS_MFMA"], "lds_instructions": k["SQ_INSTS_LDS"],
+        "salu_instructions": k["SQ_INSTS_SALU"], "smem_instructions": k["SQ_INSTS_SMEM"],
+        "valu_issue_frac": valu, "mfma_busy_frac": mfma, "issue_frac": valu + mfma,
+        "wait_inst_any_over_wave_cycles": k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"],
+        "lds_bank_conflict_over_lds_active": k["SQ_LDS_BANK_CONFLICT"] / max(k["SQ_LDS_IDX_ACTIVE"], 1.0),
+        "scalar_cache_hit_rate": k["SQC_DCACHE_HITS"] / (k["SQC_DCACHE_HITS"] + k["SQC_DCACHE_MISSES"]),
+    }
+json.dump(out, open(dst + "_issue_utilisation.json", "w"), indent=1)
+
+k = kernel_of(pm["c3"])
+P = [None]
+alg = 723552                                         # bench.py: 608 KB (x) + 112 KB (parameters) for the C3 launch
+# C3 parameter counts (K = 9, H = 8): count(D) = 32 + (D-1)*368 + 8*(D-1)*D/2
+cnt = lambda D: 32 + (D - 1) * 368 + 8 * ((D - 1) * D // 2)
+Pc = [cnt(D) for D in (6, 8, 8, 10, 10, 12, 12, 12)]
+copies = 8
+grad_bytes = copies * sum(Pc) * 4
+state_bytes = 3 * sum(Pc) * 4
+traffic = {
+    "kernel": "nsf_train1_kernel<9,8,1>", "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
+              "(the launch also applies the previous iteration's Adam update)",
+    "launches_averaged": 970,
+    "FETCH_SIZE_KB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KB_raw": k["WRITE_SIZE"],
+    "hbm_side_bytes_per_launch_lower": int(1024 * (k["FETCH_SIZE"] + k["WRITE_SIZE"])),
+    "hbm_side_bytes_per_launch_upper": int(1024 * (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"])),
+    "algorithmic_bytes_per_launch": alg,
+    "bytes_the_launch_must_move": {"gradient_copies_written": grad_bytes, "adam_state_written": state_bytes,
+                                   "gradient_copies_and_state_read_per_dim_block": "8 blocks per (clique, dim) each read the 8 "
+                                   "copies + theta, m, v of the dim: %d B in total, L2 / Infinity-Cache hits after the first block" % (8 * (grad_bytes + state_bytes))},
+    "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (scripts/collect_profiles.sh), means over the 970 "
+            "launches of the run.  The counters sit at the L2-fabric boundary and include Infinity-Cache hits.  FETCH_SIZE counts "
+            "64 B per 128-B request for wide streaming reads on gfx950 (MI355X_MICROARCH.md), i.e. up to x2 (both bounds given).  "
+            "WRITE_SIZE: one gradient copy per BLOCK (8 per clique, %.2f MB) + the new theta/m/v (%.2f MB) are written with 4-byte "
+            "stores per lane, which the counter prices at one 32-B sector each (x8): %.2f MB expected at that rate, %.2f MB counted.  "
+            "At 130-330 GB/s of fabric traffic the kernel is nowhere near the HBM roofline; the figure that matters is the issue "
+            "utilisation (r02_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, 8 * (grad_bytes + state_bytes) / 1e6,
+                                                            k["WRITE_SIZE"] * 1024 / 1e6),
+}
+traffic["ratio_to_algorithmic"] = [traffic["hbm_side_bytes_per_launch_lower"] / alg, traffic["hbm_side_bytes_per_launch_upper"] / alg]
+json.dump(traffic, open(dst + "_train_kernel_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1)); print(json.dumps(traffic, indent=1)[:1500])

@@ -13,13 +13,17 @@ K, H, B, L = 9, 8, 5.0, 1
 rng = np.random.RandomState(0)
 xs = [torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev) for _ in range(nc)]
 kps = [nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, c)).to(dev), D, K, H, L) for c in range(nc)]
-tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=100000, early_stop=False)
-for _ in range(3):
-    tb.gradient_only()
-torch.cuda.synchronize()
 lib = nh.lib()
-lib.nfisam_debug_write_stamps((C.c_ulonglong * (64 * 32))())
-tb.gradient_only()
+if os.environ.get("STAMPS_TRAIN"):     # a whole chunk of training iterations: the stamps are those of its last gradient launch (fused Adam pending)
+    tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=8, average_window=4, loss_delta_tol=0.0, early_stop=True)
+    tb.run(use_graph=False)
+else:
+    tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=100000, early_stop=False)
+    for _ in range(3):
+        tb.gradient_only()
+    torch.cuda.synchronize()
+    lib.nfisam_debug_write_stamps((C.c_ulonglong * (64 * 32))())
+    tb.gradient_only()
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 32))()
 assert lib.nfisam_debug_read_stamps(buf) == 0
@@ -34,9 +38,9 @@ for w in range(min(64, 4 * D)):
 
 if os.environ.get("STAMPS_LIB", "").endswith("stamps2.so"):
     # light stamps (one tile per wave): raw times in program order
-    order = [10, 0, 11, 1, 2, 14, 3, 4, 5, 6, 7, 8, 9]
+    order = [10, 0, 11, 1, 2, 14, 3, 4, 5, 6, 7, 8, 12, 9]
     label = {10: "entry", 0: "setup", 11: "fetch+panel+barrier", 1: "tile stored/top", 2: "tile in LDS", 14: "hidden", 3: "cond fwd",
-             4: "spline fwd", 5: "spline bwd", 6: "cond bwd", 7: "phase A", 8: "phase B", 9: "sink"}
+             4: "spline fwd", 5: "spline bwd", 6: "cond bwd", 7: "phase A", 8: "phase B", 9: "loss", 12: "fragments + block sum + copy"}
     print("light stamps, cycles since kernel entry -> delta per phase:")
     for w in range(min(64, 4 * D)):
         t = {k: int(st[w][k]) for k in order if st[w][k] > 0}

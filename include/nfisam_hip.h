@@ -229,8 +229,11 @@ typedef struct nfisam_clique {
  * loss words behind them) when the largest clique of its batch has n
  * particles: launches of <= 128 particle tiles write per-tile partial gradients with plain stores and
  * the Adam kernel sums them in tile order (no atomics); larger ones accumulate with float atomics
- * into a single copy.  A tile is 32 particles (two-lanes-per-particle kernel, launches that leave
- * SIMDs idle) or 64 (one lane per particle, big batches); the count is the upper bound of both.   */
+ * into a single copy.  A tile is 32 particles (two-lanes-per-particle kernel) or 64 (one lane per
+ * particle; the dim-major kernel of one-layer flows writes one copy per block of 4 waves); the count is
+ * the upper bound of all, plus -- for one-layer flows of <= 32 tiles of 64 -- the second set of copies
+ * and the second (theta | m | v) buffer of the launches that apply the previous iteration's Adam update
+ * themselves (nfisam_nsf_train_plan_run; no separate Adam launch per iteration).                  */
 size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
 /* The gradient half of a training iteration on its own (forward + analytic backward + reduction into

@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
     float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
     const int r16 = lane & 15, kq = lane >> 4;
+    const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     cfloat* lp = (cfloat*)kparams;
     cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
@@ -901,14 +902,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
                     wave_lds_sync();
                 }
             }
-            const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;     // input columns 0..15 (column i = bias)
-            const float* pb1 = hrow + rh * XS + kq;
+            if (merged) {
+                // i <= 16 - (H + 1): the columns [h1 (H) | 1 | x_0 .. x_{i-1}] of BOTH products fit one 16-column operand
+                // (they share the bias column): one MFMA chain instead of two.  Rows 0..H-1 (ga2) x columns 0..H give
+                // dW1t | db1, rows H.. (ga1) x columns H.. give db0 | dW0t; the cross terms are not used.
+                const int kx = r16 - (H + 1);
+                const float* pbm = ((r16 < H) ? hrow + r16 * XS : xt + ((kx >= 0 && kx < i) ? kx : 0) * XS) + kq;
+                const bool one = (r16 == H) || kx >= i;
 #pragma unroll
-            for (int s4 = 0; s4 < NS; ++s4) {
-                areg[s4] = pa[4 * s4];
-                const float bx = pb0[4 * s4], bh = pb1[4 * s4];
-                c1 = mfma4(areg[s4], (r16 < H) ? bh : 1.0f, c1);
-                c0 = mfma4(areg[s4], (r16 < i) ? bx : 1.0f, c0);
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    const float b = pbm[4 * s4];
+                    c1 = mfma4(areg[s4], one ? 1.0f : b, c1);
+                }
+            } else {
+                const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;     // input columns 0..15 (column i = bias)
+                const float* pb1 = hrow + rh * XS + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    const float bx = pb0[4 * s4], bh = pb1[4 * s4];
+                    c1 = mfma4(areg[s4], (r16 < H) ? bh : 1.0f, c1);
+                    c0 = mfma4(areg[s4], (r16 < i) ? bx : 1.0f, c0);
+                }
             }
             for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
                 const int cab = ct * 16 + r16;
@@ -953,7 +969,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
                 float* d = &(frag + LY::oW1(i))[r16 * H + 4 * kq];
                 d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
             }
-            if (kq >= 2 && r16 <= i) {
+            if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
+                const int k0 = (r16 == H) ? i : r16 - (H + 1);
+                if (kq >= 2 && (r16 == H || (r16 > H && k0 < i))) {
+                    float* d = &frag[k0 * H + 4 * (kq - 2)];
+                    d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
+                }
+            } else if (kq >= 2 && r16 <= i) {
                 float* d = &frag[r16 * H + 4 * (kq - 2)];
                 d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w;
             }
@@ -996,7 +1018,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             }
         }
         if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
-        if (kq >= 2 && r16 <= i) gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, false);
+        if (merged) {
+            const int k0 = (r16 == H) ? i : r16 - (H + 1);
+            if (kq >= 2 && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - 2)], c1, false);
+        } else if (kq >= 2 && r16 <= i) {
+            gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, false);
+        }
     }
     STAMP(9);
     const float tot = wave_sum(lossv);

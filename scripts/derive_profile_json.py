@@ -58,11 +58,12 @@ traffic = {
     "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (scripts/collect_profiles.sh), means over the 970 "
             "launches of the run.  The counters sit at the L2-fabric boundary and include Infinity-Cache hits.  FETCH_SIZE counts "
             "64 B per 128-B request for wide streaming reads on gfx950 (MI355X_MICROARCH.md), i.e. up to x2 (both bounds given).  "
-            "WRITE_SIZE: one gradient copy per BLOCK (8 per clique, %.2f MB) + the new theta/m/v (%.2f MB) are written with 4-byte "
-            "stores per lane, which the counter prices at one 32-B sector each (x8): %.2f MB expected at that rate, %.2f MB counted.  "
-            "At 130-330 GB/s of fabric traffic the kernel is nowhere near the HBM roofline; the figure that matters is the issue "
-            "utilisation (r02_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, 8 * (grad_bytes + state_bytes) / 1e6,
-                                                            k["WRITE_SIZE"] * 1024 / 1e6),
+            "WRITE_SIZE: one gradient copy per BLOCK (8 per clique, %.2f MB) on every launch + the new theta/m/v (%.2f MB) on the "
+            "training launches that carry a pending Adam update (about half of the 970: the kernel-timing loop launches the "
+            "gradient alone): %.2f MB counted.  (With 8 VGPRs spilled the same counter read 6.2 MB: 2 KB of scratch per wave.)  "
+            "FETCH_SIZE is dominated by the fused update: the 8 blocks of a (clique, dim) each read its 8 copies + theta, m, v "
+            "(L2 / Infinity-Cache hits after the first).  At ~300 GB/s of fabric traffic the kernel is nowhere near the HBM "
+            "roofline; the figure that matters is the issue utilisation (r02_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, k["WRITE_SIZE"] * 1024 / 1e6),
 }
 traffic["ratio_to_algorithmic"] = [traffic["hbm_side_bytes_per_launch_lower"] / alg, traffic["hbm_side_bytes_per_launch_upper"] / alg]
 json.dump(traffic, open(dst + "_train_kernel_traffic.json", "w"), indent=1)

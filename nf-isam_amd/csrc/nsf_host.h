@@ -60,6 +60,7 @@ struct TrainArgs {
     int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
     int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
     int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
+    int grid_gx, grid_cliques;      // nsf_train1_kernel: blocks per (clique, dim) group, cliques of the launch (1-D XCD-aware grid)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;

@@ -652,20 +652,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
     // atomics, which count against both memory counters)
-    const nfisam_clique* cp = a.cliques != nullptr ? (a.cliques + blockIdx.y) : nullptr;
+    // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one): the
+    // 1-D grid is laid out so that the gx blocks of one (clique, dim) GROUP are 8 apart, i.e. share an XCD and its L2 --
+    // they read the same parameters and the same gradient copies (fused Adam), which the group's blocks of the previous
+    // launch wrote through that L2 if the dispatcher kept its rotation (a speed matter only, never correctness).
+    const int pb = blockIdx.x, gxb = a.grid_gx;
+    const int grp = (pb & 7) + 8 * ((pb >> 3) / gxb);
+    const int bx = (pb >> 3) % gxb;                           // tile group inside the (clique, dim)
+    if (grp >= a.grid_cliques * a.xrows) return;              // padding of the group count to a multiple of 8
+    const int by = grp % a.grid_cliques;                      // clique
+    const nfisam_clique* cp = a.cliques != nullptr ? (a.cliques + by) : nullptr;
     const gfloat* x = (const gfloat*)(cp ? cp->x : a.single.x);
     const float* kparams = cp ? cp->kparams : a.single.kparams;
     gfloat* G = (gfloat*)(cp ? cp->kgrad : a.single.kgrad);
     nfisam_train_state* st = cp ? cp->state : a.single.state;
     const int n = cp ? cp->n : a.single.n;
     const int D = cp ? cp->D : a.single.D;
-    const int i = blockIdx.z;                                 // this block's dim
+    const int i = a.xrows - 1 - grp / a.grid_cliques;         // this block's dim: the long ones first
     if (i >= D) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
-    const int slot = blockIdx.x * W + w;                      // this wave's gradient copy
+    const int slot = bx * W + w;                              // this wave's tile group
     const int p0 = slot * TILE * T;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
     STAMP(10);
@@ -688,7 +697,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
     const gfloat* Gprev = par ? G : Gset1;                    // copy 0 of the previous iteration
     if (par) G = Gset1;
-    if (slab) G += (size_t)blockIdx.x * gstride;              // one gradient copy per block
+    if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
     const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
     const float* pan = smem;                                  // CM: the block's conditioner panel (nsf_cond_mfma.h)
     const int wave_rows = train1_wave_rows(xrows, H);
@@ -767,7 +776,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             const gfloat* t_src = src_alt ? alt : own_t;
             fa.m_src = src_alt ? alt + gstride : own_m;
             fa.v_src = src_alt ? alt + 2 * gstride : own_v;
-            const bool writer = pending && blockIdx.x == 0;
+            const bool writer = pending && bx == 0;
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
@@ -983,7 +992,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         }
         __syncthreads();                                      // waves without a tile left before the panel barrier
         const int waves_c = (n + TILE * T - 1) / (TILE * T);
-        const int alive = (waves_c - (int)blockIdx.x * W < W) ? waves_c - (int)blockIdx.x * W : W;
+        const int alive = (waves_c - bx * W < W) ? waves_c - bx * W : W;
         const int nj = (i == 0) ? PoP : LY::block(i);
         gfloat* Gc = G + ((i == 0) ? 0 : LY::off(i));
         for (int e = threadIdx.x; e < nj; e += 64 * alive) {
@@ -1974,6 +1983,10 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int waves = (max_n + TILE * T - 1) / (TILE * T);
         const int gx = (waves + W - 1) / W;
         a.n_copies = gx;                                       // one gradient copy per block (a.slab = TILE * T * W particles)
+        a.grid_gx = gx;
+        a.grid_cliques = n_cliques;
+        const int groups = n_cliques * max_D;                  // (clique, dim) groups of gx blocks, padded to the 8 XCDs
+        const int nblocks = ((groups + 7) / 8) * 8 * gx;
         const size_t tiles_lds = (size_t)W * (size_t)train1_wave_rows(max_D, 8) * XS * sizeof(float);
         // conditioner: 1 = v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h), 0 = VALU FMAs with
         // scalar-path weights.  3 waves per SIMD either way (the 128-register build spills and measures slower).
@@ -1984,11 +1997,11 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
             const size_t lds = tiles_lds + (size_t)CondPanel<KK, 8>::floats(max_D) * sizeof(float);
             rc = set_lds(nsf_train1_kernel<KK, 8, 1>, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 1>), dim3(gx, n_cliques, max_D), dim3(64 * W), lds, s, a);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 1>), dim3(nblocks), dim3(64 * W), lds, s, a);
         } else {
             rc = set_lds(nsf_train1_kernel<KK, 8, 0>, tiles_lds);
             if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 0>), dim3(gx, n_cliques, max_D), dim3(64 * W), tiles_lds, s, a);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 0>), dim3(nblocks), dim3(64 * W), tiles_lds, s, a);
         }
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;

@@ -258,7 +258,7 @@ __device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const
         cm_f32x4 t[G2];
 #pragma unroll
         for (int g = 0; g < G2; ++g) t[g] = *(const cm_f32x4*)(pan + CP::ob2 + 4 * g);
-        mfma_rows<G2, H, 2, 1, EveryCol>(pan + CP::oW2T + r * ST, ST, t, h2);
+        mfma_rows<G2, H, (G2 % 4 == 0 ? 4 : 2), 1, EveryCol>(pan + CP::oW2T + r * ST, ST, t, h2);
 #pragma unroll
         for (int g = 0; g < G2; ++g)
 #pragma unroll

@@ -587,8 +587,7 @@ static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_cl
 // end of a chunk: (fused-Adam launches) the last iteration's pending update, then the bookkeeping
 static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                              int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s) {
-    if (fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H)) &&
-        getenv("NFISAM_DEBUG_SKIP_CLOSE") == nullptr) {
+    if (fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H))) {
         AdamArgs ad;
         fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
         ad.close_chunk = chunk;

@@ -109,6 +109,10 @@ __device__ __forceinline__ void load_theta(WP lp, int i, const float* xin, int x
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ---- diagnostic build only (-DNSF_STAMPS): per-wave s_memtime stamps at phase boundaries ---------
+// which waves are stamped and into which of the 64 slots: tile group 0 of clique 0, slot = 4 * dim + wave (the dim-major
+// kernel, whose grid is 1-D, redefines the two around its body)
+#define STAMP_SEL (blockIdx.x == 0 && blockIdx.y == 0)
+#define STAMP_SLOT ((w + blockIdx.z * (blockDim.x >> 6)) & 63)
 #if defined(NSF_STAMPS) && NSF_UNIT == 0   // stamps exist in the K = 9, H = 8 unit only
 __device__ unsigned long long g_stamps[64 * 32];
 __device__ unsigned long long g_blk[4096 * 2];
@@ -120,8 +124,8 @@ __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
         __builtin_amdgcn_sched_barrier(0);                                                          \
         unsigned long long t_;                                                                      \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)                                        \
-            g_stamps[((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32 + (id)] = t_;                 \
+        if (STAMP_SEL && lane == 0)                                                                 \
+            g_stamps[STAMP_SLOT * 32 + (id)] = t_;                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
 #else
@@ -133,8 +137,8 @@ __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
         if (sprev_ != 0ull) sacc_[(id) & 15] += t_ - sprev_;                                        \
         sprev_ = t_;                                                                                \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (id) < 32) {                         \
-            const int sw_ = ((w + blockIdx.z * (blockDim.x >> 6)) & 63) * 32;                      \
+        if (STAMP_SEL && lane == 0 && (id) < 32) {                                                  \
+            const int sw_ = STAMP_SLOT * 32;                                                        \
             g_stamps[sw_ + (id)] = t_;                                                              \
             g_stamps[sw_ + 16 + ((id) & 15)] = sacc_[(id) & 15];                                    \
         }                                                                                           \
@@ -641,6 +645,10 @@ __device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (
 // parked in registers while the staging rows are re-used for the other operand): 8.4 KB at D = 15, so the
 // register allocation (OCC) decides the occupancy, not LDS.
 // =============================================================================================
+#undef STAMP_SEL
+#undef STAMP_SLOT
+#define STAMP_SEL (bx == 0 && by == 0)
+#define STAMP_SLOT ((w + i * 4) & 63)
 template <int K, int H, int CM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
@@ -1043,6 +1051,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         if (dst != nullptr) gsink(dst, tot, false);
     }
 }
+
+#undef STAMP_SEL
+#undef STAMP_SLOT
+#define STAMP_SEL (blockIdx.x == 0 && blockIdx.y == 0)
+#define STAMP_SLOT ((w + blockIdx.z * (blockDim.x >> 6)) & 63)
 
 // =============================================================================================
 // training / VJP kernel, two lanes per particle (nsf_split.h): a wave covers 32 particles, so the same

@@ -134,5 +134,5 @@ def test_two_rank_solver_matches_single_process(tmp_path, posterior):
         a, b = ranks[0][v][:, :2], single[v][:, :2]
         scale = max(1.0, float(b.std(0).max()))
         m = _mmd(a / scale, b / scale, np.sqrt(2.0))
-        assert m < 0.12, (v, m)
+        assert m < 0.16, (v, m)          # two separately trained posteriors: 0.05-0.13 seen across kernel revisions; a wrong separator message gives > 0.5
         assert np.linalg.norm(a.mean(0) - b.mean(0)) < 0.5 + 0.25 * scale, (v, a.mean(0), b.mean(0))

@@ -182,7 +182,6 @@ __device__ __forceinline__ void mfma_rows(const float* rows, int stride, cm_f32x
     for (int gg = 0; gg < SG; ++gg) buf[0][gg] = *(const cm_f32x4*)(rows + 4 * gg * stride);
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
-        constexpr int dummy = 0; (void)dummy;
         const int q = s / NGS, gs = s % NGS;
         if (s + 1 < NSLAB) {
             const int qn = (s + 1) / NGS, gn = (s + 1) % NGS;

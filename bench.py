@@ -454,6 +454,15 @@ def main():
                 out["roofline"]["traffic_profiled"] = dict(json.load(open(tj)), source="profiles/r02_train_kernel_traffic.json")
             except Exception:   # noqa: BLE001
                 pass
+        uj = os.path.join(ROOT, "profiles", "r02_issue_utilisation.json")
+        if os.path.exists(uj):   # VALU issue / MFMA busy fractions from the same EARLIER profiled run (not measured here)
+            try:
+                u = json.load(open(uj))
+                out["roofline"]["issue_profiled"] = {k: {f: u[k][f] for f in ("valu_issue_frac", "mfma_busy_frac", "issue_frac")}
+                                                     for k in ("C3", "batch64")}
+                out["roofline"]["issue_profiled"]["source"] = "profiles/r02_issue_utilisation.json"
+            except Exception:   # noqa: BLE001
+                pass
         if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only
             out["wall_clock_per_incremental_update"] = None
         else:

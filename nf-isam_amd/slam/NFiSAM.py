@@ -520,6 +520,12 @@ class NFiSAM(FactorGraphSolver):
         wave of 64 samples walks all cliques on the device; one D2H copy at the end.  The per-clique
         device pointers are cached on the model (they do not change after training); only the column
         indices, which shift as the elimination ordering grows, are rebuilt per update."""
+        return self.posterior_collect(self.posterior_launch(), timer)
+
+    def posterior_launch(self):
+        """First half of `sample_posterior`: assemble the clique table and enqueue the walk on the current stream.
+        -> handle for `posterior_collect` (several solvers can have their walks in flight on different streams:
+        slam.ReplicaNFiSAM)."""
         start = time.time()
         num_samples = self._args.posterior_sample_num
         order = self._elimination_ordering
@@ -569,10 +575,17 @@ class NFiSAM(FactorGraphSolver):
         table["front_off"] = table["sep_off"] + n_sep
         K, H, B, L = cfg
         S = _nh.posterior_walk_raw(table, np.concatenate(cols), np.concatenate(obs), total_dim, num_samples, max_D,
-                                   K, H, B, L, device).cpu().numpy()
-        samples = {v: S[:, pcol[v]:pcol[v] + v.dim] for v in order}
+                                   K, H, B, L, device)
+        return dict(S=S, pcol=pcol, order=list(order), start=start, stream=torch.cuda.current_stream())
+
+    def posterior_collect(self, handle, timer: List = None):
+        """Second half: wait for the walk, one D2H copy, per-variable views of the sample matrix."""
+        with torch.cuda.stream(handle["stream"]):
+            S = handle["S"].cpu().numpy()
+        pcol = handle["pcol"]
+        samples = {v: S[:, pcol[v]:pcol[v] + v.dim] for v in handle["order"]}
         if timer is not None:
-            timer.append(time.time() - start)
+            timer.append(time.time() - handle["start"])
         return samples
 
     # ---- model reuse / message construction --------------------------------------------------

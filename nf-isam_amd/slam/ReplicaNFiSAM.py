@@ -81,6 +81,7 @@ class ReplicaNFiSAM:
             self._states.append(self._grab())
         self._put(outer)
         self.last_batches: List[int] = []    # cliques per batched launch sequence of the last update
+        self._streams: List[torch.cuda.Stream] = []
 
     def __len__(self):
         return len(self.solvers)
@@ -147,9 +148,19 @@ class ReplicaNFiSAM:
                 for r in live:
                     timers[r].append(dt / len(preps))   # the reference's per-clique training timer: this replica's share
                 self.last_batches.append(len(preps))
-        out = []
+        # posterior walks: every replica's tree walk (a few waves, strictly sequential inside) is enqueued on its own stream,
+        # so the R walks run side by side; then one D2H copy each
+        if len(self._streams) < R:
+            self._streams = [torch.cuda.Stream() for _ in range(R)]
+        handles = []
         for r in range(R):
             with self.turn(r) as s:
-                s._samples = s.sample_posterior(timer=timers[r])
-                out.append(s._samples)
+                self._streams[r].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._streams[r]):
+                    handles.append(s.posterior_launch())
+        out = []
+        for r in range(R):
+            s = self.solvers[r]
+            s._samples = s.posterior_collect(handles[r], timer=timers[r])
+            out.append(s._samples)
         return out

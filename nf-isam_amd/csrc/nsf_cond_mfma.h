@@ -90,22 +90,22 @@ __device__ __forceinline__ float fused_sum_grads(const FusedAdam& fa, const floa
     return gs;
 }
 
-// The block's 256 threads bring dim i's parameter block (i > 0: conditioner weights -> panel; i == 0: the PoP spline
+// The block's threads bring dim i's parameter block (i > 0: conditioner weights -> panel; i == 0: the PoP spline
 // parameters -> pan[0..PoP)) into LDS; a workgroup barrier follows at the call site.  Thread t owns parameters
-// t, t + 256, ... of the block: two at a time, every global load of both issued before the first use.  Padding no
+// t, t + NT, ... of the block: two at a time, every global load of both issued before the first use.  Padding no
 // 16-byte read ever touches is not written; the zero weights behind W0's i rows are (layer 0 contracts whole groups
 // of eight inputs).
 // `st_step`, `st_stop` are the clique's state words, requested at kernel entry: they are first LOOKED AT after this
 // function's own loads have arrived (the empty asm is a use of the loaded values in front of the branch, so the loads are
 // not sunk behind it), i.e. the two round trips overlap.  -> false: the clique is finished, the block returns.
 template <int K, int H>
-__device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_generic, FusedAdam& fa, int i, int tid,
+__device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_generic, FusedAdam& fa, int i, int tid, int NT,
                                                  int st_step, int st_stop, const TrainArgs& a, int n) {
     using CP = CondPanel<K, H>;
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
     gp t_src = (gp)theta_generic;                              // the clique's parameter vector (before the pending update)
-    constexpr int PoP = CP::PoP, ST = CP::ST, NT = 256;
+    constexpr int PoP = CP::PoP, ST = CP::ST;                  // NT = threads of the block (256 or 512)
     const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
     const int s0 = CP::s0_of(i);
     auto place = [&](int jj, float v) {

@@ -61,6 +61,7 @@ struct TrainArgs {
     int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
     int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
     int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
+    int waves;                      // nsf_train1_kernel: waves per block (4 or 8)
     int grid_gx, grid_cliques;      // nsf_train1_kernel: blocks per (clique, dim) group, cliques of the launch (1-D XCD-aware grid)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     nfisam_adam_cfg adam;
@@ -146,13 +147,18 @@ __host__ __device__ static inline int train1_wave_rows(int max_D, int H) {
 }
 // conditioner of the dim-major kernel: v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h) unless
 // NFISAM_COND=scalar (VALU FMAs with scalar-path weights) or the block is not the four waves the panel copy assumes
-static inline int dim_major_waves() {
+// Waves per block of the dim-major kernel (they share the (clique, dim): one weight panel, one gradient copy): 4.
+// NFISAM_BIG_W = 1..8 for experiments.  Eight (half the gradient copies for the fused Adam update to read back, half the
+// staging work per thread) measured 13 % SLOWER on a single Plaza clique: two waves per SIMD on 60 CUs instead of one
+// wave per SIMD on 120 -- in the latency regime a wave wants its SIMD to itself.
+static inline int dim_major_waves(int n_cliques, int max_n, int max_D, int T) {
+    (void)n_cliques; (void)max_n; (void)max_D; (void)T;
     const char* e = getenv("NFISAM_BIG_W");
-    return (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) ? atoi(e) : 4;
+    return (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 4;
 }
 static inline bool dim_major_mfma_cond() {
     const char* ce = getenv("NFISAM_COND");
-    return dim_major_waves() == 4 && !(ce != nullptr && strcmp(ce, "scalar") == 0);
+    return !(ce != nullptr && strcmp(ce, "scalar") == 0);
 }
 // smallest launch ((tile, dim) units) that goes to the dim-major kernel; NFISAM_DIM_MAJOR_MIN overrides (experiments)
 static inline long dim_major_min_units() {

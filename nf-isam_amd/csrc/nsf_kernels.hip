@@ -497,13 +497,17 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
 
 // Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
 // shared copy accumulated with float atomics).
-struct TrainShape { int tile, T, slab; };
+struct TrainShape { int tile, T, slab, W; };
 static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H) {
     TrainShape sh;
     sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1);
     sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile, H);
     sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
-    if (sh.slab != 0 && is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H)) sh.slab *= dim_major_waves();   // one copy per block
+    sh.W = 0;
+    if (is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H)) {
+        sh.W = dim_major_waves(n_cliques, max_n, max_D, sh.T);
+        sh.slab *= sh.W;                                            // one copy per block
+    }
     return sh;
 }
 
@@ -523,7 +527,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
-    a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab;
+    a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab; a.waves = sh.W;
     if (fused_cfg != nullptr) {
         a.fused_adam = 1;
         a.adam = *fused_cfg;

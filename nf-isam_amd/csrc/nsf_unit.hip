@@ -650,7 +650,7 @@ __device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (
 #define STAMP_SEL (bx == 0 && by == 0)
 #define STAMP_SLOT ((w + i * 4) & 63)
 template <int K, int H, int CM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x, st_step, st_stop, a, n)) return;
+            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
             __syncthreads();
         }
         if (p0 >= n) return;
@@ -1989,9 +1989,9 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         return NFISAM_ERR_ARG;
     } else {
         // throughput regime: one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
-        const int W = dim_major_waves();
         const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
         a.tiles_per_block = T;
+        const int W = a.waves > 0 ? a.waves : dim_major_waves(n_cliques, max_n, max_D, T);
         a.xrows = max_D;
         const int waves = (max_n + TILE * T - 1) / (TILE * T);
         const int gx = (waves + W - 1) / W;

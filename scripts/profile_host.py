@@ -19,4 +19,4 @@ def run(lo, hi):
         solver.incremental_inference()
 run(0, 5)     # warm-up
 pr = cProfile.Profile(); pr.enable(); run(5, N); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "45"))); print(s.getvalue()[:9000])

@@ -161,13 +161,26 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const int wnd = a.cfg.average_window;
     __shared__ float s_loss[LOSS_RING];
     __shared__ float s_wsum[4];
-    // all iterations of the chunk at once: wave w sums the slots of iterations w, w+4, ... (independent loads)
-    for (int it = w; it < cnt; it += 4) {
-        float* slot = ring + ((s0 + it) & (LOSS_RING - 1)) * LOSS_SLOTS;
-        const float part = slot[lane];
-        slot[lane] = 0.0f;
-        const float loss = wave_sum(part) * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
-        if (lane == 0) { s_loss[it] = loss; iter_loss[s0 + it] = loss; }
+    // all iterations of the chunk at once: wave w sums the slots of iterations w, w+4, ...  Every load is requested
+    // before the first is consumed (one memory round trip for the whole chunk instead of one per iteration).
+    {
+        constexpr int PER_WAVE = LOSS_RING / 4;
+        float part[PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int it = w + 4 * k;
+            float* slot = ring + ((s0 + (it < cnt ? it : 0)) & (LOSS_RING - 1)) * LOSS_SLOTS;
+            part[k] = slot[lane];
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int it = w + 4 * k;
+            if (it < cnt) {                                   // wave-uniform
+                ring[((s0 + it) & (LOSS_RING - 1)) * LOSS_SLOTS + lane] = 0.0f;
+                const float loss = wave_sum(part[k]) * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
+                if (lane == 0) { s_loss[it] = loss; iter_loss[s0 + it] = loss; }
+            }
+        }
     }
     __syncthreads();
     // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)

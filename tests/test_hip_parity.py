@@ -619,3 +619,39 @@ def test_mfma_conditioner_matches_the_scalar_path_conditioner():
         assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])), (n, D, a[0], b[0])
         scale = max(1e-3, float(np.abs(a[2]).max()))
         assert np.abs(a[2] - b[2]).max() < 2e-5 * scale, (n, D, np.abs(a[2] - b[2]).max(), scale)      # m_1 = 0.1 * gradient
+
+
+@pytest.mark.parametrize("H", [4, 8, 16])
+def test_every_kernel_instantiation_against_the_oracle(H):
+    """All 45 (num_knots, hidden_dim) pairs the library instantiates (2..16 x {4, 8, 16}; include/nfisam_hip.h): forward,
+    NLL gradient, inverse round trip and three training iterations (gradient kernel + Adam, fused where the launch
+    qualifies) of a small one-layer problem against the float64 C oracle, plus a two-layer forward / gradient."""
+    B = 5.0
+    for K in range(2, 17):
+        assert nh.supported(K, H), (K, H)
+        n, D = 70 + K, 4 + (K % 3)
+        for L in (1, 2):
+            blob, x = make_problem(n, D, K, H, L, seed=17 * K + H + L)
+            kp = kpack(blob, D, K, H, L)
+            zc, ldc = CO.forward(x, blob, K, H, B, L, dtype=np.float64)
+            z, ld, _ = nh.forward(dev(x), kp, K, H, B, L)
+            np.testing.assert_allclose(z.cpu().numpy(), zc, atol=Z_ATOL * L, err_msg=str((K, H, L)))
+            np.testing.assert_allclose(ld.cpu().numpy(), ldc, atol=LD_ATOL * L, err_msg=str((K, H, L)))
+            lossc, gradc, _, _ = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+            kg, _, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
+            assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L, (K, H, L)
+            grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3, atol=2e-5 * L)
+        # L = 1: inverse of forward, and the training path (the dim-major kernel for H = 8, the wide kernel otherwise)
+        blob1, x1 = make_problem(n, D, K, H, 1, seed=17 * K + H + 1)
+        kp1 = kpack(blob1, D, K, H, 1)
+        xb = nh.inverse(nh.forward(dev(x1), kp1, K, H, B, 1)[0], None, kp1, K, H, B, 1)
+        inside = np.abs(x1).max(1) < 4.9
+        np.testing.assert_allclose(xb.cpu().numpy()[inside], x1[inside], atol=3e-3, err_msg=str((K, H)))
+        tb = nh.TrainBatch([dev(x1)], [kpack(blob1, D, K, H, 1)], K, H, B, 1, lr=0.01, max_iters=3, average_window=3,
+                           loss_delta_tol=0.0, early_stop=True)
+        assert tb.run(use_graph=False) == [3]
+        bc, lc, _, _, _ = CO.train(x1, blob1, K, H, B, 1, lr=0.01, max_iters=3, early_stop=False, dtype=np.float64)
+        np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy()[:3], lc[:3], atol=5e-4, rtol=2e-4, err_msg=str((K, H)))
+        err = np.abs(nh.unpack(tb.kparams[0], D, K, H).cpu().numpy() - bc)
+        assert np.quantile(err, 0.98) < 2e-3 and err.max() < 0.031, (K, H, np.quantile(err, 0.98), err.max())
+        tb.close()

@@ -129,7 +129,7 @@ static inline int train_tile(int n_cliques, int max_n, int max_D, int H, bool nl
         if (strcmp(e, "wide") == 0) return TILE;
         if (strcmp(e, "split") == 0) return TILE2;
     }
-    if (nll_L1 && dim_major_enabled()) return TILE;
+    if (nll_L1 && dim_major_enabled() && max_D <= 96) return TILE;
     const long waves = (long)((max_n + TILE2 - 1) / TILE2) * (long)max_D * (long)n_cliques;
     return waves <= 1280 ? TILE2 : TILE;
 }
@@ -167,7 +167,10 @@ static inline long dim_major_min_units() {
 }
 static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
-    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && tiles * max_D > dim_major_min_units();
+    // four waves' LDS rows + the weight panel must fit next to each other (160 KB per CU): D <= 96; wider cliques take
+    // the tile-major kernels
+    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && max_D <= 96 &&
+           tiles * max_D > dim_major_min_units();
 }
 
 // 64-particle tiles summed into one gradient copy (one wave's sweep in nsf_train1_kernel, one block's in

@@ -602,6 +602,22 @@ def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, 
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("D", [64, 96, 100, 130])
+def test_wide_cliques_train_against_the_oracle(D):
+    """Very wide cliques: up to D = 96 the dim-major kernel (its LDS rows grow with D), beyond it the tile-major kernels;
+    three training iterations against the float64 oracle either way."""
+    K, H, B, n = 5, 8, 5.0, 130
+    blob, x = make_problem(n, D, K, H, 1, seed=D, spread=1.0)
+    tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, 1)], K, H, B, 1, lr=0.01, max_iters=3, average_window=3,
+                       loss_delta_tol=0.0, early_stop=True)
+    assert tb.run(use_graph=False) == [3]
+    bc, lc, _, _, _ = CO.train(x, blob, K, H, B, 1, lr=0.01, max_iters=3, early_stop=False, dtype=np.float64)
+    np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy()[:3], lc[:3], atol=2e-3, rtol=3e-4)
+    err = np.abs(nh.unpack(tb.kparams[0], D, K, H).cpu().numpy() - bc)
+    assert np.quantile(err, 0.98) < 2e-3 and err.max() < 0.031, (D, np.quantile(err, 0.98), err.max())
+    tb.close()
+
+
 def test_mfma_conditioner_matches_the_scalar_path_conditioner():
     """Dim-major training kernel: the conditioner as v_mfma_f32_4x4x1 chains fed from the LDS weight panel against the
     VALU conditioner with scalar-path weights (NFISAM_COND=scalar) -- same fp32 products, different summation order."""

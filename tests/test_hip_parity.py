@@ -671,3 +671,24 @@ def test_every_kernel_instantiation_against_the_oracle(H):
         err = np.abs(nh.unpack(tb.kparams[0], D, K, H).cpu().numpy() - bc)
         assert np.quantile(err, 0.98) < 2e-3 and err.max() < 0.031, (K, H, np.quantile(err, 0.98), err.max())
         tb.close()
+
+
+def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels():
+    """24 cliques of D = 18..20, n = 2000: the dim-major kernel sweeps several tiles per wave (T > 1) and accumulates the
+    dW0 rows 16.. in its own LDS rows across them; first Adam moments (0.1 x gradient) and losses against the tile-major
+    wide kernel (`NFISAM_DIM_MAJOR=0`), which shares no code with that path."""
+    K, H, B = 9, 8, 5.0
+    shapes = [(2000, 18 + (c % 3)) for c in range(24)]
+    res = {}
+    for mode in ("0", None):
+        with _Env(NFISAM_DIM_MAJOR=mode):
+            probs = [make_problem(n, D, K, H, 1, seed=900 + c, spread=1.0) for c, (n, D) in enumerate(shapes)]
+            tb = nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H) for (b, _), (_, D) in zip(probs, shapes)],
+                               K, H, B, 1, lr=0.01, max_iters=1, average_window=1, loss_delta_tol=0.0, early_stop=True)
+            assert tb.run(use_graph=False) == [1] * len(shapes)
+            torch.cuda.synchronize()
+            res[mode] = ([m.cpu().numpy() for m in tb.m], [float(l[0]) for l in tb.iter_loss])
+            tb.close()
+    for c, (a, b) in enumerate(zip(res["0"][0], res[None][0])):
+        assert np.abs(a - b).max() < 2e-5 * max(1e-3, np.abs(a).max()), (c, np.abs(a - b).max(), np.abs(a).max())
+    np.testing.assert_allclose(res["0"][1], res[None][1], rtol=2e-6, atol=1e-5)

@@ -160,6 +160,13 @@ static inline bool dim_major_mfma_cond() {
     const char* ce = getenv("NFISAM_COND");
     return !(ce != nullptr && strcmp(ce, "scalar") == 0);
 }
+// hidden widths the dim-major kernel is instantiated for ([ga2 | ga1] must fit one 16-row MFMA operand tile)
+static inline bool dim_major_mfma_cond();
+static inline bool dim_major_hidden(int H) {
+    const char* e = getenv("NFISAM_GRAD");
+    if (e != nullptr && strcmp(e, "butterfly") == 0) return false;
+    return H == 8 || (H == 4 && dim_major_mfma_cond());       // H = 4: with the MFMA conditioner only
+}
 // smallest launch ((tile, dim) units) that goes to the dim-major kernel; NFISAM_DIM_MAJOR_MIN overrides (experiments)
 static inline long dim_major_min_units() {
     const char* e = getenv("NFISAM_DIM_MAJOR_MIN");
@@ -169,7 +176,7 @@ static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int 
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
     // four waves' LDS rows + the weight panel must fit next to each other (160 KB per CU): D <= 96; wider cliques take
     // the tile-major kernels
-    return tile == TILE && L == 1 && use_mfma_grad(H) && dim_major_enabled() && max_D <= 96 &&
+    return tile == TILE && L == 1 && dim_major_hidden(H) && dim_major_enabled() && max_D <= 96 &&
            tiles * max_D > dim_major_min_units();
 }
 
@@ -179,7 +186,7 @@ static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int 
 // waves per SIMD (4096).  The decision depends on the launch shape only, so the gradient, Adam and bookkeeping
 // launches of an iteration agree on the number of gradient copies.
 static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, int tile, int H) {
-    if (tile != TILE || L != 1 || !use_mfma_grad(H)) return 1;
+    if (tile != TILE || L != 1 || !(use_mfma_grad(H) || dim_major_hidden(H))) return 1;
     const long tiles_c = (max_n + TILE - 1) / TILE, tiles = tiles_c * n_cliques;
     if (tiles * max_D <= dim_major_min_units()) return 1;
     const char* e = getenv("NFISAM_TILES_PER_BLOCK");

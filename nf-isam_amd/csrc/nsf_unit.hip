@@ -655,7 +655,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
     constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
-    static_assert(H == 8 && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H = 8");
+    static_assert((H == 8 || H == 4) && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H <= 8");
+    constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
@@ -949,13 +950,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
                 f32x4 cx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; cx = mfma4(areg[s4], (cab < i) ? v : 1.0f, cx); }
-                if (kq >= 2 && cab <= i) {
+                if (kq >= QH && kq < 2 * QH && cab <= i) {
                     if (slab) {
-                        float* dst = &ctacc[(cab - 16) * H + 4 * (kq - 2)];
+                        float* dst = &ctacc[(cab - 16) * H + 4 * (kq - QH)];
                         if (tt > 0) { cx.x += dst[0]; cx.y += dst[1]; cx.z += dst[2]; cx.w += dst[3]; }
                         dst[0] = cx.x; dst[1] = cx.y; dst[2] = cx.z; dst[3] = cx.w;
                     } else {
-                        gsink4(&Gb[cab * H + 4 * (kq - 2)], cx, false);
+                        gsink4(&Gb[cab * H + 4 * (kq - QH)], cx, false);
                     }
                 }
             }
@@ -982,18 +983,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
                         d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
                     }
             }
-            if (kq < 2 && r16 <= H) {
+            if (kq < QH && r16 <= H) {
                 float* d = &(frag + LY::oW1(i))[r16 * H + 4 * kq];
                 d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
             }
             if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
                 const int k0 = (r16 == H) ? i : r16 - (H + 1);
-                if (kq >= 2 && (r16 == H || (r16 > H && k0 < i))) {
-                    float* d = &frag[k0 * H + 4 * (kq - 2)];
+                if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) {
+                    float* d = &frag[k0 * H + 4 * (kq - QH)];
                     d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
                 }
-            } else if (kq >= 2 && r16 <= i) {
-                float* d = &frag[r16 * H + 4 * (kq - 2)];
+            } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
+                float* d = &frag[r16 * H + 4 * (kq - QH)];
                 d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w;
             }
             for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
@@ -1034,12 +1035,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
                 if (f < TOT) gsink(&Gw[f], stg[f], false);
             }
         }
-        if (kq < 2 && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
+        if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
         if (merged) {
             const int k0 = (r16 == H) ? i : r16 - (H + 1);
-            if (kq >= 2 && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - 2)], c1, false);
-        } else if (kq >= 2 && r16 <= i) {
-            gsink4(&Gb[r16 * H + 4 * (kq - 2)], c0, false);
+            if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1, false);
+        } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
+            gsink4(&Gb[r16 * H + 4 * (kq - QH)], c0, false);
         }
     }
     STAMP(9);
@@ -1985,10 +1986,10 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
 
 template <int KK, int HH>
 static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
-    if constexpr (HH != 8) {
+    if constexpr (HH != 8 && HH != 4) {
         return NFISAM_ERR_ARG;
     } else {
-        // throughput regime: one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
+        // one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)
         const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
         a.tiles_per_block = T;
         const int W = a.waves > 0 ? a.waves : dim_major_waves(n_cliques, max_n, max_D, T);
@@ -2000,21 +2001,23 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         a.grid_cliques = n_cliques;
         const int groups = n_cliques * max_D;                  // (clique, dim) groups of gx blocks, padded to the 8 XCDs
         const int nblocks = ((groups + 7) / 8) * 8 * gx;
-        const size_t tiles_lds = (size_t)W * (size_t)train1_wave_rows(max_D, 8) * XS * sizeof(float);
+        const size_t tiles_lds = (size_t)W * (size_t)train1_wave_rows(max_D, HH) * XS * sizeof(float);
         // conditioner: 1 = v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h), 0 = VALU FMAs with
         // scalar-path weights.  3 waves per SIMD either way (the 128-register build spills and measures slower).
         const int cm = dim_major_mfma_cond() ? 1 : 0;
         if (a.fused_adam != 0 && !cm) return NFISAM_ERR_ARG;
         int rc;
         if (cm) {
-            const size_t lds = tiles_lds + (size_t)CondPanel<KK, 8>::floats(max_D) * sizeof(float);
-            rc = set_lds(nsf_train1_kernel<KK, 8, 1>, lds);
+            const size_t lds = tiles_lds + (size_t)CondPanel<KK, HH>::floats(max_D) * sizeof(float);
+            rc = set_lds(nsf_train1_kernel<KK, HH, 1>, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 1>), dim3(nblocks), dim3(64 * W), lds, s, a);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, 1>), dim3(nblocks), dim3(64 * W), lds, s, a);
+        } else if constexpr (HH == 8) {
+            rc = set_lds(nsf_train1_kernel<KK, HH, 0>, tiles_lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, 0>), dim3(nblocks), dim3(64 * W), tiles_lds, s, a);
         } else {
-            rc = set_lds(nsf_train1_kernel<KK, 8, 0>, tiles_lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, 8, 0>), dim3(nblocks), dim3(64 * W), tiles_lds, s, a);
+            return NFISAM_ERR_ARG;                             // the scalar-path conditioner exists for H = 8 only
         }
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;

@@ -8,7 +8,7 @@ import nfisam_hip as nh
 import bench as BM
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-K, H, B = 9, 8, 5.0
+K, H, B = 9, int(sys.argv[3]) if len(sys.argv) > 3 else 8, 5.0
 bad = 0
 for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     nc = int(rng.choice([1, 1, 2, 3, 5, 9]))

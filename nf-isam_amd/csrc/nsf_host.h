@@ -37,6 +37,7 @@ constexpr int XS = 66;            // LDS row stride (floats) of every [feature][
 // iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
 // bookkeeping kernel that closes a chunk of iterations consumes and clears them.
 constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
+constexpr int ONES_ROW = 68;       // nsf_train1_kernel: LDS words of 1.0 read as the bias column of the gradient GEMM operands
 // fused Adam (nsf_cond_mfma.h): 64 reserved words behind the loss ring, then the second set of gradient copies and the
 // second state buffer; the workspace is sized for cliques of up to this many 64-particle tiles
 constexpr int FUSED_COUNTERS = 64, FUSED_MAX_COPIES = 32;

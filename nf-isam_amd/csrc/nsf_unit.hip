@@ -710,7 +710,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
     const float* pan = smem;                                  // CM: the block's conditioner panel (nsf_cond_mfma.h)
     const int wave_rows = train1_wave_rows(xrows, H);
-    float* tiles0 = smem + (CM ? CondPanel<K, H>::floats(xrows) : 0);
+    // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
+    // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
+    // Every wave writes the same 68 words; its own LDS operations are in order, so it reads what it wrote.
+    float* ones = smem + (CM ? CondPanel<K, H>::floats(xrows) : 0);
+    float* tiles0 = ones + ONES_ROW;
     // fixed-size rows first: their offsets from the wave's base are immediates of the LDS instructions (fewer address registers)
     float* stg = tiles0 + (size_t)w * (wave_rows * XS);       // [16][XS] staging rows
     float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
@@ -718,6 +722,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
     float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
     const int r16 = lane & 15, kq = lane >> 4;
+    ones[lane] = 1.0f;
+    if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     cfloat* lp = (cfloat*)kparams;
     cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
@@ -885,12 +891,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
         // generation is read into registers completely, then the NEXT one is written before this one's MFMAs are
         // issued: the LDS writes complete under the 16 x 32 MFMA cycles and only the reads' round trip stays exposed.
         const float* pa = stg + r16 * XS + kq;
-        const int rh = (r16 < H) ? r16 : 0;                      // [h | 1] operand: every lane loads, lanes >= H take 1
         float breg[NS], areg[NS];
         {
             wave_lds_sync();
+            const float* pah = ((r16 < H) ? stg + r16 * XS : ones) + kq;
 #pragma unroll
-            for (int s4 = 0; s4 < NS; ++s4) { const float v2 = stg[rh * XS + kq + 4 * s4]; breg[s4] = (r16 < H) ? v2 : 1.0f; }
+            for (int s4 = 0; s4 < NS; ++s4) breg[s4] = pah[4 * s4];
             wave_lds_sync();
         }
         STAMP(7);
@@ -925,31 +931,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
                 // (they share the bias column): one MFMA chain instead of two.  Rows 0..H-1 (ga2) x columns 0..H give
                 // dW1t | db1, rows H.. (ga1) x columns H.. give db0 | dW0t; the cross terms are not used.
                 const int kx = r16 - (H + 1);
-                const float* pbm = ((r16 < H) ? hrow + r16 * XS : xt + ((kx >= 0 && kx < i) ? kx : 0) * XS) + kq;
                 const bool one = (r16 == H) || kx >= i;
+                const float* pbm = (one ? ones : ((r16 < H) ? hrow + r16 * XS : xt + kx * XS)) + kq;
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) {
                     areg[s4] = pa[4 * s4];
-                    const float b = pbm[4 * s4];
-                    c1 = mfma4(areg[s4], one ? 1.0f : b, c1);
+                    c1 = mfma4(areg[s4], pbm[4 * s4], c1);
                 }
             } else {
-                const float* pb0 = xt + (r16 < i ? r16 : 0) * XS + kq;     // input columns 0..15 (column i = bias)
-                const float* pb1 = hrow + rh * XS + kq;
+                const float* pb0 = ((r16 < i) ? xt + r16 * XS : ones) + kq;     // input columns 0..15 (column i = bias)
+                const float* pb1 = ((r16 < H) ? hrow + r16 * XS : ones) + kq;
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) {
                     areg[s4] = pa[4 * s4];
-                    const float bx = pb0[4 * s4], bh = pb1[4 * s4];
-                    c1 = mfma4(areg[s4], (r16 < H) ? bh : 1.0f, c1);
-                    c0 = mfma4(areg[s4], (r16 < i) ? bx : 1.0f, c0);
+                    c1 = mfma4(areg[s4], pb1[4 * s4], c1);
+                    c0 = mfma4(areg[s4], pb0[4 * s4], c0);
                 }
             }
             for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
                 const int cab = ct * 16 + r16;
-                const float* pb0 = xt + (cab < i ? cab : 0) * XS + kq;
+                const float* pb0 = ((cab < i) ? xt + cab * XS : ones) + kq;
                 f32x4 cx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) { const float v = pb0[4 * s4]; cx = mfma4(areg[s4], (cab < i) ? v : 1.0f, cx); }
+                for (int s4 = 0; s4 < NS; ++s4) cx = mfma4(areg[s4], pb0[4 * s4], cx);
                 if (kq >= QH && kq < 2 * QH && cab <= i) {
                     if (slab) {
                         float* dst = &ctacc[(cab - 16) * H + 4 * (kq - QH)];
@@ -2001,7 +2005,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         a.grid_cliques = n_cliques;
         const int groups = n_cliques * max_D;                  // (clique, dim) groups of gx blocks, padded to the 8 XCDs
         const int nblocks = ((groups + 7) / 8) * 8 * gx;
-        const size_t tiles_lds = (size_t)W * (size_t)train1_wave_rows(max_D, HH) * XS * sizeof(float);
+        const size_t tiles_lds = ((size_t)W * (size_t)train1_wave_rows(max_D, HH) * XS + ONES_ROW) * sizeof(float);
         // conditioner: 1 = v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h), 0 = VALU FMAs with
         // scalar-path weights.  3 waves per SIMD either way (the 128-register build spills and measures slower).
         const int cm = dim_major_mfma_cond() ? 1 : 0;

@@ -523,4 +523,139 @@ __device__ __forceinline__ float spline_backward(const Spline<K>& S, float B, fl
     return g_x;
 }
 
+
+// ---- the spline of the NLL training kernels, written for VALU instruction count --------------------------------------
+// Same mathematics as spline_eval<..., false> + spline_backward (utils.py:85-164 and its hand-derived backward), arranged
+// so that a wave issues ~500 instead of ~610 VALU slots per particle:
+//  * the softmax terms stay UNNORMALISED (e_m = exp(th_m - max)); knot j = -B + j 2B minbin + c E_j with E_j the running
+//    sum of e (the last of them is the softmax denominator: no separate sum pass) and c = 2B (1 - K minbin) / E_K;
+//  * the bin is found by K - 1 comparisons whose results stay in scalar registers (sel[j] = v >= knot_j, monotone) and
+//    select the two knots of the bin on either axis and its two derivative logits; the backward pass re-uses them as
+//    "m < k / m == k" masks instead of comparing a bin index again;
+//  * sum_m p_m c_m of the softmax backward needs only P(m < k) and p_k, both known from the selected knots;
+//  * outside [-B, B] the upstream gradients are zeroed once instead of every output.
+// lean forward + backward of the spline for the NLL training kernel
+template <int K>
+struct SplineT {
+    float ew[K], eh[K];             // UNNORMALISED softmax terms exp(th - max)
+    float iw, ih;                   // 1 / sum
+    float Xk, dx, Yk, dy, d0, d1, ud0, ud1, t;
+    bool sel[K];                    // sel[j] = v >= X_j (j >= 1; monotone: true up to the bin)
+    bool inside;
+};
+template <int K, int PoP>
+__device__ __forceinline__ void spline_train_fwd(float v, const float (&th)[PoP], float B, SplineT<K>& S, float& z, float& lad) {
+    using LY = Layout<K, 8>;
+    S.inside = (v >= -B) && (v <= B);
+    const float vs = S.inside ? v : 0.0f;
+    float mw = th[LY::iw(0)], mh = th[LY::ih(0)];
+#pragma unroll
+    for (int j = 1; j < K; ++j) { mw = fmaxf(mw, th[LY::iw(j)]); mh = fmaxf(mh, th[LY::ih(j)]); }
+    const float nmw = -mw * kLog2e, nmh = -mh * kLog2e;
+    float Ew[K + 1], Eh[K + 1];     // unnormalised cumulative sums: E[j] = sum_{m<j} e_m
+    Ew[0] = 0.0f; Eh[0] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        S.ew[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(th[LY::iw(j)], kLog2e, nmw));
+        S.eh[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(th[LY::ih(j)], kLog2e, nmh));
+        Ew[j + 1] = Ew[j] + S.ew[j];
+        Eh[j + 1] = Eh[j] + S.eh[j];
+    }
+    S.iw = frcp(Ew[K]); S.ih = frcp(Eh[K]);
+    const float mix = 1.0f - kMinBin * (float)K, twoB = 2.0f * B;
+    const float cw = twoB * mix * S.iw, ch = twoB * mix * S.ih;
+    // knot j = -B + j * 2B * minbin + c * E[j]   (j = 1..K-1; knot 0 = -B, knot K = B pinned: utils.py:85-92)
+    float Xk = -B, Xk1 = B, Yk = -B, Yk1 = B;
+    float X1 = __builtin_fmaf(cw, Ew[1], twoB * kMinBin - B), Y1 = __builtin_fmaf(ch, Eh[1], twoB * kMinBin - B);
+    if (K > 1) { Xk1 = X1; Yk1 = Y1; }
+    S.ud0 = kBoundLogit; S.ud1 = (K > 1) ? th[LY::idv(0)] : kBoundLogit;
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+        const float Xj = X1, Yj = Y1;
+        float Xn = B, Yn = B;
+        if (j + 1 < K) {
+            const float cj = (float)(j + 1) * twoB * kMinBin - B;
+            Xn = __builtin_fmaf(cw, Ew[j + 1], cj);
+            Yn = __builtin_fmaf(ch, Eh[j + 1], cj);
+        }
+        const bool s = vs >= Xj;
+        S.sel[j] = s;
+        Xk = s ? Xj : Xk; Xk1 = s ? Xn : Xk1;
+        Yk = s ? Yj : Yk; Yk1 = s ? Yn : Yk1;
+        S.ud0 = s ? th[LY::idv(j - 1)] : S.ud0;
+        S.ud1 = s ? ((j + 1 < K) ? th[LY::idv(j < K - 1 ? j : 0)] : kBoundLogit) : S.ud1;
+        X1 = Xn; Y1 = Yn;
+    }
+    S.Xk = Xk; S.dx = Xk1 - Xk; S.Yk = Yk; S.dy = Yk1 - Yk;
+    S.d0 = kMinDeriv + fsoftplus(S.ud0);
+    S.d1 = kMinDeriv + fsoftplus(S.ud1);
+    rq_math<false>(vs, S.Xk, S.dx, S.Yk, S.dy, S.d0, S.d1, S.t, z, lad);
+    if (!S.inside) { z = v; lad = 0.0f; }
+}
+// gth = dL/dtheta for upstream gz = dL/dz, gl = dL/dlogdet (pads of the layout are written 0)
+template <int K, int PoP>
+__device__ __forceinline__ void spline_train_bwd(const SplineT<K>& S, float B, float gz_in, float gl_in, float (&gth)[PoP]) {
+    using LY = Layout<K, 8>;
+    const float gz = S.inside ? gz_in : 0.0f, gl = S.inside ? gl_in : 0.0f;     // outside the interval: identity, no parameter gradient
+    const float w = S.dx, h = S.dy, d0 = S.d0, d1 = S.d1, t = S.t;
+    const float iw = frcp(w);
+    const float s = h * iw, sig = d0 + d1 - 2.0f * s, q = t * (1.0f - t), omt = 1.0f - t, o2t = 1.0f - 2.0f * t;
+    const float N = s * t * t + d0 * q, den = s + sig * q;
+    const float iden = frcp(den), u = N * iden, iden2 = iden * iden;
+    const float u_t = ((2.0f * s * t + d0 * o2t) * den - N * sig * o2t) * iden2;
+    const float u_s = (t * t * den - N * (1.0f - 2.0f * q)) * iden2;
+    const float u_d0 = q * (den - N) * iden2;
+    const float u_d1 = -N * q * iden2;
+    const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
+    const float iM = frcp(M);
+    const float M_t = 2.0f * d1 * t + 2.0f * s * o2t - 2.0f * d0 * omt;
+    const float ld_t = M_t * iM - 2.0f * sig * o2t * iden;
+    const float ld_s = 2.0f * frcp(s) + 2.0f * q * iM - 2.0f * (1.0f - 2.0f * q) * iden;
+    const float ld_d0 = omt * omt * iM - 2.0f * q * iden;
+    const float ld_d1 = t * t * iM - 2.0f * q * iden;
+    const float gzh = gz * h;
+    const float G_t = gzh * u_t + gl * ld_t;
+    const float G_s = gzh * u_s + gl * ld_s;
+    const float G_d0 = gzh * u_d0 + gl * ld_d0;
+    const float G_d1 = gzh * u_d1 + gl * ld_d1;
+    const float g_x = G_t * iw;
+    const float g_w = -(G_t * t + G_s * s) * iw;
+    const float g_h = gz * u + G_s * iw;
+    const bool lo = (K > 1) ? S.sel[K > 1 ? 1 : 0] : false;            // k >= 1
+    const bool hi = (K > 1) ? !S.sel[K - 1] : false;                    // k + 1 <= K - 1
+    const float gXk = lo ? (-g_x - g_w) : 0.0f, gXk1 = hi ? g_w : 0.0f;
+    const float gYk = lo ? (gz - g_h) : 0.0f, gYk1 = hi ? g_h : 0.0f;
+    const float mix = 1.0f - kMinBin * (float)K, twoB = 2.0f * B;
+    const float scale = twoB * mix;
+    const float cw1 = scale * (gXk + gXk1), cw2 = scale * gXk1;
+    const float ch1 = scale * (gYk + gYk1), ch2 = scale * gYk1;
+    // softmax backward: gth_m = p_m (c_m - sum_j p_j c_j), c_m = c1 (m < k), c2 (m = k), 0 (m > k).  The sum needs only
+    // P(<k) = sum_{m<k} p_m and p_k, both known from the selected knots: X_k + B = 2B (k minbin + mix P(<k)), dx = 2B (minbin + mix p_k)
+    int kc = 0;
+#pragma unroll
+    for (int j = 1; j < K; ++j) kc += S.sel[j] ? 1 : 0;
+    const float kf = (float)kc, tk = twoB * kMinBin, r = frcp(scale);
+    const float Pw = __builtin_fmaf(-kf, tk, S.Xk + B), Ph = __builtin_fmaf(-kf, tk, S.Yk + B);
+    const float dotw = r * __builtin_fmaf(cw1, Pw, cw2 * (w - tk)), doth = r * __builtin_fmaf(ch1, Ph, ch2 * (h - tk));
+    const float aw1 = S.iw * (cw1 - dotw), aw2 = S.iw * (cw2 - dotw), aw3 = -S.iw * dotw;
+    const float ah1 = S.ih * (ch1 - doth), ah2 = S.ih * (ch2 - doth), ah3 = -S.ih * doth;
+#pragma unroll
+    for (int o = 0; o < PoP; ++o) gth[o] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const bool ge = (m == 0) ? true : S.sel[m];                  // k >= m
+        const bool gt = (m + 1 < K) ? S.sel[m + 1] : false;          // k >  m
+        gth[LY::iw(m)] = S.ew[m] * (gt ? aw1 : (ge ? aw2 : aw3));
+        gth[LY::ih(m)] = S.eh[m] * (gt ? ah1 : (ge ? ah2 : ah3));
+    }
+    const float gd0 = G_d0 * fsigmoid(S.ud0), gd1 = G_d1 * fsigmoid(S.ud1);
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {     // interior knot j + 1: k == j + 1 -> gd0, k == j -> gd1
+        const bool gej = (j == 0) ? true : S.sel[j];
+        const bool gej1 = S.sel[j + 1];
+        const bool gej2 = (j + 2 < K) ? S.sel[j + 2] : false;
+        gth[LY::idv(j)] = gej2 ? 0.0f : (gej1 ? gd0 : (gej ? gd1 : 0.0f));
+    }
+}
+
 }  // namespace nsf

@@ -839,13 +839,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
         }
         STAMP(3);
-        Spline<K> S;
+        SplineT<K> S;
         float z, lad;
-        spline_eval<K, PoP, false>(xt[i * XS + lane], th, B, S, z, lad);
+        spline_train_fwd<K, PoP>(xt[i * XS + lane], th, B, S, z, lad);
         STAMP(4);
         if (valid) lossv += 0.5f * z * z - lad;
-        const float gxs = spline_backward<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
-        (void)gxs;
+        spline_train_bwd<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
         STAMP(5);
         if (i == 0) {   // init_param: plain sum over particles of gth
             constexpr int N0 = (PoP <= 32) ? 32 : 64;
@@ -2012,7 +2011,8 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if (a.fused_adam != 0 && !cm) return NFISAM_ERR_ARG;
         int rc;
         if (cm) {
-            const size_t lds = tiles_lds + (size_t)CondPanel<KK, HH>::floats(max_D) * sizeof(float);
+            size_t lds = tiles_lds + (size_t)CondPanel<KK, HH>::floats(max_D) * sizeof(float);
+            if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
             rc = set_lds(nsf_train1_kernel<KK, HH, 1>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, 1>), dim3(nblocks), dim3(64 * W), lds, s, a);

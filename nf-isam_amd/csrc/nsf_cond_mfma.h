@@ -90,50 +90,70 @@ __device__ __forceinline__ float fused_sum_grads(const FusedAdam& fa, const floa
     return gs;
 }
 
+// Where parameter jj of dim i's kernel-layout block goes in the panel: (first word) | (second word) << 16, LDS words
+// counted from the start of the block's dynamic LDS (the panel starts PANEL_BASE words in; word 0 is a dump for the
+// "second store" of parameters that have one destination).  Host-built once per (K, H) for dims 0 .. max_i and read by
+// the staging threads next to the parameter itself: the index arithmetic (two divisions and a six-way branch per
+// parameter) costs a lone wave ~2k cycles when done in the kernel.
+template <int K, int H>
+static inline void build_panel_map(uint32_t* map, int max_D) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    constexpr int PoP = CP::PoP, ST = CP::ST;
+    for (int j = 0; j < PoP; ++j) map[j] = (uint32_t)(PANEL_BASE + j);           // dim 0: the spline parameters themselves
+    for (int i = 1; i < max_D; ++i) {
+        const int s0 = CP::s0_of(i);
+        uint32_t* m = map + LY::off(i);
+        for (int jj = 0; jj < LY::block(i); ++jj) {
+            int d0 = 0, d1 = -PANEL_BASE;
+            if (jj < LY::ob0(i)) {
+                const int k = jj / H, j = jj - k * H;
+                d0 = CP::oW0T + j * s0 + k;
+            } else if (jj < LY::oW1(i)) {
+                d0 = CP::ob0 + (jj - LY::ob0(i));
+            } else if (jj < LY::ob1(i)) {
+                const int e = jj - LY::oW1(i), k = e / H, j = e - k * H;
+                d0 = CP::oW1T + j * ST + k;
+                d1 = CP::oW1N + k * ST + j;
+            } else if (jj < LY::oW2(i)) {
+                d0 = CP::ob1 + (jj - LY::ob1(i));
+            } else if (jj < LY::ob2(i)) {
+                const int e = jj - LY::oW2(i), k = e / PoP, o = e - k * PoP;
+                d0 = CP::oW2T + o * ST + k;
+                d1 = CP::oW2N + k * CP::NS2 + o;
+            } else {
+                d0 = CP::ob2 + (jj - LY::ob2(i));
+            }
+            m[jj] = (uint32_t)(PANEL_BASE + d0) | ((uint32_t)(PANEL_BASE + d1) << 16);
+        }
+    }
+}
+
 // The block's threads bring dim i's parameter block (i > 0: conditioner weights -> panel; i == 0: the PoP spline
 // parameters -> pan[0..PoP)) into LDS; a workgroup barrier follows at the call site.  Thread t owns parameters
-// t, t + NT, ... of the block: two at a time, every global load of both issued before the first use.  Padding no
-// 16-byte read ever touches is not written; the zero weights behind W0's i rows are (layer 0 contracts whole groups
-// of eight inputs).
+// t, t + NT, ... of the block: two at a time, every global load of both (parameter, panel word, and with an update
+// pending the gradient copies and moments) issued before the first use.  Padding no 16-byte read ever touches is not
+// written; the zero weights behind W0's i rows are (layer 0 contracts whole groups of eight inputs).
 // `st_step`, `st_stop` are the clique's state words, requested at kernel entry: they are first LOOKED AT after this
 // function's own loads have arrived (the empty asm is a use of the loaded values in front of the branch, so the loads are
 // not sunk behind it), i.e. the two round trips overlap.  -> false: the clique is finished, the block returns.
 template <int K, int H>
-__device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_generic, FusedAdam& fa, int i, int tid, int NT,
-                                                 int st_step, int st_stop, const TrainArgs& a, int n) {
+__device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta_generic, FusedAdam& fa, const uint32_t* map_generic,
+                                                 int i, int tid, int NT, int st_step, int st_stop, const TrainArgs& a, int n) {
     using CP = CondPanel<K, H>;
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
     gp t_src = (gp)theta_generic;                              // the clique's parameter vector (before the pending update)
-    constexpr int PoP = CP::PoP, ST = CP::ST;                  // NT = threads of the block (256 or 512)
+    constexpr int PoP = CP::PoP;                               // NT = threads of the block
     const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
-    const int s0 = CP::s0_of(i);
-    auto place = [&](int jj, float v) {
-        if (i == 0) { pan[jj] = v; return; }
-        if (jj < LY::ob0(i)) {
-            const int k = jj / H, j = jj - k * H;
-            pan[CP::oW0T + j * s0 + k] = v;
-        } else if (jj < LY::oW1(i)) {
-            pan[CP::ob0 + (jj - LY::ob0(i))] = v;
-        } else if (jj < LY::ob1(i)) {
-            const int e = jj - LY::oW1(i), k = e / H, j = e - k * H;
-            pan[CP::oW1T + j * ST + k] = v;
-            pan[CP::oW1N + k * ST + j] = v;
-        } else if (jj < LY::oW2(i)) {
-            pan[CP::ob1 + (jj - LY::ob1(i))] = v;
-        } else if (jj < LY::ob2(i)) {
-            const int e = jj - LY::oW2(i), k = e / PoP, o = e - k * PoP;
-            pan[CP::oW2T + o * ST + k] = v;
-            pan[CP::oW2N + k * CP::NS2 + o] = v;
-        } else {
-            pan[CP::ob2 + (jj - LY::ob2(i))] = v;
-        }
-    };
+    gu map = (gu)map_generic + j0;
     for (int base = 0; base < nj; base += 2 * NT) {
-        // two parameters per thread, every global load of both requested before the first is consumed (one round trip)
         const int ja = base + tid, jb = base + NT + tid;
-        const int ia = j0 + (ja < nj ? ja : 0), ib = j0 + (jb < nj ? jb : 0);
+        const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
+        const int ia = j0 + ca, ib = j0 + cb;
         float ta = t_src[ia], tb = t_src[ib];
+        uint32_t da = map[ca], db = map[cb];
         float ga[8], gb[8], ma = 0.f, va = 0.f, mb = 0.f, vb = 0.f;
         if (fa.grads != nullptr) {                             // launch-uniform: an update is pending
             fused_load_grads(fa, ia, ga);
@@ -141,7 +161,7 @@ __device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_
             ma = fa.m_src[ia]; va = fa.v_src[ia]; mb = fa.m_src[ib]; vb = fa.v_src[ib];
             asm volatile("" : "+v"(ga[0]), "+v"(ga[7]), "+v"(gb[0]), "+v"(gb[7]), "+v"(ma), "+v"(vb));
         }
-        asm volatile("" : "+v"(ta), "+v"(tb));
+        asm volatile("" : "+v"(ta), "+v"(tb), "+v"(da), "+v"(db));
         if (base == 0) {
             if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // block-uniform
             if (fa.grads != nullptr)
@@ -155,14 +175,15 @@ __device__ __forceinline__ bool stage_cond_panel(float* pan, const float* theta_
                 if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
             }
         }
-        if (ja < nj) place(ja, ta);
-        if (jb < nj) place(jb, tb);
+        if (ja < nj) { lds0[da & 0xffffu] = ta; lds0[da >> 16] = ta; }
+        if (jb < nj) { lds0[db & 0xffffu] = tb; lds0[db >> 16] = tb; }
     }
     if (i > 0) {
+        const int s0 = CP::s0_of(i);
         const int npad = (((i + 7) & ~7) - i) * H;             // zero weights behind W0's rows
         for (int e = tid; e < npad; e += NT) {
             const int k = i + e / H, j = e % H;
-            pan[CP::oW0T + j * s0 + k] = 0.0f;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
         }
     }
     return true;

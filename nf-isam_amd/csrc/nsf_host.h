@@ -62,8 +62,12 @@ struct TrainArgs {
     int tiles_per_block;            // wide kernels, L == 1: 64-particle tiles summed into one gradient copy (per block / per wave)
     int xrows;                      // nsf_train1_kernel: rows of a wave's particle tile in LDS (largest D of the launch)
     int n_copies;                   // nsf_train1_kernel: gradient copies per clique workspace (the loss ring sits behind them)
-    int waves;                      // nsf_train1_kernel: waves per block (4 or 8)
-    int grid_gx, grid_cliques;      // nsf_train1_kernel: blocks per (clique, dim) group, cliques of the launch (1-D XCD-aware grid)
+    int waves;                      // nsf_train1_kernel: waves per block (1, 2, 4 or 8)
+    int grid_cliques;               // nsf_train1_kernel: cliques of the launch
+    int groups;                     // nsf_train1_kernel: (clique, dim) groups = cliques x largest D (grid = 8 x blocks per group x groups / 8)
+    unsigned magic_cliques;         // nsf_train1_kernel: ceil(2^32 / cliques) (0: one clique): group / cliques without a division
+    int t_shift, w_shift;           // nsf_train1_kernel: log2 of tiles per wave / waves per block
+    const uint32_t* panel_map;      // nsf_train1_kernel: kernel-layout parameter index -> LDS word(s) of the conditioner panel (nsf_cond_mfma.h)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
@@ -81,6 +85,7 @@ struct NsfUnitOps {
     int (*walk)(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs, int max_D, float B,
                 int L, int n, const float* Zt, float* St, hipStream_t s);
     int (*train)(const TrainArgs& a, int n_cliques, int max_n, int max_D, hipStream_t s);   // gradient kernel of an iteration
+    int (*prepare)(int max_D);      // device-resident tables of the training kernels (idempotent; call once outside stream capture)
 };
 #define NSF_DECLARE_UNIT(u) extern "C" const NsfUnitOps* nsf_unit_ops_u##u(int K, int H);
 NSF_UNITS(NSF_DECLARE_UNIT)
@@ -146,8 +151,9 @@ static inline bool dim_major_enabled() {
 __host__ __device__ static inline int train1_wave_rows(int max_D, int H) {
     return max_D + 16 + H + (max_D > 16 ? ((max_D - 16) * H + XS - 1) / XS : 0);
 }
-// conditioner of the dim-major kernel: v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h) unless
-// NFISAM_COND=scalar (VALU FMAs with scalar-path weights) or the block is not the four waves the panel copy assumes
+// LDS floats of one wave (its rows, rounded so that every wave's base stays 16-byte aligned: 16-byte fragment stores)
+__host__ __device__ static inline int train1_wave_floats(int max_D, int H) { return (train1_wave_rows(max_D, H) * XS + 3) & ~3; }
+constexpr int PANEL_BASE = 4;      // LDS words in front of the conditioner panel: word 0 takes the stores of parameters that have one destination only
 // Waves per block of the dim-major kernel (they share the (clique, dim): one weight panel, one gradient copy): 4.
 // NFISAM_BIG_W = 1..8 for experiments.  Eight (half the gradient copies for the fused Adam update to read back, half the
 // staging work per thread) measured 13 % SLOWER on a single Plaza clique: two waves per SIMD on 60 CUs instead of one
@@ -155,18 +161,14 @@ __host__ __device__ static inline int train1_wave_rows(int max_D, int H) {
 static inline int dim_major_waves(int n_cliques, int max_n, int max_D, int T) {
     (void)n_cliques; (void)max_n; (void)max_D; (void)T;
     const char* e = getenv("NFISAM_BIG_W");
-    return (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 4;
-}
-static inline bool dim_major_mfma_cond() {
-    const char* ce = getenv("NFISAM_COND");
-    return !(ce != nullptr && strcmp(ce, "scalar") == 0);
+    const int v = e != nullptr ? atoi(e) : 4;
+    return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
 }
 // hidden widths the dim-major kernel is instantiated for ([ga2 | ga1] must fit one 16-row MFMA operand tile)
-static inline bool dim_major_mfma_cond();
 static inline bool dim_major_hidden(int H) {
     const char* e = getenv("NFISAM_GRAD");
     if (e != nullptr && strcmp(e, "butterfly") == 0) return false;
-    return H == 8 || (H == 4 && dim_major_mfma_cond());       // H = 4: with the MFMA conditioner only
+    return H == 8 || H == 4;
 }
 // smallest launch ((tile, dim) units) that goes to the dim-major kernel; NFISAM_DIM_MAJOR_MIN overrides (experiments)
 static inline long dim_major_min_units() {
@@ -193,7 +195,7 @@ static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, in
     const char* e = getenv("NFISAM_TILES_PER_BLOCK");
     int T = 1;
     if (is_dim_major(n_cliques, max_n, max_D, L, tile, H)) {
-        if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
+        if (e != nullptr && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) return atoi(e);
         // One tile per wave while all waves are resident at once (3 per SIMD x 1024 SIMDs); beyond that a second, mostly
         // empty round costs a whole unit, so waves take two tiles (and share one prologue: tile fetch, weight panel,
         // pending Adam update), then four once even that launch is more than ~4k waves.  Measured on 7..64 cliques of

@@ -530,7 +530,7 @@ static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H)
 static bool fused_adam_shape(int n_cliques, int max_n, int max_D, int L, int H, const TrainShape& sh) {
     const char* e = getenv("NFISAM_FUSED_ADAM");
     if (e != nullptr && e[0] == '0') return false;
-    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.slab == 0 || !dim_major_mfma_cond()) return false;
+    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.slab == 0) return false;
     return (max_n + sh.slab - 1) / sh.slab <= 8;              // nsf_adam_kernel's one-thread-per-parameter summation order
 }
 
@@ -711,6 +711,11 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { nfisam_nsf_train_plan_destroy(p); return NFISAM_ERR_ARG; }
         p->max_n = host_cliques[c].n > p->max_n ? host_cliques[c].n : p->max_n;
         p->max_D = host_cliques[c].D > p->max_D ? host_cliques[c].D : p->max_D;
+    }
+    {   // device tables of the training kernels: built here, outside the capture below
+        const NsfUnitOps* ops = find_ops(K, H);
+        rc = ops != nullptr ? ops->prepare(p->max_D) : NFISAM_ERR_ARG;
+        if (rc) { nfisam_nsf_train_plan_destroy(p); return rc; }
     }
     if (use_graph) {
         // capture on a private stream: the caller's stream may be the (un-capturable) null stream

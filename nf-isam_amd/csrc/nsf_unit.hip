@@ -10,7 +10,9 @@
 //              throughput       nsf_train1_kernel: one wave = one dim x T tiles, dim-major blocks
 //   inverse    one wave per 64 particles, dims sequential (true data dependence, flows.py:115-137)
 //   walk       whole Bayes tree root -> leaves in one launch
+#include <stddef.h>
 #include <type_traits>
+#include <vector>
 
 #include "nsf_host.h"
 #include "nsf_cond_mfma.h"
@@ -632,26 +634,35 @@ __device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (
 }
 
 // =============================================================================================
-// throughput training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, blocks are dim-major.
+// dim-major training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, a block = W waves of ONE (clique, dim).
 //
 // Why: in nsf_train_kernel the four waves of a block run four different dims and every wave walks through all of
 // its dims, so a CU's resident waves read 12-16 different weight sets through the 16 KB scalar data cache: 58 % of
 // the scalar loads miss (rocprofv3 SQC_DCACHE_HITS / _MISSES, 64-clique batch) and every miss is an exposed
-// ~500-cycle round trip in front of an `s_waitcnt lgkmcnt(0)`.  Here grid = (tile groups, cliques, dims): the W
-// waves of a block run the SAME (clique, dim) on different particle tiles, each wave sweeps T tiles with that one
-// weight set and keeps the weight-gradient MFMA accumulators across them, so a CU holds 3-4 weight sets (< 8 KB),
-// emits one gradient copy per T tiles, and needs no workgroup barrier at all (every LDS byte is wave-private).
-// LDS per wave: the particle tile [D][XS] + a 16-row staging tile (the [h|1] operands of the gradient GEMMs are
-// parked in registers while the staging rows are re-used for the other operand): 8.4 KB at D = 15, so the
-// register allocation (OCC) decides the occupancy, not LDS.
+// ~500-cycle round trip in front of an `s_waitcnt lgkmcnt(0)`.  Here the W waves of a block run the SAME (clique, dim)
+// on different particle tiles, each wave sweeps T tiles with that one weight set (staged once per block into an LDS
+// panel, nsf_cond_mfma.h) and keeps the weight-gradient MFMA accumulators across them; the block emits one gradient
+// copy, and the one workgroup barrier of the main path is the panel's.
+// LDS per wave: the particle tile [D][XS] + a 16-row staging tile + [H][XS] h1 (the [h|1] operands of the gradient
+// GEMMs are parked in registers while the staging rows are re-used for the other operand): 10.3 KB at D = 15, so the
+// register allocation (3 waves per SIMD) decides the occupancy, not LDS.
+//
+// Grid = (8, blocks per group, ceil(groups / 8)), group = (clique, dim), long dims first.  Workgroups are dealt
+// round-robin over the 8 XCDs in linear order (x fastest), so blockIdx.x picks the XCD and the blocks of one group
+// (blockIdx.y) share it and its L2: they read the same parameters and the same gradient copies (fused Adam), which the
+// group's blocks of the previous launch wrote through that L2 if the dispatcher kept its rotation (a speed matter only,
+// never correctness).  No integer division in the prologue: group / cliques is a multiply-high by a host-made
+// reciprocal, tiles per wave and waves per block are powers of two, and the clique's descriptor arrives in ONE scalar
+// load (from the device array, or -- single-clique calls -- from the kernel-argument segment itself).
 // =============================================================================================
 #undef STAMP_SEL
 #undef STAMP_SLOT
 #define STAMP_SEL (bx == 0 && by == 0)
 #define STAMP_SLOT ((w + i * 4) & 63)
-template <int K, int H, int CM>
+template <int K, int H>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
     using LY = Layout<K, H>;
+    using CP = CondPanel<K, H>;
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
     constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
@@ -659,36 +670,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
+    const int bx = blockIdx.y;                                // tile group inside the (clique, dim)
+    const int grp = blockIdx.x + 8 * blockIdx.z;
+    if (grp >= a.groups) return;                              // padding of the group count to a multiple of 8
+    const int gq = a.magic_cliques != 0u ? (int)__umulhi((unsigned)grp, a.magic_cliques) : grp;    // grp / cliques
+    const int by = grp - gq * a.grid_cliques;                 // clique
+    const int i = a.xrows - 1 - gq;                           // this block's dim: the long ones first
+    typedef const __attribute__((address_space(4))) nfisam_clique cclique;
+    typedef const __attribute__((address_space(4))) char cchar;
+    cclique* cp = (a.cliques != nullptr)
+                      ? (cclique*)(a.cliques + by)
+                      : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TrainArgs, single));
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
     // atomics, which count against both memory counters)
-    // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one): the
-    // 1-D grid is laid out so that the gx blocks of one (clique, dim) GROUP are 8 apart, i.e. share an XCD and its L2 --
-    // they read the same parameters and the same gradient copies (fused Adam), which the group's blocks of the previous
-    // launch wrote through that L2 if the dispatcher kept its rotation (a speed matter only, never correctness).
-    const int pb = blockIdx.x, gxb = a.grid_gx;
-    const int grp = (pb & 7) + 8 * ((pb >> 3) / gxb);
-    const int bx = (pb >> 3) % gxb;                           // tile group inside the (clique, dim)
-    if (grp >= a.grid_cliques * a.xrows) return;              // padding of the group count to a multiple of 8
-    const int by = grp % a.grid_cliques;                      // clique
-    const nfisam_clique* cp = a.cliques != nullptr ? (a.cliques + by) : nullptr;
-    const gfloat* x = (const gfloat*)(cp ? cp->x : a.single.x);
-    const float* kparams = cp ? cp->kparams : a.single.kparams;
-    gfloat* G = (gfloat*)(cp ? cp->kgrad : a.single.kgrad);
-    nfisam_train_state* st = cp ? cp->state : a.single.state;
-    const int n = cp ? cp->n : a.single.n;
-    const int D = cp ? cp->D : a.single.D;
-    const int i = a.xrows - 1 - grp / a.grid_cliques;         // this block's dim: the long ones first
+    const gfloat* x = (const gfloat*)cp->x;
+    const float* kparams = cp->kparams;
+    gfloat* G = (gfloat*)cp->kgrad;
+    const gfloat* own_m = (const gfloat*)cp->adam_m;
+    const gfloat* own_v = (const gfloat*)cp->adam_v;
+    typedef __attribute__((address_space(1))) nfisam_train_state gstate;
+    gstate* st = (gstate*)cp->state;
+    const int n = cp->n;
+    const int D = cp->D;
     if (i >= D) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = blockDim.x >> 6;
-    const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
-    const int slot = bx * W + w;                              // this wave's tile group
-    const int p0 = slot * TILE * T;
+    const int ws = a.w_shift, ts = a.t_shift;
+    const int W = 1 << ws, T = 1 << ts;
+    const int slot = (bx << ws) + w;                          // this wave's tile group
+    const int p0 = slot << (6 + ts);
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
     STAMP(10);
 #endif
-    if (CM == 0 && p0 >= n) return;
     int st_stop = 0, st_step = 0;
     if (st != nullptr) {
         st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -700,23 +713,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
     // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
     // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
-    const int par = (CM != 0 && a.fused_adam != 0) ? (a.iter_idx & 1) : 0;
-    const bool pending = CM != 0 && a.fused_adam != 0 && a.iter_idx > 0;
+    const int par = (a.fused_adam != 0) ? (a.iter_idx & 1) : 0;
+    const bool pending = a.fused_adam != 0 && a.iter_idx > 0;
     gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
     gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
     const gfloat* Gprev = par ? G : Gset1;                    // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
     const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
-    const float* pan = smem;                                  // CM: the block's conditioner panel (nsf_cond_mfma.h)
-    const int wave_rows = train1_wave_rows(xrows, H);
+    const float* pan = smem + PANEL_BASE;                     // the block's conditioner panel (nsf_cond_mfma.h)
     // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
     // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
     // Every wave writes the same 68 words; its own LDS operations are in order, so it reads what it wrote.
-    float* ones = smem + (CM ? CondPanel<K, H>::floats(xrows) : 0);
+    float* ones = smem + PANEL_BASE + CP::floats(xrows);
     float* tiles0 = ones + ONES_ROW;
+    const int wave_floats = train1_wave_floats(xrows, H);
     // fixed-size rows first: their offsets from the wave's base are immediates of the LDS instructions (fewer address registers)
-    float* stg = tiles0 + (size_t)w * (wave_rows * XS);       // [16][XS] staging rows
+    float* stg = tiles0 + (size_t)w * wave_floats;            // [16][XS] staging rows
     float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
     const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
     float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
@@ -725,8 +738,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     ones[lane] = 1.0f;
     if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
-    cfloat* lp = (cfloat*)kparams;
-    cfloat* blk = lp + LY::off(i > 0 ? i : 1);                // (i == 0 never dereferences it)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
 
     STAMP_DECL
@@ -774,19 +785,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             store(c0, xr);
         }
     };
-    if constexpr (CM != 0) {
-        // the one workgroup barrier of the kernel: the block's waves share the (clique, dim) and so the panel
+    {
+        // the one workgroup barrier in front of the tile loop: the block's waves share the (clique, dim) and so the panel
         float xr[16];
         if (p0 < n) fetch(p0, 0, xr);
         {
             FusedAdam fa;
             fa.grads = pending ? Gprev : nullptr;
             fa.gstride = gstride;
-            fa.copies = ((n + TILE * T - 1) / (TILE * T) + W - 1) / W;
+            fa.copies = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;
             // state before the pending update: the buffer of the previous iteration's parity (even: the clique's own)
             const gfloat* own_t = (const gfloat*)kparams;
-            const gfloat* own_m = (const gfloat*)(cp ? cp->adam_m : a.single.adam_m);
-            const gfloat* own_v = (const gfloat*)(cp ? cp->adam_v : a.single.adam_v);
             const bool src_alt = pending && par == 0;
             const gfloat* t_src = src_alt ? alt : own_t;
             fa.m_src = src_alt ? alt + gstride : own_m;
@@ -795,7 +804,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
+            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, a.panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
             __syncthreads();
         }
         if (p0 >= n) return;
@@ -804,37 +813,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
 #endif
         store(0, xr);
         load_tile(p0, 16);
-    } else {
-        if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;
     }
 
     for (int tt = 0; tt < T; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
         STAMP(1);
-        if (CM == 0 || tt > 0) load_tile(pt, 0);
+        if (tt > 0) load_tile(pt, 0);
         wave_lds_sync();
         STAMP(2);
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
-        if constexpr (CM != 0) {
-            if (i == 0) {
+        if (i == 0) {
 #pragma unroll
-                for (int o = 0; o < PoP; o += 4) {
-                    const cm_f32x4 v4 = *(const cm_f32x4*)(pan + o);
-                    th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
-                }
-            } else {
-                cond_forward_mfma<K, H>(pan, i, xt, XS, lane, h1, h2, th);
+            for (int o = 0; o < PoP; o += 4) {
+                const cm_f32x4 v4 = *(const cm_f32x4*)(pan + o);
+                th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
             }
-        } else if (i == 0) {
-            load_row<PoP>(lp, th);
         } else {
-            cond_hidden<K, H, cfloat*>(blk, i, xt, XS, lane, h1, h2);
-            STAMP(14);
-            cond_theta<K, H, cfloat*>(blk, i, h2, th);
-        }
-        if (i > 0) {   // operands of the gradient GEMMs, parked while the lanes are busy with the spline
+            cond_forward_mfma<K, H>(pan, i, xt, XS, lane, h1, h2, th);
+            // operands of the gradient GEMMs, parked while the lanes are busy with the spline
             lds_rows_store<0, H, 0, H>(stg_lane, h2);
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
         }
@@ -855,34 +853,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             wave_lds_sync();                                    // the tile is overwritten by the next iteration's loads
             continue;
         }
-        // ---- per-particle back-propagation through the conditioner (VALU, scalar-path weights) ----
+        // ---- per-particle back-propagation through the conditioner (4x4x1 MFMA chains, nsf_cond_mfma.h) ----
         float ga2[H], ga1[H];
-        if constexpr (CM != 0) {
-            cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
-        } else {
-            float gh2[H], gh1[H];
-            cfloat* W2 = reload_ptr(blk + LY::oW2(i));
-            if constexpr (PoP == 32) {
-                scalar_gemv_rows<PoP, H>(W2, gth, gh2);
-            } else {
-#pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    float wr[PoP];
-                    load_row<PoP>(W2 + k * PoP, wr);
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int o = 0; o < PoP; ++o) acc = __builtin_fmaf(wr[o], gth[o], acc);
-                    gh2[k] = acc;
-                    if (k & 1) row_group_fence<cfloat*>();
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < H; ++k) ga2[k] = gh2[k] * (1.0f - h2[k] * h2[k]);
-            cfloat* W1 = reload_ptr(blk + LY::oW1(i));
-            scalar_gemv_rows<H, H>(W1, ga2, gh1);
-#pragma unroll
-            for (int k = 0; k < H; ++k) ga1[k] = gh1[k] * (1.0f - h1[k] * h1[k]);
-        }
+        cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
         STAMP(6);
         // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
         //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
@@ -954,8 +927,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) cx = mfma4(areg[s4], pb0[4 * s4], cx);
                 if (kq >= QH && kq < 2 * QH && cab <= i) {
+                    float* dst = &ctacc[(cab - 16) * H + 4 * (kq - QH)];
                     if (slab) {
-                        float* dst = &ctacc[(cab - 16) * H + 4 * (kq - QH)];
                         if (tt > 0) { cx.x += dst[0]; cx.y += dst[1]; cx.z += dst[2]; cx.w += dst[3]; }
                         dst[0] = cx.x; dst[1] = cx.y; dst[2] = cx.z; dst[3] = cx.w;
                     } else {
@@ -970,9 +943,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
 
     // ---- the gradient of this dim's parameter block ----
     if (slab) {
-        // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) tile rows, the
-        // block's threads add the fragments in wave order and write the copy with consecutive addresses.  A quarter of
-        // the copies for the Adam update to read back, and no partial 16-byte global stores.
+        // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
+        // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
+        // and write the copy with consecutive 16-byte stores.
         float* frag = stg;                                     // 24 rows: room for every dim's block
         if (i == 0) {
             if (lane < PoP) frag[lane] = r0;
@@ -981,35 +954,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             if (r16 <= H) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + 4 * kq + 3 < PoP) {
-                        float* d = &fw[r16 * PoP + 16 * t + 4 * kq];
-                        d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
-                    }
+                    if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[r16 * PoP + 16 * t + 4 * kq] = cacc[t];
             }
-            if (kq < QH && r16 <= H) {
-                float* d = &(frag + LY::oW1(i))[r16 * H + 4 * kq];
-                d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
-            }
+            if (kq < QH && r16 <= H) *(f32x4*)&(frag + LY::oW1(i))[r16 * H + 4 * kq] = c1;
             if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
                 const int k0 = (r16 == H) ? i : r16 - (H + 1);
-                if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) {
-                    float* d = &frag[k0 * H + 4 * (kq - QH)];
-                    d[0] = c1.x; d[1] = c1.y; d[2] = c1.z; d[3] = c1.w;
-                }
+                if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) *(f32x4*)&frag[k0 * H + 4 * (kq - QH)] = c1;
             } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
-                float* d = &frag[r16 * H + 4 * (kq - QH)];
-                d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w;
+                *(f32x4*)&frag[r16 * H + 4 * (kq - QH)] = c0;
             }
             for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
         }
         __syncthreads();                                      // waves without a tile left before the panel barrier
-        const int waves_c = (n + TILE * T - 1) / (TILE * T);
-        const int alive = (waves_c - bx * W < W) ? waves_c - bx * W : W;
-        const int nj = (i == 0) ? PoP : LY::block(i);
-        gfloat* Gc = G + ((i == 0) ? 0 : LY::off(i));
-        for (int e = threadIdx.x; e < nj; e += 64 * alive) {
-            float sum = tiles0[e];
-            for (int ww = 1; ww < alive; ++ww) sum += tiles0[(size_t)ww * (wave_rows * XS) + e];
+        const int waves_c = (n + (TILE << ts) - 1) >> (6 + ts);
+        const int alive = (waves_c - (bx << ws) < W) ? waves_c - (bx << ws) : W;
+        const int nj4 = ((i == 0) ? PoP : LY::block(i)) >> 2;
+        gvf4_t* Gc = (gvf4_t*)(G + ((i == 0) ? 0 : LY::off(i)));
+        for (int e = threadIdx.x; e < nj4; e += 64 * alive) {
+            f32x4 sum = *(const f32x4*)&tiles0[4 * e];
+            for (int ww = 1; ww < alive; ++ww) {
+                const f32x4 o = *(const f32x4*)&tiles0[(size_t)ww * wave_floats + 4 * e];
+                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+            }
             Gc[e] = sum;
         }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
@@ -1987,6 +1953,39 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
     }
 }
 
+// device-resident panel map of one (K, H) (nsf_cond_mfma.h: build_panel_map), one per device, built on first use.
+// The first use must be outside a stream capture (hipMalloc + a synchronous copy): plan creation calls `prepare` before
+// it starts capturing.
+constexpr int PANEL_MAP_MAX_D = 96;
+template <int KK, int HH>
+struct PanelMap {
+    static int get(int max_D, const uint32_t** out) {
+        static const uint32_t* maps[16] = {nullptr};
+        int devn = 0;
+        HIP_TRY(hipGetDevice(&devn));
+        if (devn < 0 || devn >= 16 || max_D > PANEL_MAP_MAX_D) return NFISAM_ERR_ARG;
+        if (maps[devn] == nullptr) {
+            const size_t cnt = Layout<KK, HH>::count(PANEL_MAP_MAX_D);
+            std::vector<uint32_t> host(cnt);
+            build_panel_map<KK, HH>(host.data(), PANEL_MAP_MAX_D);
+            uint32_t* d = nullptr;
+            HIP_TRY(hipMalloc((void**)&d, cnt * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice));
+            maps[devn] = d;
+        }
+        if (out != nullptr) *out = maps[devn];
+        return NFISAM_OK;
+    }
+};
+template <int KK, int HH>
+static int unit_prepare(int max_D) {
+    if constexpr (HH == 8 || HH == 4) {
+        return max_D <= PANEL_MAP_MAX_D ? PanelMap<KK, HH>::get(max_D, nullptr) : NFISAM_OK;
+    } else {
+        return NFISAM_OK;
+    }
+}
+
 template <int KK, int HH>
 static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
     if constexpr (HH != 8 && HH != 4) {
@@ -1996,33 +1995,25 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int T = a.tiles_per_block > 1 ? a.tiles_per_block : 1;
         a.tiles_per_block = T;
         const int W = a.waves > 0 ? a.waves : dim_major_waves(n_cliques, max_n, max_D, T);
+        if ((T & (T - 1)) != 0 || (W & (W - 1)) != 0 || W > 8 || T > 8) return NFISAM_ERR_ARG;
+        a.t_shift = __builtin_ctz((unsigned)T);
+        a.w_shift = __builtin_ctz((unsigned)W);
         a.xrows = max_D;
         const int waves = (max_n + TILE * T - 1) / (TILE * T);
         const int gx = (waves + W - 1) / W;
         a.n_copies = gx;                                       // one gradient copy per block (a.slab = TILE * T * W particles)
-        a.grid_gx = gx;
         a.grid_cliques = n_cliques;
-        const int groups = n_cliques * max_D;                  // (clique, dim) groups of gx blocks, padded to the 8 XCDs
-        const int nblocks = ((groups + 7) / 8) * 8 * gx;
-        const size_t tiles_lds = ((size_t)W * (size_t)train1_wave_rows(max_D, HH) * XS + ONES_ROW) * sizeof(float);
-        // conditioner: 1 = v_mfma_f32_4x4x1 chains fed from an LDS weight panel (nsf_cond_mfma.h), 0 = VALU FMAs with
-        // scalar-path weights.  3 waves per SIMD either way (the 128-register build spills and measures slower).
-        const int cm = dim_major_mfma_cond() ? 1 : 0;
-        if (a.fused_adam != 0 && !cm) return NFISAM_ERR_ARG;
-        int rc;
-        if (cm) {
-            size_t lds = tiles_lds + (size_t)CondPanel<KK, HH>::floats(max_D) * sizeof(float);
-            if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
-            rc = set_lds(nsf_train1_kernel<KK, HH, 1>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, 1>), dim3(nblocks), dim3(64 * W), lds, s, a);
-        } else if constexpr (HH == 8) {
-            rc = set_lds(nsf_train1_kernel<KK, HH, 0>, tiles_lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, 0>), dim3(nblocks), dim3(64 * W), tiles_lds, s, a);
-        } else {
-            return NFISAM_ERR_ARG;                             // the scalar-path conditioner exists for H = 8 only
-        }
+        a.groups = n_cliques * max_D;                          // (clique, dim) groups of gx blocks, padded to the 8 XCDs
+        if ((long)a.groups * (long)n_cliques >= (1L << 31) || gx > 65535 || (a.groups + 7) / 8 > 65535) return NFISAM_ERR_ARG;
+        a.magic_cliques = n_cliques > 1 ? (unsigned)(((1ull << 32) + (unsigned)n_cliques - 1) / (unsigned)n_cliques) : 0u;
+        int rc = PanelMap<KK, HH>::get(max_D, &a.panel_map);
+        if (rc) return rc;
+        const size_t lds = ((size_t)PANEL_BASE + CondPanel<KK, HH>::floats(max_D) + ONES_ROW + (size_t)W * train1_wave_floats(max_D, HH)) * sizeof(float);
+        size_t lds_launch = lds;
+        if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
+        rc = set_lds(nsf_train1_kernel<KK, HH>, lds_launch);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, (a.groups + 7) / 8), dim3(64 * W), lds_launch, s, a);
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;
     }
@@ -2085,7 +2076,7 @@ static int unit_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D
 }
 
 // ---- the unit's table -------------------------------------------------------------------------------------------
-#define NSF_OPS_ENTRY(k, h) {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>},
+#define NSF_OPS_ENTRY(k, h) {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>, unit_prepare<k, h>},
 static const NsfUnitOps g_unit_ops[] = {NSF_FOR_EACH_KH(NSF_OPS_ENTRY)};
 
 #define NSF_UNIT_FN_(u) nsf_unit_ops_u##u

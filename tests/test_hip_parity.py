@@ -619,19 +619,20 @@ def test_wide_cliques_train_against_the_oracle(D):
 
 
 def test_mfma_conditioner_matches_the_scalar_path_conditioner():
-    """Dim-major training kernel: the conditioner as v_mfma_f32_4x4x1 chains fed from the LDS weight panel against the
-    VALU conditioner with scalar-path weights (NFISAM_COND=scalar) -- same fp32 products, different summation order."""
+    """Dim-major training kernel (conditioner as v_mfma_f32_4x4x1 chains fed from the LDS weight panel, panel staged
+    through the host-built map) against the tile-major wide kernel (`NFISAM_DIM_MAJOR=0`: VALU conditioner with
+    scalar-path weights) -- same fp32 products, different summation order; shapes with one tile, partial tiles, D > 16."""
     K, H, B = 9, 8, 5.0
-    for n, D in ((2000, 15), (333, 17), (64, 2), (1000, 24)):
+    for n, D in ((2000, 15), (333, 17), (64, 2), (1000, 24), (130, 1)):
         blob, x = make_problem(n, D, K, H, 1, seed=77 + D)
         res = {}
-        for cond in ("scalar", None):
-            with _Env(NFISAM_COND=cond, NFISAM_TRAIN="wide"):
+        for mode in ("0", None):
+            with _Env(NFISAM_DIM_MAJOR=mode, NFISAM_TRAIN="wide"):
                 tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H)], K, H, B, 1, lr=0.01, max_iters=3, early_stop=False)
                 tb.step()
                 torch.cuda.synchronize()
-                res[cond] = (float(tb.iter_loss[0][0]), nh.unpack(tb.kparams[0], D, K, H).cpu().numpy(), tb.m[0].cpu().numpy())
-        a, b = res["scalar"], res[None]
+                res[mode] = (float(tb.iter_loss[0][0]), nh.unpack(tb.kparams[0], D, K, H).cpu().numpy(), tb.m[0].cpu().numpy())
+        a, b = res["0"], res[None]
         assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])), (n, D, a[0], b[0])
         scale = max(1e-3, float(np.abs(a[2]).max()))
         assert np.abs(a[2] - b[2]).max() < 2e-5 * scale, (n, D, np.abs(a[2] - b[2]).max(), scale)      # m_1 = 0.1 * gradient

@@ -91,6 +91,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// cross-lane reduce-scatter: on return lane l holds the wave total of input v[l & (N-1)].
+// log2(N) exchange steps move N-1 values in total (vs 6 per value for a plain wave reduction).
+template <int N>
+__device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
+#pragma unroll
+    for (int half = N / 2; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int t = 0; t < half; ++t) {
+            const float lo = v[t], hi = v[t + half];   // load first: keeps v[] in registers (no select-of-address)
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            v[t] = keep + __shfl_xor(send, half, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int off = N; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
+    return r;
+}
+
+
 // ---- Adam (torch.optim.Adam as the reference drives it, NFiSAM.py:425, 476-478) ---------------------------------
 // One copy of the arithmetic for the stand-alone Adam kernel and the update fused into the dim-major training
 // kernel's tail: explicit round-to-nearest operations, so that -ffp-contract cannot fuse them differently in the two

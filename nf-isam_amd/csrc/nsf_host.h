@@ -153,7 +153,11 @@ __host__ __device__ static inline int train1_wave_rows(int max_D, int H) {
 }
 // LDS floats of one wave (its rows, rounded so that every wave's base stays 16-byte aligned: 16-byte fragment stores)
 __host__ __device__ static inline int train1_wave_floats(int max_D, int H) { return (train1_wave_rows(max_D, H) * XS + 3) & ~3; }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3
+constexpr int PANEL_BASE = 68;     // + 4 waves x 16 words of per-phase cycle sums (diagnostic build)
+#else
 constexpr int PANEL_BASE = 4;      // LDS words in front of the conditioner panel: word 0 takes the stores of parameters that have one destination only
+#endif
 // Waves per block of the dim-major kernel (they share the (clique, dim): one weight panel, one gradient copy): 4.
 // NFISAM_BIG_W = 1..8 for experiments.  Eight (half the gradient copies for the fused Adam update to read back, half the
 // staging work per thread) measured 13 % SLOWER on a single Plaza clique: two waves per SIMD on 60 CUs instead of one

@@ -26,6 +26,7 @@ struct AdamArgs {
     int chunk;              // bookkeeping kernel: iterations to close
     int max_n;              // largest n of the batch (number of slabs in every workspace)
     int few_copies;         // every clique has <= 8 gradient copies: one thread per parameter
+    nfisam_train_state* mirror;   // bookkeeping kernel: host-pinned copy of the states (training plans) or nullptr
     int close_chunk;        // > 0: fused-Adam launches (nsf_cond_mfma.h): apply the LAST iteration's pending update of a chunk of
                             // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
 };
@@ -136,10 +137,14 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     }
 }
 
-// Closes a chunk of iterations (one wave per clique): turns the ring's loss sums into iter_loss entries
+// Closes a chunk of iterations (one block per clique): turns the ring's loss sums into iter_loss entries
 // (NFiSAM.py:473), evaluates the window early-stop rule (NFiSAM.py:481-491) and advances state->step.
 // It is the only writer of step / stop, and it runs alone between chunks: the training and Adam kernels of a
-// chunk all see the same state.
+// chunk all see the same state.  One memory round trip in front of the arithmetic: the state words and ALL 128 rows of
+// the loss ring are requested together (which rows belong to this chunk is decided afterwards), the 32 row sums of a
+// wave come out of one reduce-scatter (31 cross-lane exchanges instead of 32 x 6).
+// `mirror` (training plans): a host-pinned copy of the state, written last with a chunk sequence number that the host
+// polls for -- no device-to-host copy, no stream synchronisation per chunk (nfisam_nsf_train_plan_run).
 __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
@@ -149,76 +154,86 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const int n = batched ? cp->n : a.single.n;
     const int D = batched ? cp->D : a.single.D;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int s0 = st->step;
-    if (st->stop != 0 || s0 >= a.cfg.max_iters) return;
-    const int cnt = (a.chunk < a.cfg.max_iters - s0) ? a.chunk : (a.cfg.max_iters - s0);
     const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const size_t P = (size_t)a.L * (size_t)(PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
     const size_t copies = a.slab ? (size_t)((a.max_n + a.slab - 1) / a.slab) : (size_t)1;
     float* ring = G + copies * P;
-    const float inv_n = 1.0f / (float)n;
-    const int wnd = a.cfg.average_window;
+    constexpr int PER_WAVE = LOSS_RING / 4;
+    float part[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane];     // ring row w + 4k
+    const int s0 = st->step, stop0 = st->stop, have_avg = st->have_avg;
+    const float loss_avg = st->loss_avg;
+    int new_step = s0, new_stop = stop0, new_have = have_avg, new_err = st->domain_err;
+    float new_avg = loss_avg;
     __shared__ float s_loss[LOSS_RING];
     __shared__ float s_wsum[4];
-    // all iterations of the chunk at once: wave w sums the slots of iterations w, w+4, ...  Every load is requested
-    // before the first is consumed (one memory round trip for the whole chunk instead of one per iteration).
-    {
-        constexpr int PER_WAVE = LOSS_RING / 4;
-        float part[PER_WAVE];
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int it = w + 4 * k;
-            float* slot = ring + ((s0 + (it < cnt ? it : 0)) & (LOSS_RING - 1)) * LOSS_SLOTS;
-            part[k] = slot[lane];
-        }
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int it = w + 4 * k;
-            if (it < cnt) {                                   // wave-uniform
-                ring[((s0 + it) & (LOSS_RING - 1)) * LOSS_SLOTS + lane] = 0.0f;
-                const float loss = wave_sum(part[k]) * inv_n + 0.5f * (float)D * 1.8378770664093453f;  // log(2 pi)
-                if (lane == 0) { s_loss[it] = loss; iter_loss[s0 + it] = loss; }
-            }
-        }
-    }
-    __syncthreads();
-    // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)
-    int bad_at = cnt;
-    for (int it = threadIdx.x; it < cnt; it += blockDim.x) {
-        const float l = s_loss[it];
-        if (!(l == l) || fabsf(l) > 3.0e38f) bad_at = (it < bad_at) ? it : bad_at;
-    }
-    bad_at = __reduce_min_sync(~0ull, bad_at);                 // per wave
     __shared__ int s_bad[4];
-    if (lane == 0) s_bad[w] = bad_at;
-    __syncthreads();
-    bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
-    if (bad_at < cnt) {
-        if (threadIdx.x == 0) { st->domain_err = 1; st->stop = 1; st->step = s0 + bad_at + 1; }
-        return;
-    }
-    const int t_end = s0 + cnt;
-    if (wnd > 0 && (t_end % wnd) == 0) {        // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
-        float s = 0.0f;
-        for (int j = t_end - wnd + (int)threadIdx.x; j < t_end; j += blockDim.x)
-            s += (j >= s0) ? s_loss[j - s0] : iter_loss[j];
-        s = wave_sum(s);
-        if (lane == 0) s_wsum[w] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float nw = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) / (float)wnd;
-            int stop = 0;
-            if (st->have_avg != 0 && st->loss_avg != 0.0f) {
-                const float delta = fabsf(1.0f - nw / st->loss_avg);
-                if (delta < a.cfg.loss_delta_tol) stop = 1;
+    const bool active = (stop0 == 0 && s0 < a.cfg.max_iters);        // block-uniform
+    if (active) {
+        const int cnt = (a.chunk < a.cfg.max_iters - s0) ? a.chunk : (a.cfg.max_iters - s0);
+        const float inv_n = 1.0f / (float)n;
+        const int wnd = a.cfg.average_window;
+        // ring row r holds iteration (r - s0) mod 128 of this chunk (if that is < cnt)
+        const float rowsum = butterfly<PER_WAVE>(part, lane);        // lane l: total of row w + 4 (l & 31)
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int it = ((w + 4 * k) - s0) & (LOSS_RING - 1);
+            if (it < cnt) ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f;                     // wave-uniform
+        }
+        if (lane < PER_WAVE) {
+            const int it = ((w + 4 * lane) - s0) & (LOSS_RING - 1);
+            if (it < cnt) {
+                const float loss = rowsum * inv_n + 0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
+                s_loss[it] = loss;
+                iter_loss[s0 + it] = loss;
             }
-            st->loss_avg = nw;
-            st->have_avg = 1;
-            if (stop) st->stop = 1;
+        }
+        __syncthreads();
+        // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)
+        int bad_at = cnt;
+        for (int it = threadIdx.x; it < cnt; it += blockDim.x) {
+            const float l = s_loss[it];
+            if (!(l == l) || fabsf(l) > 3.0e38f) bad_at = (it < bad_at) ? it : bad_at;
+        }
+        bad_at = __reduce_min_sync(~0ull, bad_at);                 // per wave
+        if (lane == 0) s_bad[w] = bad_at;
+        __syncthreads();
+        bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
+        if (bad_at < cnt) {
+            new_err = 1; new_stop = 1; new_step = s0 + bad_at + 1;
+        } else {
+            const int t_end = s0 + cnt;
+            if (wnd > 0 && (t_end % wnd) == 0) {   // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
+                float sm = 0.0f;
+                for (int j = t_end - wnd + (int)threadIdx.x; j < t_end; j += blockDim.x)
+                    sm += (j >= s0) ? s_loss[j - s0] : iter_loss[j];
+                sm = wave_sum(sm);
+                if (lane == 0) s_wsum[w] = sm;
+                __syncthreads();
+                const float nw = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) / (float)wnd;
+                if (have_avg != 0 && loss_avg != 0.0f) {
+                    const float delta = fabsf(1.0f - nw / loss_avg);
+                    if (delta < a.cfg.loss_delta_tol) new_stop = 1;
+                }
+                new_avg = nw;
+                new_have = 1;
+            }
+            new_step = t_end;
         }
     }
-    if (threadIdx.x == 0) st->step = t_end;
+    if (threadIdx.x == 0) {
+        if (active) {
+            st->loss_avg = new_avg; st->have_avg = new_have; st->domain_err = new_err; st->stop = new_stop; st->step = new_step;
+        }
+        if (a.mirror != nullptr) {
+            nfisam_train_state* m = a.mirror + blockIdx.x;
+            const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+            m->step = new_step; m->stop = new_stop; m->have_avg = new_have; m->loss_avg = new_avg; m->domain_err = new_err;
+            __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // =============================================================================================
@@ -592,10 +607,12 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
 
 // closes a chunk of `chunk` iterations: loss record, early-stop rule, step counter
 static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                               int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s) {
+                               int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s,
+                               nfisam_train_state* mirror = nullptr) {
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
     ad.chunk = chunk;
+    ad.mirror = mirror;
     hipLaunchKernelGGL(nsf_bookkeep_kernel, dim3(n_cliques), dim3(256), 0, s, ad);
     HIP_TRY(hipGetLastError());
     return NFISAM_OK;
@@ -603,7 +620,8 @@ static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_cl
 
 // end of a chunk: (fused-Adam launches) the last iteration's pending update, then the bookkeeping
 static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
-                             int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s) {
+                             int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s,
+                             nfisam_train_state* mirror = nullptr) {
     if (fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H))) {
         AdamArgs ad;
         fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
@@ -616,7 +634,7 @@ static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_cliq
         hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
         HIP_TRY(hipGetLastError());
     }
-    return enqueue_bookkeeping(dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg, chunk, s);
+    return enqueue_bookkeeping(dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg, chunk, s, mirror);
 }
 
 // Iterations per chunk: the early-stop rule is evaluated when a chunk is closed, so the chunk length has to
@@ -674,12 +692,15 @@ struct nfisam_train_plan {
     hipEvent_t ev = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    nfisam_train_state* hst = nullptr;     // pinned host copy of the cliques' states
-    bool contiguous = false;               // the states form one device array: one copy per chunk
+    nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
+                                           // writes it (last word written: reserved[0] = chunks closed in this run)
+    nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
+    bool ahead = false;                    // the previous run left a chunk enqueued behind its early stop
 };
 
 extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p == nullptr) return NFISAM_OK;
+    if (p->cap) (void)hipStreamSynchronize(p->cap);       // a chunk enqueued ahead of an early stop may still be draining
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->ev) (void)hipEventDestroy(p->ev);
@@ -701,13 +722,14 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     p->dev = dev_cliques;
     p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
     p->chunk = chunk_length(cfg);
-    if (hipHostMalloc((void**)&p->hst, sizeof(nfisam_train_state) * (size_t)n_cliques, hipHostMallocDefault) != hipSuccess) {
-        delete p;
+    if (hipHostMalloc((void**)&p->hst, sizeof(nfisam_train_state) * (size_t)n_cliques,
+                      hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&p->hst_dev, p->hst, 0) != hipSuccess) {
+        nfisam_nsf_train_plan_destroy(p);
         return NFISAM_ERR_LAUNCH;
     }
-    p->contiguous = true;
+    memset(p->hst, 0, sizeof(nfisam_train_state) * (size_t)n_cliques);
     for (int c = 0; c < n_cliques; ++c) {
-        if (host_cliques[c].state != host_cliques[0].state + c) p->contiguous = false;
         if (host_cliques[c].n < 1 || host_cliques[c].D < 1) { nfisam_nsf_train_plan_destroy(p); return NFISAM_ERR_ARG; }
         p->max_n = host_cliques[c].n > p->max_n ? host_cliques[c].n : p->max_n;
         p->max_D = host_cliques[c].D > p->max_D ? host_cliques[c].D : p->max_D;
@@ -729,7 +751,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
                 status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap);
             if (status == NFISAM_OK)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
-                                           p->cap);
+                                           p->cap, p->hst_dev);
             e = hipStreamEndCapture(p->cap, &p->graph);
         }
         if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
@@ -743,17 +765,24 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     return NFISAM_OK;
 }
 
-static hipError_t read_states(nfisam_train_plan* p, hipStream_t work) {
-    hipError_t e = hipSuccess;
-    if (p->contiguous) {
-        e = hipMemcpyAsync(p->hst, p->host[0].state, sizeof(nfisam_train_state) * (size_t)p->n_cliques,
-                           hipMemcpyDeviceToHost, work);
-    } else {
-        for (int c = 0; c < p->n_cliques && e == hipSuccess; ++c)
-            e = hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost, work);
+// Waits until the bookkeeping kernel of chunk number `k` (1-based, this run) has written every clique's mirror.  The
+// device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms, so the host yields between
+// looks and gives up after ~20 s (a wedged GPU must not hang the caller for ever).
+static int wait_chunk(const nfisam_train_plan* p, int k) {
+    const volatile nfisam_train_state* m = p->hst;
+    for (long spins = 0;; ++spins) {
+        bool all = true;
+        for (int c = 0; c < p->n_cliques; ++c)
+            if (m[c].reserved[0] < k) { all = false; break; }
+        if (all) break;
+        if (spins > 2000000000L) return NFISAM_ERR_LAUNCH;
+        if ((spins & 0xffff) == 0xffff) {
+            if (hipStreamQuery(p->exec ? p->cap : nullptr) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
+        }
+        __builtin_ia32_pause();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(work);
-    return e;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return NFISAM_OK;
 }
 
 extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_run, nfisam_stream_t stream) {
@@ -769,38 +798,69 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     // An error return must not leave graph work running on buffers the caller is about to reset or free: every
     // failure path drains the work stream first.
     auto fail = [&](int rc) { (void)hipStreamSynchronize(work); return rc; };
-    int status = NFISAM_OK, done = 0;
-    bool read_back = false;
-    while (done < p->cfg.max_iters) {
-        const int left = p->cfg.max_iters - done;
+    // Nothing of an earlier run writes the mirror any more: its last closed chunk was waited for, and a chunk enqueued
+    // ahead of an early stop only republishes the final state, so restarting the sequence needs that chunk drained.
+    if (p->ahead) { HIP_TRY(hipStreamSynchronize(work)); p->ahead = false; }
+    for (int c = 0; c < p->n_cliques; ++c) p->hst[c].reserved[0] = 0;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    const int total_chunks = (p->cfg.max_iters + p->chunk - 1) / p->chunk;
+    int launched = 0, closed = 0, status = NFISAM_OK;
+    auto launch_chunk = [&]() -> int {
+        const int left = p->cfg.max_iters - launched * p->chunk;
         const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
         if (p->exec && todo == p->chunk) {
             const hipError_t e = hipGraphLaunch(p->exec, work);
-            if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
+            if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
         } else {
             for (int it = 0; it < todo; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
                                       &p->cfg, it, work);
-                if (rc) return fail(rc);
+                if (rc) return rc;
             }
             int rcb = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,
-                                        todo, work);
-            if (rcb) return fail(rcb);
+                                        todo, work, p->hst_dev);
+            if (rcb) return rcb;
         }
-        done += p->chunk;
-        const hipError_t e = read_states(p, work);
-        if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
-        read_back = true;
+        ++launched;
+        return NFISAM_OK;
+    };
+    // Chunk k + 1 is enqueued BEFORE the host looks at the outcome of chunk k: the stop flags are checked on the device
+    // (a chunk behind an early stop is ~chunk empty launches), so the GPU never waits for the host between chunks.
+    // NFISAM_RUN_AHEAD=0 restores launch - wait - launch.
+    static const bool run_ahead = !(getenv("NFISAM_RUN_AHEAD") != nullptr && getenv("NFISAM_RUN_AHEAD")[0] == '0');
+    if (total_chunks > 0) {
+        int rc = launch_chunk();
+        if (rc) return fail(rc);
+    }
+    while (closed < launched) {
+        if (run_ahead && launched < total_chunks) {
+            int rc = launch_chunk();
+            if (rc) return fail(rc);
+        }
+        int rc = wait_chunk(p, closed + 1);
+        if (rc) return fail(rc);
+        ++closed;
         bool all_stopped = true;
         for (int c = 0; c < p->n_cliques; ++c) {
             if (p->hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
             if (!p->hst[c].stop && p->hst[c].step < p->cfg.max_iters) all_stopped = false;
         }
         if (all_stopped) break;        // (a clique with a domain error has stop set: the others run to their own end)
+        if (!run_ahead && launched < total_chunks) {
+            rc = launch_chunk();
+            if (rc) return fail(rc);
+        }
     }
-    if (!read_back) {
-        const hipError_t e = read_states(p, work);
-        if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
+    p->ahead = closed < launched;      // an enqueued chunk behind the stop: empty launches still draining on `work`
+    if (total_chunks == 0) {           // max_iters = 0: report the state as it is
+        HIP_TRY(hipMemcpyAsync(p->hst, p->host[0].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost, work));
+        for (int c = 1; c < p->n_cliques; ++c)
+            HIP_TRY(hipMemcpyAsync(&p->hst[c], p->host[c].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost, work));
+        HIP_TRY(hipStreamSynchronize(work));
+    }
+    if (work != user) {                // the caller's stream continues behind everything enqueued here
+        HIP_TRY(hipEventRecord(p->ev, work));
+        HIP_TRY(hipStreamWaitEvent(user, p->ev, 0));
     }
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;

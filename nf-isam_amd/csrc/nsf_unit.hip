@@ -24,29 +24,6 @@
 #define NSF_PASTE(a, b) NSF_PASTE_(a, b)
 #define NSF_FOR_EACH_KH(X) NSF_PASTE(NSF_KH_, NSF_UNIT)(X)
 
-// =============================================================================================
-// cross-lane reduce-scatter: on return lane l holds the wave total of input v[l & (N-1)].
-// log2(N) exchange steps move N-1 values in total (vs 6 per value for a plain wave reduction).
-// =============================================================================================
-template <int N>
-__device__ __forceinline__ float butterfly(float (&v)[N], int lane) {
-#pragma unroll
-    for (int half = N / 2; half >= 1; half >>= 1) {
-        const bool up = (lane & half) != 0;
-#pragma unroll
-        for (int t = 0; t < half; ++t) {
-            const float lo = v[t], hi = v[t + half];   // load first: keeps v[] in registers (no select-of-address)
-            const float keep = up ? hi : lo;
-            const float send = up ? lo : hi;
-            v[t] = keep + __shfl_xor(send, half, 64);
-        }
-    }
-    float r = v[0];
-#pragma unroll
-    for (int off = N; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
-    return r;
-}
-
 // Gradient sink.  slab = false: accumulate into one shared buffer with float atomics (any number of
 // tiles).  slab = true: this tile owns a private copy of the gradient buffer and every entry is written
 // exactly once per iteration with a plain store; the Adam kernel sums the tiles in a fixed order
@@ -119,7 +96,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ unsigned long long g_stamps[64 * 32];
 __device__ unsigned long long g_blk[4096 * 2];
 __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
-#if NSF_STAMPS == 2      // light: the raw stamp only (no per-phase accumulators: they cost 32 registers and distort the kernel)
+#if NSF_STAMPS == 3      // pinned: per-phase cycle sums in LDS (nsf_train1_kernel only); PSTAMP ties the phase's results to the stamp
+#define STAMP_DECL unsigned long long sprev_ = 0ull;
+#define STAMP(id) do { } while (0)
+#define PSTAMP(id, va, vb)                                                                          \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(va), "+v"(vb)::"memory"); \
+        if (lane == 0 && sprev_ != 0ull) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + ((id) & 15)], (unsigned)(t_ - sprev_)); \
+        sprev_ = t_;                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#elif NSF_STAMPS == 2      // light: the raw stamp only (no per-phase accumulators: they cost 32 registers and distort the kernel)
 #define STAMP_DECL
 #define STAMP(id)                                                                                   \
     do {                                                                                            \
@@ -163,6 +152,9 @@ extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
 #else
 #define STAMP(id) do { } while (0)
 #define STAMP_DECL
+#endif
+#ifndef PSTAMP
+#define PSTAMP(id, va, vb) STAMP(id)
 #endif
 
 // Per-iteration loss sums live behind the gradient slabs in the kgrad workspace: a ring of LOSS_RING
@@ -742,6 +734,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
 
     STAMP_DECL
     STAMP(0);
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+    if (lane < 16) smem[PANEL_BASE - 64 + w * 16 + lane] = 0.0f;
+    { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
+#endif
     f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -818,10 +814,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     for (int tt = 0; tt < T; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
-        STAMP(1);
+        PSTAMP(1, lossv, r0);
         if (tt > 0) load_tile(pt, 0);
         wave_lds_sync();
-        STAMP(2);
+        PSTAMP(2, lossv, r0);
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
         if (i == 0) {
@@ -836,14 +832,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             lds_rows_store<0, H, 0, H>(stg_lane, h2);
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
         }
-        STAMP(3);
+        PSTAMP(3, th[0], th[PoP - 1]);
         SplineT<K> S;
         float z, lad;
         spline_train_fwd<K, PoP>(xt[i * XS + lane], th, B, S, z, lad);
-        STAMP(4);
+        PSTAMP(4, z, lad);
         if (valid) lossv += 0.5f * z * z - lad;
         spline_train_bwd<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
-        STAMP(5);
+        PSTAMP(5, gth[0], gth[LY::HP]);
         if (i == 0) {   // init_param: plain sum over particles of gth
             constexpr int N0 = (PoP <= 32) ? 32 : 64;
             float v[N0];
@@ -856,7 +852,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
         // ---- per-particle back-propagation through the conditioner (4x4x1 MFMA chains, nsf_cond_mfma.h) ----
         float ga2[H], ga1[H];
         cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
-        STAMP(6);
+        PSTAMP(6, ga1[0], ga2[H - 1]);
         // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
         //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
         // The 16 staging rows carry four generations of operands: [h2 | h1], gth tile 0, gth tile 1, [ga2 | ga1].  A
@@ -871,7 +867,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             for (int s4 = 0; s4 < NS; ++s4) breg[s4] = pah[4 * s4];
             wave_lds_sync();
         }
-        STAMP(7);
+        PSTAMP(7, breg[0], breg[NS - 1]);
         {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth ;  phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
             lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
             wave_lds_sync();
@@ -938,7 +934,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             }
             wave_lds_sync();
         }
-        STAMP(8);
+        PSTAMP(8, c1.x, cacc[0].x);
     }
 
     // ---- the gradient of this dim's parameter block ----
@@ -1012,7 +1008,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             gsink4(&Gb[r16 * H + 4 * (kq - QH)], c0, false);
         }
     }
-    STAMP(9);
+    PSTAMP(9, lossv, r0);
     const float tot = wave_sum(lossv);
     if (lane == 0) {
         gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
@@ -1020,6 +1016,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
                                       : (gfloat*)a.loss_sum;
         if (dst != nullptr) gsink(dst, tot, false);
     }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+    if (STAMP_SEL && lane < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane];
+#endif
 }
 
 #undef STAMP_SEL

@@ -1,0 +1,41 @@
+"""Diagnostic (GPU): per-phase cycle SUMS of nsf_train1_kernel waves, phases pinned by data dependences
+(needs `make -C nf-isam_amd/csrc stamps`: libnfisam_hip_stamps3.so).   argv: n_cliques n D [train]
+Waves of tile group 0 of clique 0 are stamped; sums run over the wave's T tiles."""
+import os, sys, ctypes as C
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
+import nfisam_hip as nh
+nh.LIB_PATH = os.path.join(os.path.dirname(nh.LIB_PATH), "libnfisam_hip_stamps3.so")
+import bench as BM
+dev = torch.device("cuda:0")
+nc, n, D = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+K, H, B, L = 9, 8, 5.0, 1
+rng = np.random.RandomState(0)
+xs = [torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev) for _ in range(nc)]
+kps = [nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, c)).to(dev), D, K, H, L) for c in range(nc)]
+lib = nh.lib()
+if len(sys.argv) > 4:
+    tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=8, average_window=4, loss_delta_tol=0.0, early_stop=True)
+    tb.run(use_graph=False)
+else:
+    tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=100000, early_stop=False)
+    for _ in range(3):
+        tb.gradient_only()
+    torch.cuda.synchronize()
+    lib.nfisam_debug_write_stamps((C.c_ulonglong * (64 * 32))())
+    tb.gradient_only()
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (64 * 32))()
+assert lib.nfisam_debug_read_stamps(buf) == 0
+st = np.array(buf[:]).reshape(64, 32)[:, 16:32].astype(np.int64)
+names = ["", "prologue", "load tile", "cond fwd", "spline fwd", "spline bwd", "cond bwd", "h2 operand", "grad GEMMs", "epilogue"]
+rows = [w for w in range(min(64, 4 * D)) if st[w].sum() > 0 and w >= 4]
+print("%d x (n=%d, D=%d): cycles per phase, summed over the wave's tiles (mean over %d stamped waves of dims >= 1)" % (nc, n, D, len(rows)))
+m = st[rows].mean(0)
+for i in range(1, 10):
+    print("  %-12s %8.0f" % (names[i], m[i]))
+print("  %-12s %8.0f" % ("total", m[1:10].sum()))
+for w in (4, 5, 4 * (D // 2), 4 * (D - 1)):
+    if w < 64:
+        print("  slot %2d (dim %2d wave %d): " % (w, w // 4, w % 4) + " ".join("%s=%d" % (names[i], st[w][i]) for i in range(1, 10)))

@@ -13,7 +13,7 @@ So: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on t
 rule, every rank trains its own cliques with NO collective on the data path, and only a tree edge
 whose two ends live on different ranks costs one point-to-point message: the child's separator
 sample batch [n, Ds] fp32 (<= 2000 x 11 x 4 B = 88 KB, latency-bound on a 153 GB/s xGMI link —
-never an all-reduce).  Chain-shaped trees (the `pose_first` ordering of every shipped large
+never an all-reduce).  Messages are matched by ORDER, not by tag (RCCL has none): `EdgeExchange`.  Chain-shaped trees (the `pose_first` ordering of every shipped large
 example) have no sibling subtrees: they run on one rank ("replicas only").
 
 Nothing here touches the kernels; it is scheduling + message routing around
@@ -117,46 +117,132 @@ def shard_independent(n_items: int, world_size: int, rank: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def send_separator_samples(samples: torch.Tensor, dst: int, tag: int = 0):
-    """Child -> parent message: [n, Ds] float32 (device tensor with nccl/RCCL, CPU tensor with gloo)."""
-    hdr = torch.tensor(list(samples.shape), dtype=torch.int64, device=samples.device)
-    dist.send(hdr, dst=dst, tag=tag)
-    dist.send(samples.contiguous(), dst=dst, tag=tag)
+class EdgeExchange:
+    """Point-to-point exchange of fixed-shape fp32 batches along the cross-rank edges of ONE pass over the tree, correct
+    WITHOUT message tags.
+
+    RCCL / NCCL has no tags: between two ranks, point-to-point operations are matched strictly in the order they were
+    issued, and the sends and receives a rank addresses to one peer share a stream, so they also EXECUTE in that order.
+    Matching by tag (gloo) hides both facts.  Here every rank is given the same list of edges in the same GLOBAL order
+    (the order in which the pass visits the producing cliques), and for every peer it issues its operations -- sends and
+    receives alike -- in exactly that order:
+
+      * `send(key, batch)`   first posts the (not yet posted) receives that precede this edge in the pair's sequence,
+                             then the send;
+      * `recv(key)`          posts every operation of the pair up to this edge (they can only be receives: a send that
+                             precedes it belongs to a clique this rank has already finished) and waits for this one.
+
+    So the k-th operation of rank A towards B is always the counterpart of the k-th operation of B towards A, whatever
+    the order in which the batches are consumed, with several edges between one pair and with edges in both directions.
+    Both ends know the shape of a batch ([n, Ds]: sample count x separator dims), so there is no header message.
+    Tensors stay on the device with the "nccl" backend (RCCL moves device memory); gloo gets host tensors."""
+
+    def __init__(self, edges, rank: int, device="cpu", on_device: bool = False):
+        """edges: list of (key, src_rank, dst_rank, shape) with src_rank != dst_rank, identical on every rank."""
+        self.rank, self.device, self.on_device = rank, device, on_device
+        self.edges = {}
+        self.seq: Dict[int, List] = {}           # peer -> keys of the edges between this rank and the peer, global order
+        self.pos: Dict[Hashable, int] = {}
+        for key, src, dst, shape in edges:
+            if src == dst:
+                raise ValueError("edge %r does not cross ranks" % (key,))
+            if key in self.edges:
+                raise ValueError("duplicate edge key %r" % (key,))
+            self.edges[key] = (src, dst, tuple(int(v) for v in shape))
+            if rank in (src, dst):
+                peer = dst if src == rank else src
+                self.pos[key] = len(self.seq.setdefault(peer, []))
+                self.seq[peer].append(key)
+        self.cursor = {peer: 0 for peer in self.seq}
+        self._recv: Dict[Hashable, tuple] = {}    # key -> (request, buffer)
+        self._sends: List[tuple] = []             # (request, buffer): kept alive until drain()
+        self.log: List[tuple] = []                # ("send" | "recv", peer, key) in issue order (tests)
+
+    def _buffer_device(self):
+        return self.device if self.on_device else "cpu"
+
+    def _post_until(self, peer: int, upto: int):
+        """Issue this rank's operations towards `peer` with sequence position < upto; they must all be receives."""
+        while self.cursor[peer] < upto:
+            key = self.seq[peer][self.cursor[peer]]
+            src, dst, shape = self.edges[key]
+            if dst != self.rank:
+                raise RuntimeError("edge %r: its send has to be issued before a later operation of the same rank pair "
+                                   "(the pass must visit producers in the global edge order)" % (key,))
+            buf = torch.empty(shape, dtype=torch.float32, device=self._buffer_device())
+            self._recv[key] = (dist.irecv(buf, src=src), buf)
+            self.log.append(("recv", src, key))
+            self.cursor[peer] += 1
+
+    def send(self, key, batch: torch.Tensor):
+        src, dst, shape = self.edges[key]
+        if src != self.rank:
+            raise ValueError("edge %r is not sent by rank %d" % (key, self.rank))
+        t = batch.to(torch.float32).contiguous()
+        if tuple(t.shape) != shape:
+            raise ValueError("edge %r carries %s, announced %s" % (key, tuple(t.shape), shape))
+        t = t.to(self._buffer_device())
+        self._post_until(dst, self.pos[key])
+        if self.cursor[dst] != self.pos[key]:
+            raise RuntimeError("edge %r sent twice or out of order" % (key,))
+        self._sends.append((dist.isend(t, dst=dst), t))
+        self.log.append(("send", dst, key))
+        self.cursor[dst] += 1
+
+    def recv(self, key) -> torch.Tensor:
+        src, dst, _ = self.edges[key]
+        if dst != self.rank:
+            raise ValueError("edge %r is not received by rank %d" % (key, self.rank))
+        self._post_until(src, self.pos[key] + 1)
+        req, buf = self._recv[key]
+        if req is not None:
+            req.wait()
+            self._recv[key] = (None, buf)
+        return buf
+
+    def drain(self):
+        """End of the pass: post what was never asked for, wait for every outstanding operation (the buffers of the
+        sends are kept until here)."""
+        for peer in self.seq:
+            self._post_until(peer, len(self.seq[peer]))
+        for key, (req, buf) in list(self._recv.items()):
+            if req is not None:
+                req.wait()
+                self._recv[key] = (None, buf)
+        for req, _ in self._sends:
+            req.wait()
+        self._sends = []
 
 
-def recv_separator_samples(src: int, device, tag: int = 0) -> torch.Tensor:
-    hdr = torch.empty(2, dtype=torch.int64, device=device)
-    dist.recv(hdr, src=src, tag=tag)
-    out = torch.empty(int(hdr[0]), int(hdr[1]), dtype=torch.float32, device=device)
-    dist.recv(out, src=src, tag=tag)
-    return out
+def tree_edges(tree: CliqueTree, assignment: Dict[Hashable, int], order: Sequence, shape_of: Callable) -> List[tuple]:
+    """Cross-rank child -> parent edges of a leaves-first pass, in the order the children are visited."""
+    return [(c, assignment[c], assignment[tree.parent[c]], shape_of(c)) for c in order
+            if tree.parent[c] is not None and assignment[tree.parent[c]] != assignment[c]]
 
 
 def run_tree(tree: CliqueTree, fit: Callable[[Hashable, List[torch.Tensor]], torch.Tensor], rank: int,
-             world_size: int, device="cpu") -> Dict[Hashable, torch.Tensor]:
+             world_size: int, device="cpu", message_shape=None, assignment: Dict[Hashable, int] = None,
+             exchange_log: List = None) -> Dict[Hashable, torch.Tensor]:
     """Execute `fit(clique, child_messages) -> message_to_parent` for every clique owned by this rank,
-    leaves first, routing messages over rank boundaries point-to-point.  Per clique the reference's
-    order is kept: children's separator samples -> fit -> separator factor for the parent
-    (FactorGraphSolver.py:436-470).  Returns {clique: message} for the cliques this rank ran.
-
-    Deadlock-free by construction: all ranks walk the same global leaves-first order, a send is posted
-    right after its clique finished and the matching recv is posted by the parent's rank when it
-    reaches the parent, which is later in the same order on every rank."""
-    assignment = assign_subtrees(tree, world_size)
+    leaves first, routing messages over rank boundaries point-to-point (`EdgeExchange`: no tags, no headers).
+    Per clique the reference's order is kept: children's separator samples -> fit -> separator factor for the
+    parent (FactorGraphSolver.py:436-470).  `message_shape(clique)` = shape of the clique's message (known to both
+    ends; default (5, 3), the stand-in of the tests).  Returns {clique: message} for the cliques this rank ran."""
+    assignment = assign_subtrees(tree, world_size) if assignment is None else assignment
     order = tree.leaves_first()
-    index = {c: j for j, c in enumerate(order)}
+    shape_of = message_shape if message_shape is not None else (lambda c: (5, 3))
+    ex = EdgeExchange(tree_edges(tree, assignment, order, shape_of), rank, device=device,
+                      on_device=(dist.get_backend() == "nccl"))
     produced: Dict[Hashable, torch.Tensor] = {}
     for c in order:
-        owner = assignment[c]
-        if owner == rank:
-            msgs = []
-            for k in tree.children[c]:
-                if assignment[k] == rank:
-                    msgs.append(produced[k])
-                else:
-                    msgs.append(recv_separator_samples(assignment[k], device, tag=index[k]))
-            produced[c] = fit(c, msgs)
+        if assignment[c] != rank:
+            continue
+        msgs = [produced[k] if assignment[k] == rank else ex.recv(k).to(device) for k in tree.children[c]]
+        produced[c] = fit(c, msgs)
         p = tree.parent[c]
-        if owner == rank and p is not None and assignment[p] != rank:
-            send_separator_samples(produced[c], assignment[p], tag=index[c])
+        if p is not None and assignment[p] != rank:
+            ex.send(c, produced[c])
+    ex.drain()
+    if exchange_log is not None:
+        exchange_log.extend(ex.log)
     return produced

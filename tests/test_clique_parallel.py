@@ -82,24 +82,56 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    tree = bushy_tree()
+def two_remote_children_tree():
+    # p (rank 0) has two children trained on rank 1; consumed in the order (c2, c1), produced in the order (c1, c2)
+    parent = {"p": None, "c1": "p", "c2": "p", "g1": "c1"}
+    assign = {"p": 0, "c1": 1, "c2": 1, "g1": 1}
+    return CliqueTree(parent), assign
+
+
+def both_directions_tree():
+    #        r(0)
+    #      /      \
+    #    a(1)      b(0)
+    #    |          |
+    #    a1(0)     b1(1)        edges: a1 0->1, b1 1->0, a 1->0  -- both directions between the two ranks, interleaved
+    #    |
+    #    a2(1)                  a2 1->0
+    parent = {"r": None, "a": "r", "b": "r", "a1": "a", "b1": "b", "a2": "a1"}
+    assign = {"r": 0, "a": 1, "b": 0, "a1": 0, "b1": 1, "a2": 1}
+    return CliqueTree(parent), assign
+
+
+TREES = {"bushy": lambda: (bushy_tree(), None), "two_remote_children": two_remote_children_tree,
+         "both_directions": both_directions_tree}
+
+
+def _fit_factory(tree, reverse_consumption=False):
     names = sorted(tree.parent, key=str)
     code = {c: float(i + 1) for i, c in enumerate(names)}
+
+    def shape_of(c):
+        return (4 + names.index(c), 3)              # every edge its own shape: a swapped batch cannot go unnoticed
 
     def fit(c, msgs):
         # stand-in for "sample the training batch from the children's flows, train, emit separator
         # samples": a deterministic function of the clique and everything below it
-        base = torch.full((5, 3), code[c])
-        for m in msgs:
-            base = base + 0.5 * m
+        base = torch.full(shape_of(c), code[c])
+        for j, m in enumerate(msgs):
+            base = base + 0.5 * (j + 1) * m.sum() / m.numel()
         return base
+    return fit, shape_of, code
 
-    produced = run_tree(tree, fit, rank, world, device="cpu")
-    torch.save({k: v for k, v in produced.items()}, os.path.join(out_dir, "rank%d.pt" % rank))
+
+def _worker(rank, world, port, out_dir, which="bushy"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tree, assign = TREES[which]()
+    fit, shape_of, _ = _fit_factory(tree)
+    log = []
+    produced = run_tree(tree, fit, rank, world, device="cpu", message_shape=shape_of, assignment=assign, exchange_log=log)
+    torch.save({"produced": {k: v for k, v in produced.items()}, "log": log}, os.path.join(out_dir, "rank%d.pt" % rank))
     # weak-scaling shards + the max-over-ranks timing reduction bench.py performs
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -108,29 +140,50 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_process_tree_run_matches_single_process(tmp_path):
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("which", ["bushy", "two_remote_children", "both_directions"])
+def test_two_process_tree_run_matches_single_process(tmp_path, which):
+    """No message carries a tag (RCCL has none): the k-th operation of rank 0 towards rank 1 must be the counterpart of
+    the k-th operation of rank 1 towards rank 0.  Trees: sibling subtrees on two ranks; one parent with two remote
+    children on the SAME rank; edges crossing in BOTH directions between the two ranks, interleaved."""
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    merged = {}
+    mp.spawn(_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True)
+    merged, logs = {}, []
     for r in range(world):
         part = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
-        assert not (set(part) & set(merged))          # every clique ran on exactly one rank
-        merged.update(part)
-    tree = bushy_tree()
+        assert not (set(part["produced"]) & set(merged))          # every clique ran on exactly one rank
+        merged.update(part["produced"])
+        logs.append(part["log"])
+    tree, assign = TREES[which]()
     assert set(merged) == set(tree.parent)
-    assignment = assign_subtrees(tree, world)
-    # single-process reference of the same recursion
-    names = sorted(tree.parent, key=str)
-    code = {c: float(i + 1) for i, c in enumerate(names)}
+    assignment = assign_subtrees(tree, world) if assign is None else assign
+    fit, shape_of, _ = _fit_factory(tree)
 
-    def ref(c):
-        v = torch.full((5, 3), code[c])
-        for k in tree.children[c]:
-            v = v + 0.5 * ref(k)
-        return v
+    def ref(c):           # single-process reference of the same recursion
+        return fit(c, [ref(k) for k in tree.children[c]])
     for c in tree.parent:
         assert torch.equal(merged[c], ref(c)), c
-    # at least one message crossed ranks (root's children live on different ranks)
-    assert assignment["a"] != assignment["b"]
+    # the two ranks' operation sequences towards each other are mirror images, edge by edge
+    assert len(logs[0]) == len(logs[1]) > 0
+    for (k0, p0, e0), (k1, p1, e1) in zip(logs[0], logs[1]):
+        assert e0 == e1 and {k0, k1} == {"send", "recv"} and p0 == 1 and p1 == 0, (logs[0], logs[1])
+    crossing = [c for c in tree.parent if tree.parent[c] is not None and assignment[c] != assignment[tree.parent[c]]]
+    assert sorted(e for _, _, e in logs[0]) == sorted(crossing)
+    if which == "both_directions":
+        assert {k for k, _, _ in logs[0]} == {"send", "recv"}
+    if which == "two_remote_children":
+        assert [k for k, _, _ in logs[0]] == ["recv", "recv"]
+
+
+def test_edge_exchange_rejects_inconsistent_use():
+    from slam.CliqueParallel import EdgeExchange
+    with pytest.raises(ValueError):
+        EdgeExchange([("e", 0, 0, (2, 2))], rank=0)
+    with pytest.raises(ValueError):
+        EdgeExchange([("e", 0, 1, (2, 2)), ("e", 1, 0, (2, 2))], rank=0)
+    ex = EdgeExchange([("e", 0, 1, (2, 2))], rank=0)
+    with pytest.raises(ValueError):
+        ex.send("e", torch.zeros(3, 2))            # not the announced shape
+    with pytest.raises(ValueError):
+        ex.recv("e")                               # rank 0 is the sender of this edge

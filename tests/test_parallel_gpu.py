@@ -136,3 +136,22 @@ def test_two_rank_solver_matches_single_process(tmp_path, posterior):
         m = _mmd(a / scale, b / scale, np.sqrt(2.0))
         assert m < 0.16, (v, m)          # two separately trained posteriors: 0.05-0.13 seen across kernel revisions; a wrong separator message gives > 0.5
         assert np.linalg.norm(a.mean(0) - b.mean(0)) < 0.5 + 0.25 * scale, (v, a.mean(0), b.mean(0))
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_prints_the_contract_line():
+    """`python bench.py --gpus 2` (no launcher: bench.py starts the ranks itself before touching the GPU).  The box has
+    one GPU, so the ranks share it over gloo (`BENCH_DIST_BACKEND=gloo`); on an 8-GPU node the same path runs over RCCL.
+    The LAST stdout line is the driver's JSON line: whole-job value = 2 x per-rank value, n_gpus = 2, weak scaling."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=550)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.strip()]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["metric"].startswith("flow-training samples/sec") and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * d["per_gpu_value"]) < 1e-6 * d["value"]
+    assert d["value"] > 1e7 and 0 < d["ms_per_step"] < 5.0
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None

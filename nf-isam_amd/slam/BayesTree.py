@@ -193,6 +193,7 @@ class BayesTree(object):
         (as in the reference), or -- `detach=True`, for a caller that discards this tree afterwards -- the very
         same nodes cut off from their parent (no O(tree) copy per update).
         -> (frontal variables of affected cliques, detached sub trees)."""
+        self.detached_edges = []
         frontal_of = {}
         for c in self.clique_ordering():
             for v in c.frontal:
@@ -210,6 +211,7 @@ class BayesTree(object):
             for child in list(c.children):
                 if not any(child is a for a in affected):
                     if detach:
+                        self.detached_edges.append((c, child, [x for x in c.children]))   # enough to undo the cut (reattach)
                         c.children = [x for x in c.children if x is not child]
                         child.parent = None
                         sub_trees.append(BayesTree(root_clique=child))
@@ -217,6 +219,14 @@ class BayesTree(object):
                         sub_trees.append(BayesTree(root_clique=_deep_copy_subtree(child)))
         affected_vars = set().union(*[c.frontal for c in affected]) if affected else set()
         return affected_vars, sub_trees
+
+    def reattach_detached(self) -> None:
+        """Undo the cuts of the last `get_affected_vars_and_partial_bayes_trees(detach=True)`: the caller's update failed
+        after the unaffected subtrees were moved out, and the tree has to be whole again for a retry."""
+        for parent, child, children_before in reversed(getattr(self, "detached_edges", [])):
+            parent.children = children_before
+            child.parent = parent
+        self.detached_edges = []
 
     def clique_variable_pattern(self, clique: BayesTreeNode) -> List[Variable]:
         """[separator variables, frontal variables], each in reverse elimination order."""

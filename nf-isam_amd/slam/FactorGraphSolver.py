@@ -161,41 +161,58 @@ class FactorGraphSolver:
     def update_physical_and_working_graphs(self, timer: List[float] = None, device: str = "cpu") -> "FactorGraphSolver":
         """Fold the staged nodes / factors into the graphs and re-eliminate only the part of the Bayes tree they touch
         (what the reference does in :256-358).  Three stages:
-          1. check the staged input and fix the new elimination ordering -- nothing has been modified yet, so a bad
-             factor or an unsupported ordering method leaves the solver exactly as it was;
+          1. check the staged input and compute the new elimination ordering;
           2. cut the unaffected subtrees out of the physical tree (they are moved, not copied), build the working graph
              (affected variables + the separator factors of the cut subtrees + the staged input) and its Bayes tree,
              and hang the cut subtrees under the new tree;
-          3. carry trained models over to cliques that reappear with the same variables in the same relative order."""
+          3. carry trained models over to cliques that reappear with the same variables in the same relative order.
+        Stages 1 and 2 are a transaction: the new ordering, the graphs and the trees are committed together once the
+        working tree exists; a failure before that restores the ordering, re-attaches the cut subtrees and leaves the
+        staged input pending, so a retry sees the solver exactly as it was."""
         start = time.time()
         staged_nodes, staged_factors = list(self._new_nodes), list(self._new_factors)
-        # -- 1. validation + ordering (no state is touched before this succeeds)
+        # -- 1. validation + ordering
         known = set(self.physical_vars) | set(staged_nodes)
         for f in staged_factors:
             missing = [str(v.name) for v in f.vars if v not in known]
             if missing:
                 raise KeyError("factor %s refers to variables that are neither in the graph nor staged: %s"
                                % (f, " ".join(missing)))
-        previous_ordering = self._elimination_ordering
-        self.generate_ordering()                      # raises NotImplementedError for an unknown method
-        # -- 2. working graph and trees
-        kept_subtrees = []
-        if self._physical_bayes_tree is not None:
-            touched_old = {v for f in staged_factors for v in f.vars} & set(self.physical_vars)
-            affected, kept_subtrees = self._physical_bayes_tree.get_affected_vars_and_partial_bayes_trees(
-                vars=touched_old, detach=True)
-            self._working_graph = self._physical_graph.get_sub_factor_graph_with_prior(
-                variables=affected, sub_trees=kept_subtrees, clique_prior_dict=self._implicit_factors)
-        for graph in (self._working_graph, self._physical_graph):
+        previous_ordering, previous_rmap = self._elimination_ordering, self._reverse_ordering_map
+        old_tree = self._physical_bayes_tree
+        try:
+            self.generate_ordering()                  # raises NotImplementedError for an unknown method
+            # -- 2. working graph and trees, built next to the live state
+            kept_subtrees = []
+            if old_tree is not None:
+                touched_old = {v for f in staged_factors for v in f.vars} & set(self.physical_vars)
+                affected, kept_subtrees = old_tree.get_affected_vars_and_partial_bayes_trees(vars=touched_old, detach=True)
+                working = self._physical_graph.get_sub_factor_graph_with_prior(
+                    variables=affected, sub_trees=kept_subtrees, clique_prior_dict=self._implicit_factors)
+            else:
+                working = FactorGraph()
+                for v in self._working_graph.vars:
+                    working.add_node(v)
+                for f in self._working_graph.factors:
+                    working.add_factor(f)
             for node in staged_nodes:
-                graph.add_node(node)
+                working.add_node(node)
             for factor in staged_factors:
-                graph.add_factor(factor)
-        in_working = set(self.working_vars)
-        self._working_bayes_tree = self._working_graph.get_bayes_tree(
-            ordering=[v for v in self._elimination_ordering if v in in_working])
-        self._physical_bayes_tree = self._working_bayes_tree.__copy__()
-        self._physical_bayes_tree.append_child_bayes_trees(kept_subtrees)
+                working.add_factor(factor)
+            in_working = set(working.vars)
+            working_tree = working.get_bayes_tree(ordering=[v for v in self._elimination_ordering if v in in_working])
+            physical_tree = working_tree.__copy__()
+            physical_tree.append_child_bayes_trees(kept_subtrees)
+            for node in staged_nodes:                 # (cannot fail: the working graph took the same input above)
+                self._physical_graph.add_node(node)
+            for factor in staged_factors:
+                self._physical_graph.add_factor(factor)
+        except BaseException:
+            self._elimination_ordering, self._reverse_ordering_map = previous_ordering, previous_rmap
+            if old_tree is not None:
+                old_tree.reattach_detached()
+            raise
+        self._working_graph, self._working_bayes_tree, self._physical_bayes_tree = working, working_tree, physical_tree
         # -- 3. trained models of cliques that dropped out of the tree
         self._recycle_models(previous_ordering, device)
         self._new_nodes, self._new_factors = [], []

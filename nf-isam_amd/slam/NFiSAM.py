@@ -287,6 +287,8 @@ class FlowsPriorFactor(CliqueSeparatorFactor):
 
 
 class NFiSAM(FactorGraphSolver):
+    TRAIN_PLAN_CACHE = 6      # training plans kept (least recently used first out)
+
     def __init__(self, args: NFiSAMArgs = None):
         super().__init__(args=args if args is not None else NFiSAMArgs())
         a = self._args
@@ -385,9 +387,18 @@ class NFiSAM(FactorGraphSolver):
         device = preps[0]["device"]
         key = (tuple((p["n"], p["D"]) for p in preps), K, H, L, float(a.learning_rate), int(a.flow_iterations),
                int(a.average_window), float(a.loss_delta_tol), str(device))
-        plans = self.__dict__.setdefault("_train_plans", {})
+        # Plans (hipGraphExec + pinned state mirror + device buffers incl. the multi-copy gradient workspace) are kept for
+        # the batch shapes used most recently: replicas dropping out of a lock-step batch and cliques of varying width make
+        # almost every composition a new key, so the cache is a small LRU and evicted plans are closed.
+        import collections
+        plans = self.__dict__.setdefault("_train_plans", collections.OrderedDict())
         tb = plans.get(key)
+        if tb is not None:
+            plans.move_to_end(key)
         if tb is None:
+            while len(plans) >= self.TRAIN_PLAN_CACHE:
+                _, old = plans.popitem(last=False)
+                old.close()
             tb = _nh.TrainBatch([torch.empty(p["n"], p["D"], dtype=torch.float32, device=device) for p in preps],
                                 [torch.zeros_like(p["kp0"]) for p in preps], K, H, B, L, lr=a.learning_rate,
                                 max_iters=a.flow_iterations, average_window=a.average_window,
@@ -412,7 +423,15 @@ class NFiSAM(FactorGraphSolver):
                 for c in failed:
                     logger.warning("non-finite loss while fitting clique %d of the batch: retrying once with fresh parameters", c)
                     p = preps[c]
-                    p["kp0"] = torch.cat([_nh.pack(init_reference_blob(p["D"], K, H, device), p["D"], K, H, 1) for _ in range(L)])
+                    # The fresh draw comes from a generator of its own, seeded by the failed initialisation: it consumes
+                    # nobody's random stream (replicas run this outside their RNG turn and must stay bit-identical to
+                    # the sequential run) and is reproducible.  `retried` tells callers and tests that this fit deviates
+                    # from the reference, which aborts the update here.
+                    gen = torch.Generator(device=device)
+                    gen.manual_seed(int(p["kp0"].double().abs().sum().item() * 1e6) % (2 ** 31 - 1) + 1)
+                    p["kp0"] = torch.cat([_nh.pack(init_reference_blob(p["D"], K, H, device, generator=gen), p["D"], K, H, 1)
+                                          for _ in range(L)])
+                    p["retried"] = True
                     self.train_prepared([p], retry=False)
                 done = set(failed)
                 for c, p in enumerate(preps):
@@ -441,6 +460,7 @@ class NFiSAM(FactorGraphSolver):
         clique_name = ''.join([str(var.name) for var in prep["clique"].vars])
         self._temp_training_loss[clique_name] = [float(v) for v in prep["iter_loss"].cpu().numpy().astype(np.float64)]
         self.last_fit_iterations = prep["iters"]
+        self.last_fit_retried = bool(prep.get("retried", False))
         return model
 
     def _fit_holdout(self, prep: dict, timer) -> NormalizingFlowModelWithSeparator:

@@ -26,6 +26,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(glob.glob(os.path.join(GOLDEN, "nsf_*.npz")))
 DEV = "cuda:0"
 Z_ATOL, LD_ATOL = 1e-4, 2e-4
+NOISE_GRAD = 2e-5        # |reference gradient| below the kernels' absolute gradient tolerance: sign of an Adam step undetermined
 
 
 def load(path):
@@ -102,14 +103,23 @@ class TestAgainstReferenceGolden:
         assert tb.state()["step"] == 10 and tb.state()["stop"] == 0
         np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy(), g["adam_losses"], atol=5e-4, rtol=1e-4)
         lr = float(g["adam_lr"])
+        # Adam divides every coordinate's step by sqrt(v): a coordinate whose gradient is at fp32-noise level (an empty
+        # spline bin -- K = 15 bins on 64 particles) moves by +-lr per step in EITHER implementation, so such coordinates
+        # may differ by O(steps x lr).  They are identified from the REFERENCE's own gradient at the start (|g0| below
+        # the kernels' absolute gradient tolerance, where the sign of g / sqrt(v) is not determined); every other
+        # coordinate is held to the strict tolerance, and nothing may be off by more than the steps taken.
+        g0 = np.abs(O.blob_from_state_dict(sd_of(g, "g0"), D))
+        noisy = g0 < NOISE_GRAD
+        assert noisy.mean() < 0.25, noisy.mean()
         for steps, atol in ((1, 2e-4), (2, 4e-4), (10, 2e-3)):
             ref = O.blob_from_state_dict(sd_of(g, "p%d" % steps), D)
-            # Adam divides every coordinate's step by sqrt(v): a coordinate whose gradient is at fp32-noise level (an
-            # empty spline bin -- K = 15 bins on 64 particles) moves by +-lr per step in either implementation, so a few
-            # coordinates may differ by O(steps x lr); everything else must agree to `atol`
             err = np.abs(snaps[steps] - ref)
-            bad = err > atol + 1e-3 * np.abs(ref)
-            assert bad.mean() < 0.02 and err.max() < steps * lr + 1e-4, (steps, bad.mean(), err.max())
+            excess = err - 1e-3 * np.abs(ref)
+            bad = excess > atol
+            assert not np.any(bad & ~noisy), (steps, int((bad & ~noisy).sum()), float(excess[~noisy].max()),
+                                               float(g0[bad & ~noisy].min()))
+            assert np.quantile(excess, 0.98) <= atol, (steps, float(np.quantile(excess, 0.98)))
+            assert err.max() < steps * lr + 1e-4, (steps, err.max())
         tb.step()   # beyond max_iters: must be a no-op
         torch.cuda.synchronize()
         assert tb.state()["step"] == 10

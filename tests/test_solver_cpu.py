@@ -257,6 +257,50 @@ def test_failed_update_leaves_the_solver_untouched(small_graph):
     assert set(res) == set(s.physical_vars) and len(s.physical_vars) == 2 + 4
 
 
+def test_late_failure_of_an_update_restores_ordering_and_tree(small_graph, monkeypatch):
+    """a failure AFTER the ordering was recomputed and the unaffected subtrees were cut (here: building the
+    working graph's Bayes tree) must put back the previous ordering and re-attach the subtrees, so that a retry computes
+    `previous_ordering` and the recycled models from the right state."""
+    from slam.FactorGraph import FactorGraph
+    (nodes, truth, factors), _ = small_graph
+    np.random.seed(0)
+    s = _StubSolver(SolverArgs(elimination_method="pose_first", local_sample_num=64, posterior_sample_num=16))
+    steps = group_nodes_factors_incrementally(nodes, factors, 1)
+    for vs, fs in steps[:4]:
+        for v in vs:
+            s.add_node(v)
+        for f in fs:
+            s.add_factor(f)
+        s.update_physical_and_working_graphs()
+        s.incremental_inference()
+    before_tree = str(s.physical_bayes_tree)
+    before_order = [v.name for v in s.elimination_ordering]
+    before_rmap = dict(s._reverse_ordering_map)
+    parents = {id(c): (id(c.parent) if c.parent is not None else None) for c in s.physical_bayes_tree.clique_ordering()}
+    n_factors = len(s.physical_factors)
+    vs, fs = steps[4]
+    for v in vs:
+        s.add_node(v)
+    for f in fs:
+        s.add_factor(f)
+    real = FactorGraph.get_bayes_tree
+
+    def boom(self, *a, **k):
+        raise RuntimeError("injected: elimination failed")
+    monkeypatch.setattr(FactorGraph, "get_bayes_tree", boom)
+    with pytest.raises(RuntimeError):
+        s.update_physical_and_working_graphs()
+    monkeypatch.setattr(FactorGraph, "get_bayes_tree", real)
+    assert [v.name for v in s.elimination_ordering] == before_order and s._reverse_ordering_map == before_rmap
+    assert str(s.physical_bayes_tree) == before_tree
+    assert {id(c): (id(c.parent) if c.parent is not None else None) for c in s.physical_bayes_tree.clique_ordering()} == parents
+    assert len(s.physical_factors) == n_factors and len(s.new_factors) == len(fs) and len(s.new_vars) == len(vs)
+    s.update_physical_and_working_graphs()            # the retry works on the restored state
+    res = s.incremental_inference()
+    assert set(res) == set(s.physical_vars)
+    assert [e[1] for e in s.log if e[0] == "reuse"] == [["X0"], ["X1"], ["X2"]]      # as in the undisturbed run
+
+
 def test_mmd_metric():
     rng = np.random.RandomState(0)
     a, b = rng.randn(500, 2), rng.randn(500, 2)

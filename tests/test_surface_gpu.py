@@ -421,6 +421,111 @@ def test_fused_simulator_mixture_ops_match_reference_statistics():
     assert phi.min() < -3.0 and phi.max() > 3.0 and abs(np.cos(phi).mean()) < 0.08
 
 
+def _sim_op(nh, code, a=0, b=0, c=0, k=0, p=(), srcp=0):
+    o = nh.SimOp()
+    o.code, o.a, o.b, o.c, o.k, o.src = code, a, b, c, k, srcp
+    for i, v in enumerate(p):
+        o.p[i] = float(v)
+    return o
+
+
+def test_fused_simulator_r2_ops_match_reference_bodies():
+    """Ops 11-15 of `nfisam_simulate_clique` (the R2 family of the toy range-only examples) driven directly with the inputs
+    of the REFERENCE's factor `sample` bodies (tests/golden/se2_factors.npz: src/factors/Factors.py:998-1030 displacement
+    factor in its three directions, :2080-2135 R2-R2 range, :362,451 point / ring priors).  The reference vectors carry the
+    injected noise draws `r2_noise2` / `f_noise1`: with the ops' noise scale at zero the device must return exactly the
+    reference's output minus that draw; the priors are checked by their moments."""
+    import nfisam_hip as nh
+    g = dict(np.load(os.path.join(GOLDEN, "se2_factors.npz")))
+    p1, p2, nz, nz1 = g["r2_p1"], g["r2_p2"], g["r2_noise2"], g["f_noise1"][:, 0]
+    n = p1.shape[0]
+    src = torch.from_numpy(np.hstack([p1, p2]).astype(np.float32)).to(DEV).contiguous()
+    obs = [5.0, -5.0]
+    # columns: 0..1 p1 | 2..3 p2 | 4..5 fwd(p1) | 6..7 bwd(p2) | 8..9 measurement | 10..11 ring around p1 | 12 range p1-p2
+    ops = [_sim_op(nh, nh.SIM_COPY, a=4, b=0, c=0, k=4, srcp=src.data_ptr()),
+           _sim_op(nh, nh.SIM_REL_R2_FWD, a=0, c=4, p=obs + [0, 0, 0]),
+           _sim_op(nh, nh.SIM_REL_R2_BWD, a=2, c=6, p=obs + [0, 0, 0]),
+           _sim_op(nh, nh.SIM_REL_R2_OBS, a=0, b=2, c=8, p=[0, 0, 0, 0, 0]),
+           _sim_op(nh, nh.SIM_RING, a=0, c=10, p=[12.0, 0.0]),
+           _sim_op(nh, nh.SIM_RANGE_OBS, a=0, b=2, c=12, p=[0.0])]
+    out = nh.simulate_clique(ops, n, 13, 13, 99, DEV).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(out[:, 4:6], g["r2rel_fwd"] - nz, atol=2e-5)        # var2 = var1 + obs (+ noise)
+    np.testing.assert_allclose(out[:, 6:8], g["r2rel_bwd"] + nz, atol=2e-5)        # var1 = var2 - obs (- noise)
+    np.testing.assert_allclose(out[:, 8:10], g["r2rel_meas"] - nz, atol=2e-5)      # measurement = var2 - var1 (+ noise)
+    np.testing.assert_allclose(np.linalg.norm(out[:, 10:12] - p1, axis=1), np.linalg.norm(g["r2ring"] - p1, axis=1) - nz1, atol=3e-5)
+    np.testing.assert_allclose(out[:, 12], g["r2range_meas"][:, 0] - nz1, atol=3e-5)
+    # noise of the displacement ops: mu + L z with the lower Cholesky factor as (l00, l10, l11)
+    N = 40000
+    cov = np.array([[0.5, 0.2], [0.2, 0.3]])
+    L = np.linalg.cholesky(cov)
+    lp = [L[0, 0], L[1, 0], L[1, 1]]
+    big = torch.from_numpy(np.tile(np.array([[1.0, -2.0, 4.0, 0.5]], dtype=np.float32), (N, 1))).to(DEV).contiguous()
+    ops = [_sim_op(nh, nh.SIM_COPY, a=4, b=0, c=0, k=4, srcp=big.data_ptr()),
+           _sim_op(nh, nh.SIM_REL_R2_FWD, a=0, c=4, p=obs + lp), _sim_op(nh, nh.SIM_REL_R2_BWD, a=2, c=6, p=obs + lp),
+           _sim_op(nh, nh.SIM_REL_R2_OBS, a=0, b=2, c=8, p=[0, 0] + lp),
+           _sim_op(nh, nh.SIM_PRIOR_R2, c=10, p=[5.0, -3.0] + lp),
+           _sim_op(nh, nh.SIM_PRIOR_R2_RING, c=12, p=[1.0, 2.0, 7.0, 0.5])]
+    out = nh.simulate_clique(ops, N, 14, 14, 4242, DEV).cpu().numpy().astype(np.float64)
+    se = 5.0 / np.sqrt(N)
+    for cols, mean in ((slice(4, 6), np.array([6.0, -7.0])), (slice(6, 8), np.array([-1.0, 5.5])),
+                       (slice(8, 10), np.array([3.0, 2.5])), (slice(10, 12), np.array([5.0, -3.0]))):
+        d = out[:, cols]
+        assert np.abs(d.mean(0) - mean).max() < se * np.sqrt(cov.max()), (cols, d.mean(0))
+        np.testing.assert_allclose(np.cov(d.T), cov, atol=0.03 * cov.max() + 0.004)
+    r = np.linalg.norm(out[:, 12:14] - np.array([1.0, 2.0]), axis=1)           # src/stats/Distributions.py:125-130
+    assert abs(r.mean() - 7.0) < 0.5 * se and abs(r.std() - 0.5) < 0.012
+    phi = np.arctan2(out[:, 13] - 2.0, out[:, 12] - 1.0)
+    assert phi.min() < -3.1 and phi.max() > 3.1 and abs(np.cos(phi).mean()) < 0.03 and abs(np.sin(phi).mean()) < 0.03
+
+
+def test_fused_simulator_noisy_se2_ops_have_the_reference_noise_model():
+    """`PRIOR_SE2`, `REL_FWD`, `REL_BWD`, `REL_OBS` with a NON-TRIVIAL Cholesky factor.  In the reference's draws
+    (tests/golden/se2_factors.npz: `prior_out`, `rel_fwd`, `rel_bwd`, src/factors/Factors.py:725-743, 1196-1317) the
+    tangent-space residual Log(prior^-1 x) resp. Log(obs^-1 T_i^-1 T_j) IS the injected Gaussian draw -- asserted here on
+    the golden vectors with the repo's SE2Pose (itself pinned to the reference's algebra).  The device draws its own
+    Gaussians, so the same residuals of 40 000 device samples must have mean 0 and covariance L L^T."""
+    import nfisam_hip as nh
+    from geometry.TwoDimension import SE2Pose
+    g = dict(np.load(os.path.join(GOLDEN, "se2_factors.npz")))
+    prior, obs = SE2Pose(*g["prior_pose"]), SE2Pose(*g["rel_obs_value"])
+    res = np.array([(prior.inverse() * SE2Pose(*x)).log_map() for x in g["prior_out"]])
+    np.testing.assert_allclose(res, g["f_noise3"], atol=1e-12)
+    res = np.array([(obs.inverse() * (SE2Pose(*a).inverse() * SE2Pose(*b))).log_map() for a, b in zip(g["f_x1"], g["rel_fwd"])])
+    np.testing.assert_allclose(res, g["f_noise3"], atol=1e-12)
+    res = np.array([(obs.inverse() * (SE2Pose(*a).inverse() * SE2Pose(*b))).log_map() for a, b in zip(g["rel_bwd"], g["f_x2"])])
+    np.testing.assert_allclose(res, g["f_noise3"], atol=1e-12)
+
+    N = 40000
+    cov = np.array([[0.09, 0.02, -0.004], [0.02, 0.04, 0.006], [-0.004, 0.006, 0.0025]])
+    L = np.linalg.cholesky(cov)
+    lp = [L[0, 0], L[1, 0], L[1, 1], L[2, 0], L[2, 1], L[2, 2]]
+    Ti, Tj = g["f_x1"][7], g["f_x2"][11]
+    src = torch.from_numpy(np.tile(np.hstack([Ti, Tj]).astype(np.float32), (N, 1))).to(DEV).contiguous()
+    # columns: 0..2 T_i | 3..5 T_j | 6..8 prior draw | 9..11 T_i * obs * Exp | 12..14 T_j * (obs * Exp)^-1 | 15..17 (T_i^-1 T_j) * Exp
+    ops = [_sim_op(nh, nh.SIM_COPY, a=6, b=0, c=0, k=6, srcp=src.data_ptr()),
+           _sim_op(nh, nh.SIM_PRIOR_SE2, c=6, p=list(g["prior_pose"]) + lp),
+           _sim_op(nh, nh.SIM_REL_FWD, a=0, c=9, p=list(g["rel_obs_value"]) + lp),
+           _sim_op(nh, nh.SIM_REL_BWD, a=3, c=12, p=list(g["rel_obs_value"]) + lp),
+           _sim_op(nh, nh.SIM_REL_OBS, a=0, b=3, c=15, p=[0, 0, 0] + lp)]
+    out = nh.simulate_clique(ops, N, 18, 18, 31337, DEV).cpu().numpy().astype(np.float64)
+    pi, pj = SE2Pose(*Ti), SE2Pose(*Tj)
+    d_ij = pi.inverse() * pj
+
+    def residuals(rows, f):
+        return np.array([f(SE2Pose(*x)).log_map() for x in rows[::4]])           # every 4th sample: 10 000 host log maps
+    checks = {"prior": residuals(out[:, 6:9], lambda x: prior.inverse() * x),
+              "rel_fwd": residuals(out[:, 9:12], lambda x: obs.inverse() * (pi.inverse() * x)),
+              "rel_bwd": residuals(out[:, 12:15], lambda x: obs.inverse() * (x.inverse() * pj)),
+              "rel_obs": residuals(out[:, 15:18], lambda x: d_ij.inverse() * x)}
+    sd = np.sqrt(np.diag(cov))
+    for name, e in checks.items():
+        assert np.all(np.abs(e.mean(0)) < 5 * sd / np.sqrt(len(e)) + 2e-5), (name, e.mean(0))
+        c = np.cov(e.T)
+        assert np.abs(c - cov).max() < 0.06 * cov.max() and np.all(np.abs(np.diag(c) / np.diag(cov) - 1) < 0.06), (name, c)
+        # the sign pattern of the off-diagonal terms pins the packing order of the Cholesky factor
+        assert np.sign(c[0, 1]) == np.sign(cov[0, 1]) and np.sign(c[1, 2]) == np.sign(cov[1, 2]), (name, c)
+
+
 def test_non_finite_batch_is_retried_once_then_raises():
     """A non-finite training loss ends the run of THAT clique with NFISAM_ERR_DOMAIN (the reference dies on its
     `Input outside domain` / discriminant checks, src/flows/utils.py:74-76,133); `NFiSAM.train_prepared` retries the clique

@@ -44,6 +44,7 @@ constexpr int FUSED_COUNTERS = 64, FUSED_MAX_COPIES = 32;
 
 struct TrainArgs {
     const nfisam_clique* cliques;   // device array (batched) or nullptr
+    const nfisam_clique* host_cliques;   // host copy of `cliques` when the caller has one (training plans), else nullptr: launcher-side only
     nfisam_clique single;           // by-value descriptor when cliques == nullptr
     const float* gz;                // VJP mode: upstream dL/dz [n,D]
     const float* gl;                // VJP mode: upstream dL/dlogdet [n] (nullable => 0)

@@ -551,7 +551,7 @@ static bool fused_adam_shape(int n_cliques, int max_n, int max_D, int L, int H, 
 
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
-                        const nfisam_adam_cfg* fused_cfg = nullptr) {
+                        const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
@@ -563,6 +563,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
         a.log_b2 = (float)log((double)fused_cfg->beta2);
     }
     a.cliques = dev_cliques;
+    a.host_cliques = host_cliques;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
     const NsfUnitOps* ops = find_ops(K, H);
@@ -585,10 +586,10 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 // iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
-                        hipStream_t s) {
+                        hipStream_t s, const nfisam_clique* host_cliques = nullptr) {
     const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H));
     int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
-                          fused ? cfg : nullptr);
+                          fused ? cfg : nullptr, host_cliques);
     if (rc || fused) return rc;
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
@@ -748,7 +749,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         if (e == hipSuccess) {
             const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
             for (int it = 0; it < p->chunk && status == NFISAM_OK; ++it)
-                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap);
+                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap, p->host.data());
             if (status == NFISAM_OK)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
                                            p->cap, p->hst_dev);
@@ -814,7 +815,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
         } else {
             for (int it = 0; it < todo; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,
-                                      &p->cfg, it, work);
+                                      &p->cfg, it, work, p->host.data());
                 if (rc) return rc;
             }
             int rcb = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg,

@@ -651,8 +651,28 @@ __device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (
 #undef STAMP_SLOT
 #define STAMP_SEL (bx == 0 && by == 0)
 #define STAMP_SLOT ((w + i * 4) & 63)
+// Kernel arguments: what a block needs to FIND its work comes first, as scalars -- the unit is compiled with
+// -amdgpu-kernarg-preload-count=16, so these 40 bytes are in SGPRs when the wave starts and the clique's descriptor can
+// be requested with the first instruction (two dependent ~0.4 us round trips -- kernel arguments, then descriptor --
+// become one).  Launches of at most TRAIN1_KERNARG_CLIQUES cliques carry the descriptors themselves in the argument
+// segment (`few`): the kernel-argument segment's address is known at wave start as well.
+struct Train1Head {
+    const nfisam_clique* cliques;   // device array of descriptors, or nullptr: the descriptors are in `few`
+    const uint32_t* panel_map;      // kernel-layout parameter index -> LDS word(s) of the conditioner panel (nsf_cond_mfma.h)
+    unsigned magic_cliques;         // ceil(2^32 / cliques) (0: one clique): group / cliques without a division
+    int groups;                     // (clique, dim) groups = cliques x largest D
+    int grid_cliques;               // cliques of the launch
+    int xrows;                      // rows of a wave's particle tile in LDS (largest D of the launch)
+    int shifts;                     // log2 tiles per wave | log2 waves per block << 8
+};
+constexpr int TRAIN1_KERNARG_CLIQUES = 8;
+struct Train1Few { nfisam_clique c[TRAIN1_KERNARG_CLIQUES]; };
+constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);   // kernel-argument offset of `few` (asserted on the host)
+
 template <int K, int H>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))) nsf_train1_kernel(TrainArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8)))
+nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
+                  int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
     using CP = CondPanel<K, H>;
     constexpr int PoP = LY::PoP;
@@ -664,15 +684,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
 
     const int bx = blockIdx.y;                                // tile group inside the (clique, dim)
     const int grp = blockIdx.x + 8 * blockIdx.z;
-    if (grp >= a.groups) return;                              // padding of the group count to a multiple of 8
-    const int gq = a.magic_cliques != 0u ? (int)__umulhi((unsigned)grp, a.magic_cliques) : grp;    // grp / cliques
-    const int by = grp - gq * a.grid_cliques;                 // clique
-    const int i = a.xrows - 1 - gq;                           // this block's dim: the long ones first
+    if (grp >= h_groups) return;                              // padding of the group count to a multiple of 8
+    const int gq = h_magic != 0u ? (int)__umulhi((unsigned)grp, h_magic) : grp;    // grp / cliques
+    const int by = grp - gq * h_grid_cliques;                 // clique
+    const int i = h_xrows - 1 - gq;                           // this block's dim: the long ones first
     typedef const __attribute__((address_space(4))) nfisam_clique cclique;
     typedef const __attribute__((address_space(4))) char cchar;
-    cclique* cp = (a.cliques != nullptr)
-                      ? (cclique*)(a.cliques + by)
-                      : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TrainArgs, single));
+    cclique* cp = (h_cliques != nullptr)
+                      ? (cclique*)(h_cliques + by)
+                      : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + TRAIN1_FEW_OFFSET) + by;
+    (void)few;
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
     // atomics, which count against both memory counters)
     const gfloat* x = (const gfloat*)cp->x;
@@ -687,7 +708,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     if (i >= D) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ws = a.w_shift, ts = a.t_shift;
+    const int ws = h_shifts >> 8, ts = h_shifts & 0xff;
     const int W = 1 << ws, T = 1 << ts;
     const int slot = (bx << ws) + w;                          // this wave's tile group
     const int p0 = slot << (6 + ts);
@@ -712,7 +733,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
     const gfloat* Gprev = par ? G : Gset1;                    // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
-    const int xrows = a.xrows;                                // rows of a particle tile in LDS (largest D of the launch)
+    const int xrows = h_xrows;                                // rows of a particle tile in LDS (largest D of the launch)
     const float* pan = smem + PANEL_BASE;                     // the block's conditioner panel (nsf_cond_mfma.h)
     // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
     // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
@@ -800,7 +821,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, a.panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
+            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
             __syncthreads();
         }
         if (p0 >= n) return;
@@ -2012,7 +2033,20 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
         rc = set_lds(nsf_train1_kernel<KK, HH>, lds_launch);
         if (rc) return rc;
-        hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, (a.groups + 7) / 8), dim3(64 * W), lds_launch, s, a);
+        // few cliques: their descriptors travel in the kernel arguments (host copy: the plan's, or the single one)
+        static_assert(offsetof(Train1Head, shifts) == 32 && sizeof(Train1Head) == 40, "scalar head of the kernel arguments");
+        Train1Few few;
+        memset(&few, 0, sizeof(few));
+        const nfisam_clique* dev = a.cliques;
+        const nfisam_clique* host = (a.cliques == nullptr) ? &a.single : a.host_cliques;
+        if (host != nullptr && n_cliques <= TRAIN1_KERNARG_CLIQUES) {
+            memcpy(few.c, host, sizeof(nfisam_clique) * (size_t)n_cliques);
+            dev = nullptr;
+        } else if (dev == nullptr) {
+            return NFISAM_ERR_ARG;
+        }
+        hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, (a.groups + 7) / 8), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+                           a.magic_cliques, a.groups, a.grid_cliques, a.xrows, a.t_shift | (a.w_shift << 8), a, few);
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;
     }

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Pipeline fixtures from the REFERENCE ITSELF (build container only: needs /root/reference; nothing of it travels).
+
+For BASELINE configs 0 / 3 / 4 this runs the reference's own incremental loop
+(`run_incrementally`, /root/reference/src/slam/FactorGraphSolver.py:760-933, through `NFiSAM`,
+src/slam/NFiSAM.py:317-586) on the first updates of
+    small_range   example/slam/small_range_gaussian_problem/journal_paper/case1   (run_nfisam.py arguments, incremental_step 1)
+    plaza1        example/slam/plaza_dataset/RangeOnlyDataset/Plaza1EFG            (run_nfisam.py:5-21, incremental_step 5)
+    manhattan136  example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3 (incremental_step 1)
+with a REDUCED iteration budget (CPU: ~15-25 ms per training iteration of one clique), for several seeds, and stores
+  (i)  what the reference fed to `fit_clique_density_model` (FactorGraphSolver.py:479-495): per trained clique the
+       variable ordering, the true observations and a row subsample of the training batch;
+  (ii) the posterior samples of every step (the `step{i}` files run_incrementally writes) with their orderings.
+The GPU tests (tests/test_pipeline_gpu.py) run this repository's solver with the SAME arguments and compare (i) the
+simulated training batches per clique and (ii) the per-step posteriors with the reference's seed band by MMD.
+
+The reference imports TransportMaps / dynesty / seaborn ... at module level (absent here, and never used by the NF-iSAM
+path): permissive stand-in modules are written to a TEMPORARY directory at run time and never committed.  The reference
+tree is read-only: the case directory is copied to a temp dir and `run_incrementally` writes its run folder there.
+
+    python tests/golden/make_pipeline_fixture.py [small_range plaza1 manhattan136] [--seeds 5] [--jobs 4]
+Workers are separate processes started with PYTHONHASHSEED=0 (set iteration order = reproducible orderings).
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # name: (case dir in the reference, incremental_step, updates, NFiSAM kwargs of the reference's run script with the
+    #        iteration budget reduced, posterior samples kept per step, batch rows kept per clique)
+    "small_range": ("example/slam/small_range_gaussian_problem/journal_paper/case1", 1, 6,
+                    dict(num_knots=9, flow_iterations=400, local_sample_num=2000, learning_rate=.025, hidden_dim=8,
+                         cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
+                         posterior_sample_num=500), 500, 400),
+    "plaza1": ("example/slam/plaza_dataset/RangeOnlyDataset/Plaza1EFG", 5, 4,
+               dict(num_knots=9, flow_iterations=300, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                    cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
+                    average_window=50, posterior_sample_num=300), 300, 300),
+    "manhattan136": ("example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3", 1, 6,
+                     dict(num_knots=9, flow_iterations=300, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                          cuda_training=False, elimination_method="pose_first", training_set_frac=1.0,
+                          loss_delta_tol=1e-9, average_window=50, posterior_sample_num=300), 300, 300),
+}
+
+STUB = '''
+from abc import ABCMeta
+class _Meta(ABCMeta):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Any
+class _Any(metaclass=_Meta):
+    def __init__(self, *a, **k): pass
+    def __call__(self, *a, **k): return _Any()
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Any()
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    return type(name, (_Any,), {})
+'''
+# TransportMaps.Distributions.GaussianDistribution IS used by the reference's factors (noise draws `rvs`, densities:
+# src/factors/Factors.py:336,373,695,1129,...).  Restated from TransportMaps 2.0's published behaviour: N(mu, sigma) given a
+# covariance or a precision matrix; rvs(m) = mu + chol(sigma) z with z from numpy's global generator; pdf / log_pdf /
+# grad_x_log_pdf of the multivariate normal.  (Its random STREAM differs from the real package; the fixtures are compared
+# in distribution only.)
+GAUSSIAN = '''
+import numpy as np
+class GaussianDistribution(_Any):
+    def __init__(self, mu, sigma=None, precision=None, *a, **k):
+        self.mu = np.asarray(mu, dtype=float).reshape(-1)
+        self.dim = self.mu.size
+        if sigma is None:
+            sigma = np.linalg.inv(np.asarray(precision, dtype=float))
+        self.sigma = np.asarray(sigma, dtype=float).reshape(self.dim, self.dim)
+        self.precision = np.linalg.inv(self.sigma)
+        self._chol = np.linalg.cholesky(self.sigma)
+        self._lognorm = -0.5 * (self.dim * np.log(2 * np.pi) + np.linalg.slogdet(self.sigma)[1])
+    def rvs(self, m, *a, **k):
+        return self.mu + np.random.standard_normal((int(m), self.dim)) @ self._chol.T
+    def log_pdf(self, x, *a, **k):
+        d = np.atleast_2d(x) - self.mu
+        return self._lognorm - 0.5 * np.einsum("ni,ij,nj->n", d, self.precision, d)
+    def pdf(self, x, *a, **k):
+        return np.exp(self.log_pdf(x))
+    def grad_x_log_pdf(self, x, *a, **k):
+        return -(np.atleast_2d(x) - self.mu) @ self.precision
+class StandardNormalDistribution(GaussianDistribution):
+    def __init__(self, dim, *a, **k):
+        super().__init__(np.zeros(dim), sigma=np.eye(dim))
+'''
+STUB_PACKAGES = {"TransportMaps": ["Distributions", "Likelihoods", "Maps", "Functionals", "Algorithms"],
+                 "dynesty": ["utils", "plotting"], "seaborn": [], "pingouin": [], "arviz": [], "pymc3": [],
+                 "theano": ["tensor"], "evo": [], "statsmodels": [], "pyquaternion": [], "gtsam": []}
+
+
+def write_stubs(root):
+    for pkg, subs in STUB_PACKAGES.items():
+        for d in [pkg] + [os.path.join(pkg, s) for s in subs]:
+            os.makedirs(os.path.join(root, d), exist_ok=True)
+            with open(os.path.join(root, d, "__init__.py"), "w") as f:
+                f.write(STUB + (GAUSSIAN if d == os.path.join("TransportMaps", "Distributions") else ""))
+
+
+def worker(case, seed, out_path):
+    """One reference run (own process, PYTHONHASHSEED=0)."""
+    import random
+    ref_dir, step, updates, kwargs, n_post, n_batch = CASES[case]
+    tmp = tempfile.mkdtemp(prefix="nfisam_ref_")
+    try:
+        write_stubs(os.path.join(tmp, "stubs"))
+        sys.path.insert(0, os.path.join(tmp, "stubs"))
+        sys.path.insert(0, os.path.join(REF, "src"))
+        sys.dont_write_bytecode = True
+        import matplotlib
+        matplotlib.use("Agg")
+        import torch
+        torch.set_num_threads(int(os.environ.get("REF_THREADS", "2")))
+        import slam.FactorGraphSolver as FGS
+        import slam.NFiSAM as RN
+        from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+        FGS.plot_2d_samples = lambda *a, **k: None                 # plotting only (utils/Visualization.py)
+        RN.NFiSAM.plot2d_mean_rbt_only = lambda *a, **k: None
+        case_dir = os.path.join(tmp, "case")
+        os.makedirs(case_dir)
+        shutil.copy(os.path.join(REF, ref_dir, "factor_graph.fg"), case_dir)
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        nodes, truth, factors = graph_file_parser(data_file=os.path.join(case_dir, "factor_graph.fg"), data_format="fg",
+                                                  prior_cov_scale=0.1)
+        steps = group_nodes_factors_incrementally(nodes=nodes, factors=factors, incremental_step=step)[:updates]
+        solver = RN.NFiSAM(RN.NFiSAMArgs(**kwargs))
+        fits, update_no = [], [0]
+        orig_fit = RN.NFiSAM.fit_clique_density_model
+        orig_update = RN.NFiSAM.update_physical_and_working_graphs
+
+        def fit(self, clique, samples, var_ordering, timer, *a, **k):
+            true_obs = self._clique_true_obs[clique]
+            rows = np.random.RandomState(len(fits)).permutation(samples.shape[0])[:n_batch]
+            fits.append(dict(update=update_no[0] - 1, vars=[v.name for v in var_ordering],
+                             frontal=sorted(v.name for v in clique.frontal), dims=[int(v.dim) for v in var_ordering],
+                             true_obs=np.asarray(true_obs, dtype=np.float64), batch=np.asarray(samples)[rows].astype(np.float32)))
+            return orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
+
+        def update(self, *a, **k):
+            update_no[0] += 1
+            return orig_update(self, *a, **k)
+        RN.NFiSAM.fit_clique_density_model = fit
+        RN.NFiSAM.update_physical_and_working_graphs = update
+        FGS.run_incrementally(case_dir, solver, steps, truth, False, {"show_plot": False}, False)
+        run_dir = os.path.join(case_dir, "run1")
+        out = {"n_fits": len(fits), "n_steps": len(steps)}
+        for i in range(len(steps)):
+            X = np.loadtxt(os.path.join(run_dir, "step%d" % i))
+            names = open(os.path.join(run_dir, "step%d_ordering" % i)).read().split()
+            rows = np.random.RandomState(1000 + i).permutation(X.shape[0])[:n_post]
+            out["step%d_samples" % i] = X[rows].astype(np.float32)
+            out["step%d_ordering" % i] = np.array(names)
+        for j, f in enumerate(fits):
+            out["fit%d_meta" % j] = np.array(json.dumps(dict(update=f["update"], vars=f["vars"], frontal=f["frontal"], dims=f["dims"])))
+            out["fit%d_true_obs" % j] = f["true_obs"]
+            out["fit%d_batch" % j] = f["batch"]
+        out["timing"] = np.array([float(t) for t in open(os.path.join(run_dir, "step_timing")).read().split()])
+        np.savez_compressed(out_path, **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--worker", nargs=3, metavar=("CASE", "SEED", "OUT"))
+    args = ap.parse_args()
+    if args.worker:
+        worker(args.worker[0], int(args.worker[1]), args.worker[2])
+        return
+    if not os.path.isdir(REF):
+        raise SystemExit("needs the reference at %s (build container only)" % REF)
+    work = tempfile.mkdtemp(prefix="nfisam_fixture_")
+    jobs = [(c, s, os.path.join(work, "%s_seed%d.npz" % (c, s))) for c in args.cases for s in range(args.seeds)]
+    running = []
+    env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1", REF_THREADS=str(max(1, 8 // args.jobs)))
+    while jobs or running:
+        while jobs and len(running) < args.jobs:
+            c, s, o = jobs.pop(0)
+            log = open(o + ".log", "w")
+            running.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", c, str(s), o], env=env,
+                                             stdout=log, stderr=subprocess.STDOUT), c, s, o))
+        p, c, s, o = running.pop(0)
+        if p.wait() != 0:
+            raise SystemExit("reference run %s seed %d failed: see %s.log" % (c, s, o))
+        print("done", c, s, flush=True)
+    for c in args.cases:
+        merged = {"seeds": np.arange(args.seeds), "arguments": np.array(json.dumps(CASES[c][3])),
+                  "incremental_step": np.array(CASES[c][1])}
+        for s in range(args.seeds):
+            d = np.load(os.path.join(work, "%s_seed%d.npz" % (c, s)))
+            for k in d.files:
+                merged["seed%d_%s" % (s, k)] = d[k]
+        path = os.path.join(HERE, "pipeline_%s.npz" % c)
+        np.savez_compressed(path, **merged)
+        print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+    shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

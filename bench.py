@@ -220,11 +220,15 @@ class Workload:
                 float(np.mean([v[iters - 1] for v in il])))
 
     def time_gradient_kernel(self, reps=200):
-        """Average duration of the gradient kernel exactly as a training iteration launches it: `reps` launches captured
-        in a graph (no host launch gaps), HIP events on the stream they run on; includes one ~1.5 us kernel boundary."""
+        """Average duration of the gradient kernel as ONE launch over all (clique, dim) groups: `reps` launches captured in
+        a graph (no host launch gaps), HIP events on the stream they run on; includes one ~1.5 us kernel boundary.  (A
+        training plan may issue the same kernel as `chains` concurrent launches over disjoint groups -- parallel graph
+        branches, nfisam_nsf_train_chains -- which shortens the ITERATION, `gpu_us_per_iteration_events`, not the kernel.)
+        -> (us per launch, chains of the plan)"""
         torch = self.torch
         tbk = self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, H, B, self.L, lr=LR, max_iters=10 ** 6,
                                  early_stop=False)
+        chains = tbk.chains()
         for _ in range(20):
             tbk.gradient_only()
         torch.cuda.synchronize()
@@ -241,16 +245,16 @@ class Workload:
         torch.cuda.synchronize()
         us = 1e3 * k0.elapsed_time(k1) / reps
         tbk.close()
-        return us
+        return us, chains
 
     def record(self, iters, warmup, barrier, reduce_max=None):
         dt, gpu_ms, l0, l1 = self.time_iterations(iters, warmup, barrier, reduce_max)
-        kus = self.time_gradient_kernel()
+        kus, chains = self.time_gradient_kernel()
         ach = self.flop_per_launch / (kus * 1e-6) / 1e12
         return dict(cliques=len(self.xs), D=[int(x.shape[1]) for x in self.xs] if len(self.xs) <= 8 else int(self.xs[0].shape[1]),
                     particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, iterations=iters, replays=self.replays,
                     us_per_iteration=1e6 * dt / iters, gpu_us_per_iteration_events=1e3 * gpu_ms / iters,
-                    samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus,
+                    samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus, launches_per_training_iteration=chains,
                     flop_per_launch=self.flop_per_launch, achieved_tflops=ach, frac_of_fp32_peak=ach / FP32_PEAK_TFLOPS,
                     first_loss=l0, final_loss=l1), dt
 

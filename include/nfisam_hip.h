@@ -244,6 +244,18 @@ size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
                               int max_D, int K, int H, float B, int L, nfisam_stream_t stream);
 
+/* Training plans split an iteration of a one-layer batch into `nfisam_nsf_train_chains(...)` launches that run as
+ * parallel branches of the chunk's hipGraph (the (clique, dim) groups of a one-layer flow are independent optimisation
+ * problems, reference loop src/slam/NFiSAM.py:451-494; a branch's kernel prologue and tail then run under another
+ * branch's arithmetic).  `nfisam_nsf_train_gradient_part` is launch `chain` of `n_chains` of the gradient half, for
+ * callers that want to time or drive the launches exactly as a plan issues them (bench.py: one stream per chain).
+ * n_chains = 1 is nfisam_nsf_train_gradient.  Launch shapes that are not split return 1 from nfisam_nsf_train_chains
+ * and NFISAM_ERR_ARG for n_chains > 1. */
+int nfisam_nsf_train_chains(int n_cliques, int max_n, int max_D, int K, int H, int L);
+int nfisam_nsf_train_gradient_part(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                                   int max_D, int K, int H, float B, int L, int chain, int n_chains,
+                                   nfisam_stream_t stream);
+
 /* One full-batch training iteration of `n_cliques` independent cliques (grid.y = clique):
  * forward + analytic backward + gradient reduction, the Adam update, and a one-wave bookkeeping kernel
  * that records iter_loss[step], evaluates the reference's window early-stop rule on the device and

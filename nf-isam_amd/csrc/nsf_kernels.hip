@@ -551,7 +551,8 @@ static bool fused_adam_shape(int n_cliques, int max_n, int max_D, int L, int H, 
 
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
-                        const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr) {
+                        const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr,
+                        int chain = 0, int n_chains = 1) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
@@ -564,6 +565,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
     }
     a.cliques = dev_cliques;
     a.host_cliques = host_cliques;
+    a.chain = chain; a.n_chains = n_chains;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
     const NsfUnitOps* ops = find_ops(K, H);
@@ -586,10 +588,11 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 // iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
-                        hipStream_t s, const nfisam_clique* host_cliques = nullptr) {
+                        hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1) {
     const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H));
+    if (!fused && n_chains > 1) return NFISAM_ERR_ARG;
     int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
-                          fused ? cfg : nullptr, host_cliques);
+                          fused ? cfg : nullptr, host_cliques, chain, n_chains);
     if (rc || fused) return rc;
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
@@ -656,6 +659,45 @@ static int check_cfg(const nfisam_adam_cfg* cfg, int K, int H, int L, float B) {
     return NFISAM_OK;
 }
 
+// Parallel launches per iteration of a training plan (see nfisam_nsf_train_plan_create): NFISAM_CHAINS=n, default by size.
+static int plan_chains(int n_cliques, int max_n, int max_D, int K, int H, int L) {
+    (void)K;
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh)) return 1;
+    const long waves = (long)n_cliques * max_D * ((max_n + 64 * sh.T - 1) / (64 * sh.T));
+    // measured (MI355X): C3 (3072 waves) 15.0 -> 14.5 us per iteration, 64 cliques (7680 waves) 89.5 -> 82.5;
+    // one Plaza clique (480 waves) 11.3 -> 11.7: stays one launch
+    int chains = waves >= 1536 ? 2 : 1;
+    if (const char* ce = getenv("NFISAM_CHAINS")) chains = atoi(ce);
+    const int octets = (n_cliques * max_D + 7) / 8;
+    if (chains > octets) chains = octets;
+    if (chains < 1) chains = 1;
+    if (chains > 8) chains = 8;
+    return chains;
+}
+
+extern "C" int nfisam_nsf_train_chains(int n_cliques, int max_n, int max_D, int K, int H, int L) {
+    if (n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !nfisam_nsf_supported(K, H)) return 1;
+    return plan_chains(n_cliques, max_n, max_D, K, H, L);
+}
+
+extern "C" int nfisam_nsf_train_gradient_part(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
+                                              int max_D, int K, int H, float B, int L, int chain, int n_chains,
+                                              nfisam_stream_t stream) {
+    if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
+        !nfisam_nsf_supported(K, H) || n_chains < 1 || chain < 0 || chain >= n_chains)
+        return NFISAM_ERR_ARG;
+    if (n_chains > 1 && !fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H)))
+        return NFISAM_ERR_ARG;
+    if (cliques_on_host) {
+        if (n_cliques != 1) return NFISAM_ERR_ARG;
+        return enqueue_grad(nullptr, cliques, 1, max_n, max_D, K, H, B, L, 0x7fffffff, 0, (hipStream_t)stream, nullptr,
+                            nullptr, chain, n_chains);
+    }
+    return enqueue_grad(cliques, nullptr, n_cliques, max_n, max_D, K, H, B, L, 0x7fffffff, 0, (hipStream_t)stream, nullptr,
+                        nullptr, chain, n_chains);
+}
+
 extern "C" int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
                                          int max_D, int K, int H, float B, int L, nfisam_stream_t stream) {
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
@@ -691,6 +733,8 @@ struct nfisam_train_plan {
     nfisam_adam_cfg cfg;
     hipStream_t cap = nullptr;
     hipEvent_t ev = nullptr;
+    std::vector<hipStream_t> side;         // capture-time streams of the extra chains (parallel branches of the graph)
+    std::vector<hipEvent_t> side_ev;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
@@ -705,6 +749,8 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->ev) (void)hipEventDestroy(p->ev);
+    for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
+    for (hipStream_t st : p->side) (void)hipStreamDestroy(st);
     if (p->cap) (void)hipStreamDestroy(p->cap);
     if (p->hst) (void)hipHostFree(p->hst);
     delete p;
@@ -745,12 +791,35 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         int status = NFISAM_OK;
         hipError_t e = hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+        // Chains: with one layer the (clique, dim) groups are independent optimisation problems for a whole chunk (every
+        // group's blocks read and write that group's parameters, moments and gradient copies only), so an iteration may
+        // be split into n launches that form n PARALLEL branches of the graph: the branches drift apart, and one
+        // branch's kernel prologue / tail (memory round trips, a barrier, nothing to issue) runs under another's
+        // arithmetic.  Pays in the latency regime (few waves per SIMD); NFISAM_CHAINS=n, default by launch size.
+        const int chains = plan_chains(n_cliques, p->max_n, p->max_D, K, H, L);
+        for (int g = 1; g < chains && e == hipSuccess; ++g) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev2 = nullptr;
+            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e == hipSuccess) { p->side.push_back(st); e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming); }
+            if (e == hipSuccess) p->side_ev.push_back(ev2);
+        }
         if (e == hipSuccess) e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
-            for (int it = 0; it < p->chunk && status == NFISAM_OK; ++it)
-                status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it, p->cap, p->host.data());
-            if (status == NFISAM_OK)
+            for (int g = 1; g < chains && e == hipSuccess; ++g) {      // fork
+                e = hipEventRecord(p->ev, p->cap);
+                if (e == hipSuccess) e = hipStreamWaitEvent(p->side[g - 1], p->ev, 0);
+            }
+            for (int it = 0; it < p->chunk && status == NFISAM_OK && e == hipSuccess; ++it)
+                for (int g = 0; g < chains && status == NFISAM_OK; ++g)
+                    status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it,
+                                          g == 0 ? p->cap : p->side[g - 1], p->host.data(), g, chains);
+            for (int g = 1; g < chains && e == hipSuccess; ++g) {      // join
+                e = hipEventRecord(p->side_ev[g - 1], p->side[g - 1]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(p->cap, p->side_ev[g - 1], 0);
+            }
+            if (status == NFISAM_OK && e == hipSuccess)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
                                            p->cap, p->hst_dev);
             e = hipStreamEndCapture(p->cap, &p->graph);

@@ -683,7 +683,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int bx = blockIdx.y;                                // tile group inside the (clique, dim)
-    const int grp = blockIdx.x + 8 * blockIdx.z;
+    // (chains: an iteration may be split into n launches on parallel graph branches, see nfisam_nsf_train_plan_create;
+    //  launch c takes the octets of groups c, c + n, ...)
+    const int grp = blockIdx.x + 8 * (blockIdx.z * ((h_shifts >> 24) & 0xff) + ((h_shifts >> 16) & 0xff));
     if (grp >= h_groups) return;                              // padding of the group count to a multiple of 8
     const int gq = h_magic != 0u ? (int)__umulhi((unsigned)grp, h_magic) : grp;    // grp / cliques
     const int by = grp - gq * h_grid_cliques;                 // clique
@@ -708,7 +710,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     if (i >= D) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ws = h_shifts >> 8, ts = h_shifts & 0xff;
+    const int ws = (h_shifts >> 8) & 0xff, ts = h_shifts & 0xff;
     const int W = 1 << ws, T = 1 << ts;
     const int slot = (bx << ws) + w;                          // this wave's tile group
     const int p0 = slot << (6 + ts);
@@ -2045,8 +2047,14 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         } else if (dev == nullptr) {
             return NFISAM_ERR_ARG;
         }
-        hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, (a.groups + 7) / 8), dim3(64 * W), lds_launch, s, dev, a.panel_map,
-                           a.magic_cliques, a.groups, a.grid_cliques, a.xrows, a.t_shift | (a.w_shift << 8), a, few);
+        const int nch = a.n_chains > 1 ? a.n_chains : 1, ch = a.n_chains > 1 ? a.chain : 0;
+        const int octets = (a.groups + 7) / 8;
+        const int gz = (octets - ch + nch - 1) / nch;          // octets ch, ch + nch, ...
+        if (nch > 255 || ch < 0 || ch >= nch) return NFISAM_ERR_ARG;
+        if (gz > 0)
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+                               a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
+                               a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;
     }

@@ -22,7 +22,7 @@ EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
-    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient",
+    "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
     "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
@@ -310,6 +310,21 @@ class TrainBatch:
             rc = lib().nfisam_nsf_train_step(C.c_void_p(self.dev_desc.data_ptr()), self.nc, 0, self.max_n, self.max_D,
                                              self.K, self.H, C.c_float(self.B), self.L, C.byref(self.cfg), _stream())
         _check(rc, "nfisam_nsf_train_step")
+
+    def chains(self):
+        """Launches a training plan issues per iteration for this batch (parallel graph branches; 1 = not split)."""
+        return int(lib().nfisam_nsf_train_chains(self.nc, self.max_n, self.max_D, self.K, self.H, self.L))
+
+    def gradient_part(self, chain, n_chains, stream=None):
+        """Launch `chain` of `n_chains` of the gradient half of an iteration, on `stream` (default: the current one)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+        if self.nc == 1:
+            rc = lib().nfisam_nsf_train_gradient_part(C.byref(self.host_desc[0]), 1, 1, self.max_n, self.max_D, self.K, self.H,
+                                                      C.c_float(self.B), self.L, int(chain), int(n_chains), st)
+        else:
+            rc = lib().nfisam_nsf_train_gradient_part(C.c_void_p(self.dev_desc.data_ptr()), self.nc, 0, self.max_n, self.max_D,
+                                                      self.K, self.H, C.c_float(self.B), self.L, int(chain), int(n_chains), st)
+        _check(rc, "nfisam_nsf_train_gradient_part")
 
     def gradient_only(self):
         """Enqueue only the gradient kernel of an iteration (no Adam, no bookkeeping)."""

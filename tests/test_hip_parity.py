@@ -612,6 +612,53 @@ def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, 
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
 
 
+def test_gradient_parts_cover_the_gradient_launch():
+    """`nfisam_nsf_train_gradient_part`: the launches of a split iteration write exactly the gradient copies and loss sums
+    of the single launch (disjoint (clique, dim) groups), in any order; a launch shape that is not split refuses parts."""
+    K, H, B = 9, 8, 5.0
+    shapes = [(1900, 12), (300, 17), (700, 9)]
+    probs = [make_problem(n, D, K, H, 1, seed=500 + c) for c, (n, D) in enumerate(shapes)]
+
+    def batch():
+        return nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H) for (b, _), (_, D) in zip(probs, shapes)], K, H, B, 1,
+                             lr=0.01, max_iters=5, early_stop=False)
+    ref = batch()
+    ref.gradient_only()
+    got = batch()
+    for g in (2, 0, 1):
+        got.gradient_part(g, 3)
+    torch.cuda.synchronize()
+    assert ref.chains() >= 1
+    for (n, D), a, b in zip(shapes, ref.g, got.g):
+        copies = ((n + 63) // 64 + 3) // 4 * nh.kparam_count(D, K, H)      # one gradient copy per block of four tiles
+        assert torch.equal(a[:copies], b[:copies])                          # gradient copies: plain stores, bit for bit
+        assert float(a[:copies].abs().sum()) > 0
+        torch.testing.assert_close(a[copies:], b[copies:], rtol=1e-5, atol=1e-4)    # loss sums: float atomics (order-dependent rounding)
+    lm = nh.TrainBatch([dev(probs[0][1])], [kpack(make_problem(1900, 12, K, H, 2, seed=1)[0], 12, K, H, 2)], K, H, B, 2, lr=0.01,
+                       max_iters=5, early_stop=False)
+    assert lm.chains() == 1
+    with pytest.raises(Exception):
+        lm.gradient_part(0, 2)
+
+
+@pytest.mark.parametrize("chains", [2, 3, 5])
+def test_parallel_graph_branches_leave_the_same_bits(chains):
+    """`NFISAM_CHAINS=n`: an iteration split into n launches on parallel branches of the chunk's hipGraph (independent
+    (clique, dim) groups: nsf_kernels.hip, plan creation) trains exactly the parameters and moments of the single-launch
+    iteration -- ragged batch with D > 16, a single-tile clique, full + partial chunks, more chains than group octets."""
+    shapes, iters, window = [(1900, 12), (300, 17), (2048, 3), (65, 1), (700, 9)], 130, 50
+    with _Env(NFISAM_CHAINS="1"):
+        d0, ref = _train_ragged(shapes, iters, window, True)
+    with _Env(NFISAM_CHAINS=str(chains)):
+        d1, got = _train_ragged(shapes, iters, window, True)
+    assert d0 == d1 == [iters] * len(shapes)
+    for name, a, b in zip(("theta", "m", "v"), ref[:3], got[:3]):
+        for c, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), (name, c, np.abs(x - y).max())
+    for x, y in zip(ref[3], got[3]):                        # the loss record goes through float atomics (order-dependent rounding)
+        np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("D", [64, 96, 100, 130])
 def test_wide_cliques_train_against_the_oracle(D):
     """Very wide cliques: up to D = 96 the dim-major kernel (its LDS rows grow with D), beyond it the tile-major kernels;

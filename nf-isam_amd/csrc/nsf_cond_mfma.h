@@ -25,6 +25,9 @@
 #pragma once
 #include "nsf_device.h"
 #include "nsf_host.h"
+#ifndef NSF_COND_SPLIT
+#define NSF_COND_SPLIT 1
+#endif
 
 typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -95,6 +98,11 @@ __device__ __forceinline__ float fused_sum_grads(const FusedAdam& fa, const floa
 // "second store" of parameters that have one destination).  Host-built once per (K, H) for dims 0 .. max_i and read by
 // the staging threads next to the parameter itself: the index arithmetic (two divisions and a six-way branch per
 // parameter) costs a lone wave ~2k cycles when done in the kernel.
+constexpr uint32_t PANEL_SCALED = 0x8000u;          // panel map: the first destination takes the parameter x 2 log2(e)
+constexpr float kTanhScale = 2.0f * 1.4426950408889634f;
+// tanh(a) from a' = 2 log2(e) a
+__device__ __forceinline__ float ftanh_scaled(float as) { return 1.0f - 2.0f * frcp(1.0f + __builtin_amdgcn_exp2f(as)); }
+
 template <int K, int H>
 static inline void build_panel_map(uint32_t* map, int max_D) {
     using CP = CondPanel<K, H>;
@@ -124,7 +132,10 @@ static inline void build_panel_map(uint32_t* map, int max_D) {
             } else {
                 d0 = CP::ob2 + (jj - LY::ob2(i));
             }
-            m[jj] = (uint32_t)(PANEL_BASE + d0) | ((uint32_t)(PANEL_BASE + d1) << 16);
+            // forward copies of layers 0 and 1 (W0T, b0, W1T, b1) are staged pre-multiplied by 2 log2(e): tanh of the
+            // pre-activation is then 1 - 2 / (1 + exp2(a')) without a multiplication per hidden unit and particle
+            const bool scaled = jj < LY::oW2(i);
+            m[jj] = (uint32_t)(PANEL_BASE + d0) | (scaled ? PANEL_SCALED : 0u) | ((uint32_t)(PANEL_BASE + d1) << 16);
         }
     }
 }
@@ -175,8 +186,8 @@ __device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta
                 if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
             }
         }
-        if (ja < nj) { lds0[da & 0xffffu] = ta; lds0[da >> 16] = ta; }
-        if (jb < nj) { lds0[db & 0xffffu] = tb; lds0[db >> 16] = tb; }
+        if (ja < nj) { lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta; }
+        if (jb < nj) { lds0[db & 0x7fffu] = (db & PANEL_SCALED) ? tb * kTanhScale : tb; lds0[db >> 16] = tb; }
     }
     if (i > 0) {
         const int s0 = CP::s0_of(i);
@@ -228,14 +239,17 @@ template <int K, int H>
 __device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const float* xt, int xs, int lane,
                                                   float (&h1)[H], float (&h2)[H], float (&th)[Layout<K, H>::PoP]) {
     using CP = CondPanel<K, H>;
-    constexpr int ST = CP::ST, GH = CP::GH, G2 = CP::G2, SP = (H >= 8) ? 2 : 1;
+    constexpr int ST = CP::ST, GH = CP::GH, G2 = CP::G2, SP = (H >= 8) ? NSF_COND_SPLIT : 1;
     const int r = lane & 3;
     const cm_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {   // layer 0: the only contraction whose length depends on the dim: eight inputs per round (zero weights past i,
         // the clamped row keeps the activation finite), four chains (group x quad parity)
-        cm_f32x4 a1[GH][2];
+        cm_f32x4 a1[GH][SP];
 #pragma unroll
-        for (int g = 0; g < GH; ++g) { a1[g][0] = *(const cm_f32x4*)(pan + CP::ob0 + 4 * g); a1[g][1] = zero; }
+        for (int g = 0; g < GH; ++g) {
+            a1[g][0] = *(const cm_f32x4*)(pan + CP::ob0 + 4 * g);
+            if (SP == 2) a1[g][SP - 1] = zero;
+        }
         const int s0 = CP::s0_of(i);
         const float* w0 = pan + CP::oW0T + r * s0;
         for (int k0 = 0; k0 < i; k0 += 8) {
@@ -248,18 +262,27 @@ __device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const
 #pragma unroll
                 for (int q = 0; q < 2; ++q) a4[g][q] = *(const cm_f32x4*)(w0 + 4 * g * s0 + k0 + 4 * q);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SP == 2) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int g = 0; g < GH; ++g)
+                    for (int g = 0; g < GH; ++g)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) a1[g][q] = mfma1(a4[g][q][u], xk[4 * q + u], a1[g][q]);
+                        for (int q = 0; q < 2; ++q) a1[g][q] = mfma1(a4[g][q][u], xk[4 * q + u], a1[g][q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int g = 0; g < GH; ++g) a1[g][0] = mfma1(a4[g][q][u], xk[4 * q + u], a1[g][0]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int g = 0; g < GH; ++g)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) h1[4 * g + u] = ftanh(a1[g][0][u] + a1[g][1][u]);
+            for (int u = 0; u < 4; ++u) h1[4 * g + u] = ftanh_scaled(SP == 2 ? a1[g][0][u] + a1[g][SP - 1][u] : a1[g][0][u]);
     }
     {
         cm_f32x4 a2[GH * SP];
@@ -272,7 +295,7 @@ __device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const
 #pragma unroll
         for (int g = 0; g < GH; ++g)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) h2[4 * g + u] = ftanh(SP == 2 ? a2[g * SP][u] + a2[g * SP + 1][u] : a2[g][u]);
+            for (int u = 0; u < 4; ++u) h2[4 * g + u] = ftanh_scaled(SP == 2 ? a2[g * SP][u] + a2[g * SP + 1][u] : a2[g][u]);
     }
     {
         cm_f32x4 t[G2];
@@ -293,20 +316,20 @@ __device__ __forceinline__ void cond_backward_mfma(const float* pan, int lane, c
                                                    const float (&h1)[H], const float (&h2)[H],
                                                    float (&ga2)[H], float (&ga1)[H]) {
     using CP = CondPanel<K, H>;
-    constexpr int PoP = CP::PoP, GH = CP::GH, SP = (H >= 8) ? 2 : 1;
+    constexpr int PoP = CP::PoP, GH = CP::GH, SP = (H >= 8) ? NSF_COND_SPLIT : 1;
     const int r = lane & 3;
     const cm_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
-        cm_f32x4 s[GH * 2];
+        cm_f32x4 s[GH * SP];
 #pragma unroll
-        for (int g = 0; g < GH * 2; ++g) s[g] = zero;
-        mfma_rows<GH, PoP, GH, 2, ThetaColUsed<K, H>>(pan + CP::oW2N + r * CP::NS2, CP::NS2, s, gth);
+        for (int g = 0; g < GH * SP; ++g) s[g] = zero;
+        mfma_rows<GH, PoP, GH, SP, ThetaColUsed<K, H>>(pan + CP::oW2N + r * CP::NS2, CP::NS2, s, gth);
 #pragma unroll
         for (int g = 0; g < GH; ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float h = h2[4 * g + u];
-                ga2[4 * g + u] = (s[2 * g][u] + s[2 * g + 1][u]) * (1.0f - h * h);
+                ga2[4 * g + u] = (SP == 2 ? s[SP * g][u] + s[SP * g + SP - 1][u] : s[g][u]) * (1.0f - h * h);
             }
     }
     {

@@ -748,5 +748,6 @@ def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels():
             res[mode] = ([m.cpu().numpy() for m in tb.m], [float(l[0]) for l in tb.iter_loss])
             tb.close()
     for c, (a, b) in enumerate(zip(res["0"][0], res[None][0])):
-        assert np.abs(a - b).max() < 2e-5 * max(1e-3, np.abs(a).max()), (c, np.abs(a - b).max(), np.abs(a).max())
+        # (the dim-major kernel stages W0 / W1 pre-multiplied by 2 log2(e) for its tanh: products rounded once more)
+        assert np.abs(a - b).max() < 5e-5 * max(1e-3, np.abs(a).max()), (c, np.abs(a - b).max(), np.abs(a).max())
     np.testing.assert_allclose(res["0"][1], res[None][1], rtol=2e-6, atol=1e-5)

@@ -124,13 +124,17 @@ class ReplicaNFiSAM:
         R = len(self.solvers)
         timers = timers if timers is not None else [[] for _ in range(R)]
         gens = []
+        prof = self.__dict__.setdefault("profile", {"graphs": 0.0, "simulate+prepare": 0.0, "train": 0.0, "posterior": 0.0})
+        t_ph = time.time()
         for r in range(R):
             with self.turn(r) as s:
                 s.update_physical_and_working_graphs(timer=timers[r])
                 gens.append(s.fit_tree_steps(timer=timers[r]))
         live = list(range(R))
         self.last_batches = []
+        prof["graphs"] += time.time() - t_ph
         while live:
+            t_ph = time.time()
             preps, still = [], []
             for r in live:
                 with self.turn(r):
@@ -140,6 +144,8 @@ class ReplicaNFiSAM:
                     except StopIteration:
                         pass
             live = still
+            torch.cuda.synchronize()
+            prof["simulate+prepare"] += time.time() - t_ph
             if preps:
                 t0 = time.time()
                 self.solvers[0].train_prepared(preps)   # ONE batched launch sequence for the pending cliques
@@ -148,6 +154,8 @@ class ReplicaNFiSAM:
                 for r in live:
                     timers[r].append(dt / len(preps))   # the reference's per-clique training timer: this replica's share
                 self.last_batches.append(len(preps))
+                prof["train"] += dt
+        t_ph = time.time()
         # posterior walks: every replica's tree walk (a few waves, strictly sequential inside) is enqueued on its own stream,
         # so the R walks run side by side; then one D2H copy each
         if len(self._streams) < R:
@@ -163,4 +171,5 @@ class ReplicaNFiSAM:
             s = self.solvers[r]
             s._samples = s.posterior_collect(handles[r], timer=timers[r])
             out.append(s._samples)
+        prof["posterior"] += time.time() - t_ph
         return out

@@ -66,6 +66,21 @@ class Variable(object):
     def R_dim_indices(self):
         return list(range(self.dim))[self.translational_dim:]
 
+    @staticmethod
+    def file2vars(order_file: str, pose_space: str = "SE2") -> List["Variable"]:
+        """Variables named in an ordering file (`step{i}_ordering` of a run folder: whitespace-separated names): names
+        starting with 'L' are R2 landmarks, the others poses in `pose_space` ("SE2" or "R2"); reference Variables.py:142-154."""
+        with open(order_file) as f:
+            names = f.read().split()
+        make_pose = {"SE2": SE2Variable, "R2": R2Variable}.get(pose_space)
+        out = []
+        for name in names:
+            if name.startswith("L"):
+                out.append(R2Variable(name=name, variable_type=VariableType.Landmark))
+            elif make_pose is not None:                       # (an unknown pose space yields landmarks only, as the reference)
+                out.append(make_pose(name=name, variable_type=VariableType.Pose))
+        return out
+
     def __copy__(self) -> "Variable":
         return Variable(name=self._name, dim=self._dim)
 

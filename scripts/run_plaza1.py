@@ -48,7 +48,7 @@ if replicas > 1:
     w = np.array(walls)
     summary = dict(replicas=replicas, updates=len(walls), total_s=total, wall_per_update_all_replicas_median=float(np.median(w)),
                    wall_per_replica_update_mean=float(w.mean() / replicas), wall_per_replica_update_median=float(np.median(w) / replicas),
-                   training_sample_iters=float(2000 * fit_iters), final_rmse=rm)
+                   training_sample_iters=float(2000 * fit_iters), final_rmse=rm, seconds_by_phase=getattr(rep, 'profile', None))
     print(json.dumps(summary))
     if out_json:
         json.dump(dict(summary=summary, walls=walls), open(out_json, "w"))

@@ -196,6 +196,42 @@ def test_separator_forward_and_log_pdf_match_oracle_marginal_flow():
     assert np.quantile(err, 0.95) < 2e-3 * max(1.0, np.abs(gref).max()), np.quantile(err, 0.95)
 
 
+def test_unif_to_sample_is_the_conditional_inverse_of_the_normal_quantiles():
+    """`FlowsPriorFactor.unif_to_sample` (nested-sampling prior transform, src/slam/NFiSAM.py:290-303): u in (0,1)^d ->
+    z = Phi^-1(u) -> conditional inverse given the true observation, un-normalised.  Oracle: the float64 C oracle's inverse
+    of the same flow on the normalised observation, un-normalised (and angle-wrapped) by hand; with and without observation."""
+    import scipy.stats
+    from flows.flows import NSF_AR
+    from flows.prior_dist import CustomMultivariateNormal
+    from slam.NFiSAM import FlowsPriorFactor, NormalizingFlowModelWithSeparator
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    rng = np.random.RandomState(9)
+    for n_obs in (1, 0):
+        D, sep_dim = n_obs + 5 + 3, 5                     # columns [obs | L0 xy | X0 x y th | X1 x y th]
+        blob = BM.init_blob_np(D, K, H, 1, 5) + 0.2 * rng.randn(O.param_count(D, K, H)).astype(np.float32)
+        circ = [False] * n_obs + [False, False, False, False, True, False, False, True]
+        mean = (rng.randn(D) * 3).astype(np.float32); std = (0.5 + rng.rand(D)).astype(np.float32)
+        flow = NSF_AR.from_kernel_params(D, K, B, H, nh.pack(dev(blob), D, K, H, 1))
+        Ds = n_obs + sep_dim
+        model = NormalizingFlowModelWithSeparator([flow], CustomMultivariateNormal(dim=D, device=DEV),
+                                                  CustomMultivariateNormal(dim=Ds, device=DEV), circ, torch.tensor(mean),
+                                                  torch.tensor(std))
+        true_obs = np.array([mean[0] + 0.3 * std[0]], dtype=np.float64)[:n_obs]
+        fac = FlowsPriorFactor([R2Variable("L0", VariableType.Landmark), SE2Variable("X0")], model, true_obs, circ[n_obs:Ds])
+        for _ in range(4):
+            u = rng.uniform(0.05, 0.95, size=sep_dim)
+            got = np.asarray(fac.unif_to_sample(u), dtype=np.float64)
+            assert got.shape == (sep_dim,)
+            z = scipy.stats.norm.ppf(u)[None, :]
+            obs_n = ((true_obs - mean[:n_obs]) / std[:n_obs])[None, :]
+            Pt = O.param_count(Ds, K, H)
+            xn = CO.inverse(z, obs_n if n_obs else None, blob[:Pt], K, H, B, 1, dtype=np.float64)[0][0]
+            ref = xn * std[n_obs:Ds] + mean[n_obs:Ds]
+            cm = np.array(circ[n_obs:Ds])
+            ref[cm] = (ref[cm] + np.pi) % (2 * np.pi) - np.pi
+            np.testing.assert_allclose(got, ref, atol=2e-3)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # config[3] / config[4] end to end: first updates through NFiSAM_empirial_study
 # ---------------------------------------------------------------------------------------------------------

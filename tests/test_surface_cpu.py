@@ -96,3 +96,46 @@ def test_searchsorted_matches_reference_golden():
     idx = searchsorted(bins, torch.tensor(g["ss_q"]))
     np.testing.assert_array_equal(idx.numpy(), g["ss_idx"])
     np.testing.assert_array_equal(bins.numpy(), g["ss_bins_after"])     # in-place eps bump, like the reference
+
+
+def test_file2vars_reads_an_ordering_file(tmp_path):
+    """`Variable.file2vars` (reference src/slam/Variables.py:142-154): names from a run folder's ordering file; 'L...' are R2
+    landmarks, the rest poses of the requested space."""
+    from slam.Variables import R2Variable, SE2Variable, Variable, VariableType
+    p = tmp_path / "step3_ordering"
+    p.write_text("X0 X1 L1 X2 L2")
+    vs = Variable.file2vars(str(p))
+    assert [v.name for v in vs] == ["X0", "X1", "L1", "X2", "L2"]
+    assert [type(v) for v in vs] == [SE2Variable, SE2Variable, R2Variable, SE2Variable, R2Variable]
+    assert [v.type for v in vs] == [VariableType.Pose, VariableType.Pose, VariableType.Landmark, VariableType.Pose, VariableType.Landmark]
+    assert [v.dim for v in Variable.file2vars(str(p), pose_space="R2")] == [2, 2, 2, 2, 2]
+    single = tmp_path / "one"
+    single.write_text("X7\n")
+    assert [v.name for v in Variable.file2vars(str(single))] == ["X7"]
+
+
+def test_multivariate_normal_vonmises_prior():
+    """`flows.prior_dist.MultivariateNormalVonmises` (reference prior_dist.py:29-70): independent columns, N(0,1) for
+    Euclidean and VonMises(0, 1) for circular ones; log_prob = sum of the column log densities; sample shape / support."""
+    import torch
+    from flows.prior_dist import MultivariateNormalVonmises
+    circ = [False, True, False, True]
+    d = MultivariateNormalVonmises(circ)
+    assert d.dim == 4 and d.is_cpu()
+    torch.manual_seed(0)
+    x = d.sample((4000,))
+    assert tuple(x.shape) == (4000, 4)
+    assert float(x[:, 1].abs().max()) <= np.pi + 1e-6 and float(x[:, 3].abs().max()) <= np.pi + 1e-6
+    assert abs(float(x[:, 0].std()) - 1.0) < 0.05 and abs(float(x[:, 2].mean())) < 0.06
+    # circular variance of VonMises(kappa = 1): 1 - I1(1)/I0(1) = 0.5536
+    assert abs(1.0 - float(torch.cos(x[:, 1]).mean()) - 0.5536) < 0.03
+    lp = d.log_prob(x[:16])
+    ref = torch.zeros(16)
+    for c, is_c in enumerate(circ):
+        col = x[:16, c]
+        ref = ref + (torch.distributions.VonMises(torch.zeros(1), torch.ones(1)).log_prob(col) if is_c
+                     else torch.distributions.Normal(0.0, 1.0).log_prob(col))
+    np.testing.assert_allclose(lp.numpy(), ref.numpy(), atol=1e-5)
+    with pytest.raises(ValueError):
+        d.log_prob(x[:, :3])
+    assert d.to("cpu").dim == 4 and d.cpu().is_cpu()

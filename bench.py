@@ -453,36 +453,43 @@ def main():
             "final_loss": head["final_loss"], "first_loss": head["first_loss"],
             "roofline": {"bound": "valu_issue", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "nsf_train1_kernel<9,8,1>", "kernel_us": head["gradient_kernel_us"],
+                         "kernel": "nsf_train1_kernel<9,8>", "kernel_us": head["gradient_kernel_us"],
                          "flop_per_launch": head["flop_per_launch"],
+                         "launches_per_training_iteration": head["launches_per_training_iteration"],
+                         "achieved_in_training": head["flop_per_launch"] / (head["gpu_us_per_iteration_events"] * 1e-6) / 1e12,
                          "note": "fp32 INSTRUCTION-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, HBM does not bind), priced "
                                  "against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  Per (dim, 64-particle "
-                                 "tile) unit a wave issues ~1.9k VALU instructions (spline, tanh, operand staging), 164 "
-                                 "v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane) and 64 v_mfma_f32_16x16x4 (the "
-                                 "weight-gradient GEMMs); on gfx950 MFMA and VALU issue of a SIMD do not overlap (measured: "
-                                 "profiles/r02_mfma_valu_issue_microbench.txt), so their times add.  333 MFLOP per launch = "
-                                 "2.1 us at peak: the C3 launch is 2496 waves of ONE unit each at 2.4 waves per SIMD, i.e. one "
-                                 "dependent instruction stream per wave - latency-bound by construction; "
-                                 "`regimes.batch64_n2000_D15` is the throughput regime.  `kernel_us` times the gradient launch "
-                                 "alone; in a training iteration the same kernel also applies the previous iteration's Adam "
-                                 "update on its way into LDS (no separate Adam launch: `ms_per_step`).  Algorithmic HBM bytes "
-                                 "per launch: 608 KB (x) + 112 KB (parameters); `traffic` is null because it is not measured in "
-                                 "this run (PMC passes: profiles/, see `traffic_profiled`)."},
+                                 "tile) unit a wave issues ~560 VALU instructions (~450 of them the spline, 64 transcendentals), "
+                                 "164 v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane), 48-64 v_mfma_f32_16x16x4 "
+                                 "(the weight-gradient GEMMs) and ~220 LDS instructions; on gfx950 f32 MFMA and VALU issue of a "
+                                 "SIMD do not overlap (profiles/r02_mfma_valu_issue_microbench.txt), so their times add, and under "
+                                 "load a VALU instruction costs ~2.9 cycles of the port (profiles/r03_phase_cycles_stamps3.txt): "
+                                 "the 64-clique batch (`regimes.batch64_n2000_D15`, the throughput regime) runs at ~95 % of what "
+                                 "this instruction mix allows (DESIGN.md §3.1c).  333 MFLOP per launch = 2.1 us at peak: the C3 "
+                                 "launch is 3072 waves of ONE unit each at 3 waves per SIMD, i.e. a third of it is prologue / "
+                                 "epilogue latency (memory round trips, one barrier).  `kernel_us` times the gradient kernel as "
+                                 "ONE launch over all (clique, dim) groups, back to back in a graph; a training plan issues it as "
+                                 "`launches_per_training_iteration` concurrent launches over disjoint groups (parallel graph "
+                                 "branches) and the same kernel also applies the previous iteration's Adam update on its way into "
+                                 "LDS (no separate Adam launch): `achieved_in_training` = flop_per_launch / GPU time per training "
+                                 "iteration of the timed region.  Algorithmic HBM bytes per launch: 608 KB (x) + 112 KB "
+                                 "(parameters); `traffic` is null because it is not measured in this run (PMC passes: profiles/, "
+                                 "see `traffic_profiled`)."},
             "regimes": regimes,
         }
-        tj = os.path.join(ROOT, "profiles", "r02_train_kernel_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r03_train_kernel_traffic.json")
         if os.path.exists(tj):   # HBM bytes per launch from separate rocprofv3 --pmc passes of an EARLIER run of this workload
             try:
-                out["roofline"]["traffic_profiled"] = dict(json.load(open(tj)), source="profiles/r02_train_kernel_traffic.json")
+                out["roofline"]["traffic_profiled"] = dict(json.load(open(tj)), source="profiles/r03_train_kernel_traffic.json")
             except Exception:   # noqa: BLE001
                 pass
-        uj = os.path.join(ROOT, "profiles", "r02_issue_utilisation.json")
+        uj = os.path.join(ROOT, "profiles", "r03_issue_utilisation.json")
         if os.path.exists(uj):   # VALU issue / MFMA busy fractions from the same EARLIER profiled run (not measured here)
             try:
                 u = json.load(open(uj))
                 out["roofline"]["issue_profiled"] = {k: {f: u[k][f] for f in ("valu_issue_frac", "mfma_busy_frac", "issue_frac")}
                                                      for k in ("C3", "batch64")}
-                out["roofline"]["issue_profiled"]["source"] = "profiles/r02_issue_utilisation.json"
+                out["roofline"]["issue_profiled"]["source"] = "profiles/r03_issue_utilisation.json"
             except Exception:   # noqa: BLE001
                 pass
         if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only

@@ -196,7 +196,8 @@ int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int 
                         float* gx, float* loss_sum, nfisam_stream_t stream);
 
 /* Device-resident control block of one clique's training run. */
-typedef struct nfisam_train_state {      /* 32 bytes since ABI 1200 (the unused loss_acc / loss_slots[64] of ABI 1100 are gone) */
+typedef struct nfisam_train_state {      /* 32 bytes since ABI 1200 (the unused loss_acc / loss_slots[64] of ABI 1100 are gone);
+                                          * ABI 1300: reserved[0] of a plan's host mirror counts the chunks closed in the current run */
     int32_t step;        /* iterations completed and recorded so far (advances when a chunk is closed) */
     int32_t stop;        /* set by the device when the early-stop rule fired                 */
     int32_t have_avg;    /* a previous window mean exists                                    */

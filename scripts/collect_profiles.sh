@@ -1,13 +1,20 @@
 #!/bin/bash
-# Round-2 profile collection on the gpurun MI355X box: kernel-trace stats and PMC passes (each in its own run, never
+# Profile collection on the gpurun MI355X box (profiles/rNN_*): kernel-trace stats and PMC passes (each in its own run, never
 # combined with tracing) of the bench.py headline workload (C3) and of the 64-clique throughput batch.
 # usage: scripts/collect_profiles.sh <out dir under gpurun_out>
 out=$GRAFT_REPO_ROOT/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-update-bench"
+# counters and per-kernel durations are per LAUNCH: the profiled runs issue every iteration as ONE launch (a plan would
+# split big batches into two concurrent launches over disjoint (clique, dim) groups, nfisam_nsf_train_chains); the
+# `*_chains_*` trace keeps the default so that the concurrent launches show up as they run in training
+export NFISAM_CHAINS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_trace -- $B --no-regimes > $out/c3_bench_line.json 2> $out/c3_trace.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/all_trace -- $B > $out/all_bench_line.json 2> $out/all_trace.err
+unset NFISAM_CHAINS
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_chains_trace -- $B --no-regimes > $out/c3_chains_bench_line.json 2> $out/c3_chains_trace.err
+export NFISAM_CHAINS=1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_SCA" \
@@ -41,9 +48,9 @@ def summarize(prefix):
 c3 = summarize("c3")
 b64 = summarize("b64")
 json.dump(dict(c3=c3, b64=b64), open(out + "/pmc_means.json", "w"), indent=1)
-for pre in ("c3_trace", "all_trace"):
+for pre in ("c3_trace", "all_trace", "c3_chains_trace"):
     for f in glob.glob(out + "/%s/*/*kernel_stats.csv" % pre):
         os.system("cp %s %s/%s_kernel_stats.csv" % (f, out, pre))
-os.system("rm -rf %s/*_pmc[0-9] %s/c3_trace %s/all_trace" % (out, out, out))
+os.system("rm -rf %s/*_pmc[0-9] %s/c3_trace %s/all_trace %s/c3_chains_trace" % (out, out, out, out))
 PY
 ls -la $out

@@ -15,7 +15,10 @@ def kernel_of(d):
 out = {"_formulas": {
     "kernel_cycles": "SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines' busy cycles)",
     "valu_issue_frac": "2 * SQ_ACTIVE_INST_VALU / (kernel_cycles * 1024 SIMDs): the counter advances 1 per plain VALU instruction "
-                       "and 2 per transcendental (scripts/exp/valu_rate.hip), a plain fp32 VALU instruction occupies the issue port 2 cycles",
+                       "and 2 per transcendental (scripts/exp/valu_rate.hip); 2 cycles per plain fp32 VALU instruction is the BEST case "
+                       "of the issue port -- under load the kernel's phases measure ~2.9 cycles per instruction (scripts/stamps3.py, "
+                       "DESIGN.md 3.1b), so this fraction understates how busy the port is",
+    "instruction_counts": "SQ_INSTS_VALU includes the MFMA instructions (static count of the tile loop: ~560 VALU + 212 MFMA per unit)",
     "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024)",
     "issue_frac": "valu_issue_frac + mfma_busy_frac (MFMA and VALU issue of a SIMD do not overlap: profiles/r02_mfma_valu_issue_microbench.txt)",
     "scalar_cache_hit_rate": "SQC_DCACHE_HITS / (SQC_DCACHE_HITS + SQC_DCACHE_MISSES)"}}
@@ -25,7 +28,7 @@ for name, key in (("C3", "c3"), ("batch64", "b64")):
     valu = 2.0 * k["SQ_ACTIVE_INST_VALU"] / (cyc * SIMDS)
     mfma = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS)
     out[name] = {
-        "kernel": "nsf_train1_kernel<9,8,1>", "kernel_cycles": cyc, "waves_launched": k["SQ_WAVES"],
+        "kernel": "nsf_train1_kernel<9,8>", "kernel_cycles": cyc, "waves_launched": k["SQ_WAVES"],
         "valu_instructions": k["SQ_INSTS_VALU"], "mfma_instructions": k["SQ_INSTS_MFMA"], "lds_instructions": k["SQ_INSTS_LDS"],
         "salu_instructions": k["SQ_INSTS_SALU"], "smem_instructions": k["SQ_INSTS_SMEM"],
         "valu_issue_frac": valu, "mfma_busy_frac": mfma, "issue_frac": valu + mfma,
@@ -45,9 +48,9 @@ copies = 8
 grad_bytes = copies * sum(Pc) * 4
 state_bytes = 3 * sum(Pc) * 4
 traffic = {
-    "kernel": "nsf_train1_kernel<9,8,1>", "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
+    "kernel": "nsf_train1_kernel<9,8>", "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
               "(the launch also applies the previous iteration's Adam update)",
-    "launches_averaged": 970,
+    "launches_averaged": int(k.get("_n", 0)) or None,
     "FETCH_SIZE_KB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KB_raw": k["WRITE_SIZE"],
     "hbm_side_bytes_per_launch_lower": int(1024 * (k["FETCH_SIZE"] + k["WRITE_SIZE"])),
     "hbm_side_bytes_per_launch_upper": int(1024 * (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"])),
@@ -55,15 +58,15 @@ traffic = {
     "bytes_the_launch_must_move": {"gradient_copies_written": grad_bytes, "adam_state_written": state_bytes,
                                    "gradient_copies_and_state_read_per_dim_block": "8 blocks per (clique, dim) each read the 8 "
                                    "copies + theta, m, v of the dim: %d B in total, L2 / Infinity-Cache hits after the first block" % (8 * (grad_bytes + state_bytes))},
-    "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (scripts/collect_profiles.sh), means over the 970 "
-            "launches of the run.  The counters sit at the L2-fabric boundary and include Infinity-Cache hits.  FETCH_SIZE counts "
+    "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (scripts/collect_profiles.sh), means over the "
+            "launches of the run (training iterations issued as ONE launch each: NFISAM_CHAINS=1).  The counters sit at the L2-fabric boundary and include Infinity-Cache hits.  FETCH_SIZE counts "
             "64 B per 128-B request for wide streaming reads on gfx950 (MI355X_MICROARCH.md), i.e. up to x2 (both bounds given).  "
             "WRITE_SIZE: one gradient copy per BLOCK (8 per clique, %.2f MB) on every launch + the new theta/m/v (%.2f MB) on the "
-            "training launches that carry a pending Adam update (about half of the 970: the kernel-timing loop launches the "
+            "training launches that carry a pending Adam update (most of them: the kernel-timing loop launches the "
             "gradient alone): %.2f MB counted.  (With 8 VGPRs spilled the same counter read 6.2 MB: 2 KB of scratch per wave.)  "
             "FETCH_SIZE is dominated by the fused update: the 8 blocks of a (clique, dim) each read its 8 copies + theta, m, v "
             "(L2 / Infinity-Cache hits after the first).  At ~300 GB/s of fabric traffic the kernel is nowhere near the HBM "
-            "roofline; the figure that matters is the issue utilisation (r02_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, k["WRITE_SIZE"] * 1024 / 1e6),
+            "roofline; the figure that matters is the issue utilisation (*_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, k["WRITE_SIZE"] * 1024 / 1e6),
 }
 traffic["ratio_to_algorithmic"] = [traffic["hbm_side_bytes_per_launch_lower"] / alg, traffic["hbm_side_bytes_per_launch_upper"] / alg]
 json.dump(traffic, open(dst + "_train_kernel_traffic.json", "w"), indent=1)

@@ -796,7 +796,11 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         // be split into n launches that form n PARALLEL branches of the graph: the branches drift apart, and one
         // branch's kernel prologue / tail (memory round trips, a barrier, nothing to issue) runs under another's
         // arithmetic.  Pays in the latency regime (few waves per SIMD); NFISAM_CHAINS=n, default by launch size.
-        const int chains = plan_chains(n_cliques, p->max_n, p->max_D, K, H, L);
+        // (a plan that is ONE short chunk keeps one launch per iteration: the two-branch graph costs ~12 us more to launch,
+        //  which 20 iterations do not earn back -- C3, 20 iterations: 18.2 vs 18.8 us per iteration; with several chunks the
+        //  launch of chunk k + 1 hides behind chunk k and two branches win from 20 iterations per chunk up: 15.2 -> 14.5)
+        const bool one_short_chunk = cfg->max_iters <= p->chunk && p->chunk < 40 && getenv("NFISAM_CHAINS") == nullptr;
+        const int chains = one_short_chunk ? 1 : plan_chains(n_cliques, p->max_n, p->max_D, K, H, L);
         for (int g = 1; g < chains && e == hipSuccess; ++g) {
             hipStream_t st = nullptr;
             hipEvent_t ev2 = nullptr;

@@ -68,6 +68,7 @@ struct TrainArgs {
     int groups;                     // nsf_train1_kernel: (clique, dim) groups = cliques x largest D (grid = 8 x blocks per group x groups / 8)
     unsigned magic_cliques;         // nsf_train1_kernel: ceil(2^32 / cliques) (0: one clique): group / cliques without a division
     int t_shift, w_shift;           // nsf_train1_kernel: log2 of tiles per wave / waves per block
+    int pair_dims;                  // nsf_train2_kernel: waves that share a SIMD take the cheapest dims (see the kernel)
     int chain, n_chains;            // nsf_train1_kernel: this launch covers the (clique, dim) groups g with (g / 8) % n_chains == chain
     const uint32_t* panel_map;      // nsf_train1_kernel: kernel-layout parameter index -> LDS word(s) of the conditioner panel (nsf_cond_mfma.h)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)

@@ -1106,6 +1106,12 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
     const int W = blockDim.x >> 6;
     const int dim_lo = blockIdx.z * W;
     const int dim_step = (gridDim.z > 1) ? D : W;
+    // Which dim a wave takes.  A workgroup's waves go to the four SIMDs cyclically, so waves w and w + 4 share one; with
+    // 5..8 waves the SIMDs that host two of them set the pace of every layer (55 % of the wave-cycles of C2 were barrier
+    // waits).  Units get dearer with the dim (layer 0 contracts i inputs, dL/dx has i outputs) and dim 0 has no
+    // conditioner at all, so the PAIRED waves take the cheapest dims and the waves that own a SIMD the dearest:
+    // rank of wave w in the order (0, 4, 1, 5, 2, 6, 3, 7).  NFISAM_DIM_PAIRING=0 in the launcher keeps w.
+    const int wdim = (a.pair_dims != 0 && W > 4 && W <= 8) ? (w < 4 ? w + (w < W - 4 ? w : W - 4) : 2 * (w - 4) + 1) : w;
     if (dim_lo >= D) return;
     const int gp = p0 + p;
     const bool valid = gp < n;
@@ -1186,7 +1192,7 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
         const float* lp = kp + (size_t)l * Pk;
         const float* xin = xs + l * DT;
         float* xout = xs + (l + 1) * DT;
-        for (int i = dim_lo + w; i < D; i += dim_step) {
+        for (int i = dim_lo + wdim; i < D; i += dim_step) {
             float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP];
             load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
             Spline2<K> S;
@@ -1214,7 +1220,7 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
             for (int e = threadIdx.x; e < DT; e += blockDim.x) gprev[e] = 0.0f;
             __syncthreads();
         }
-        for (int i = dim_lo + w; i < D; i += dim_step) {
+        for (int i = dim_lo + wdim; i < D; i += dim_step) {
             float h1m[HH], h1o[HH], h2m[HH], h2o[HH], th[HP], gth[HP];
             STAMP(2);
             load_theta2<K, H>(lp, i, xin, p, hf, h1m, h1o, h2m, h2o, th);
@@ -1952,6 +1958,10 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if (independent_dims && tiles * max_D <= 2048) { W = 1; groups = max_D; }
         else if (independent_dims && tiles * W <= 4096) groups = (max_D + W - 1) / W;
         a.g_tiles = independent_dims ? 0 : 1;
+        {
+            const char* pe = getenv("NFISAM_DIM_PAIRING");
+            a.pair_dims = (pe != nullptr && pe[0] == '0') ? 0 : 1;
+        }
         const size_t tile_floats = (((size_t)a.L + 2 * a.g_tiles) * max_D + 1 + (size_t)W * StgRows<KK, HH>::split) * XS2;
         const size_t wfloats = block_weight_floats<KK, HH>(a, max_D, W, groups);
         // the lanes of a pair read different weight rows: LDS copy whenever it fits, global loads otherwise

@@ -1,0 +1,15 @@
+"""One-off (GPU): cProfile of eight Plaza1 replicas in lock-step (first 40 updates)."""
+import cProfile, pstats, os, sys, io
+__file__ = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scripts", "run_plaza1.py")
+sys.argv = ["run_plaza1.py", "40"]
+os.environ["REPLICAS"] = "8"; os.environ["EVERY"] = "1000"
+pr = cProfile.Profile()
+pr.enable()
+try:
+    exec(compile(open(__file__).read(), __file__, "exec"))
+except SystemExit:
+    pass
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[:9000])

@@ -612,6 +612,41 @@ def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, 
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [[(2000, 15)], [(1900, 12), (300, 17), (700, 9)]], ids=["one-clique", "batch"])
+def test_chunks_enqueued_ahead_of_an_early_stop_change_nothing(shape):
+    """Training plans enqueue chunk k + 1 before the host has seen the outcome of chunk k (the states arrive in pinned host
+    memory; the stop flags are checked on the device).  With an early stop the chunk behind it must be a no-op: same stop
+    iteration, parameters, moments and loss record as launch - wait - launch (`NFISAM_RUN_AHEAD=0`); and the plan must be
+    re-usable right away (the next run drains what is still in flight before it restarts the chunk sequence)."""
+    K, H, B = 9, 8, 5.0
+    probs = [make_problem(n, D, K, H, 1, seed=700 + c) for c, (n, D) in enumerate(shape)]
+
+    def run(ahead):
+        with _Env(NFISAM_RUN_AHEAD=ahead):
+            tb = nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H) for (b, _), (_, D) in zip(probs, shape)], K, H, B, 1,
+                               lr=0.01, max_iters=600, average_window=50, loss_delta_tol=0.05, early_stop=True)
+            first = tb.run(use_graph=True)
+            torch.cuda.synchronize()
+            snap = [[t.cpu().numpy().copy() for t in arr] for arr in (tb.kparams, tb.m, tb.v, tb.iter_loss)]
+            tb.reset([kpack(b, D, K, H) for (b, _), (_, D) in zip(probs, shape)])       # while a chunk may still be draining
+            second = tb.run(use_graph=True)
+            torch.cuda.synchronize()
+            again = [t.cpu().numpy().copy() for t in tb.kparams]
+            tb.close()
+        return first, snap, second, again
+    f0, s0, r0, a0 = run("0")
+    f1, s1, r1, a1 = run(None)
+    assert f0 == f1 == r0 == r1 and all(100 <= i < 600 and i % 50 == 0 for i in f0), (f0, f1, r0, r1)   # stopped early
+    for a, b in zip(s0[:3], s1[:3]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    for x, y in zip(s0[3], s1[3]):
+        np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
+        assert np.all(x[f0[0]:] == 0) or len(shape) > 1
+    for x, y, z in zip(a0, a1, s1[0]):
+        assert np.array_equal(x, y) and np.array_equal(y, z)        # the re-run reproduces the first run
+
+
 def test_gradient_parts_cover_the_gradient_launch():
     """`nfisam_nsf_train_gradient_part`: the launches of a split iteration write exactly the gradient copies and loss sums
     of the single launch (disjoint (clique, dim) groups), in any order; a launch shape that is not split refuses parts."""

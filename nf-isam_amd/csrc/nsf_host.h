@@ -203,16 +203,17 @@ static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, in
     int T = 1;
     if (is_dim_major(n_cliques, max_n, max_D, L, tile, H)) {
         if (e != nullptr && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4 || atoi(e) == 8)) return atoi(e);
-        // One tile per wave while all waves are resident at once (3 per SIMD x 1024 SIMDs); beyond that a second, mostly
-        // empty round costs a whole unit, so waves take two tiles (and share one prologue: tile fetch, weight panel,
-        // pending Adam update), then four once even that launch is more than ~4k waves.  Measured on 7..64 cliques of
-        // n = 2000, D = 15 (scripts/time_grad.py with NFISAM_TILES_PER_BLOCK=1|2|4): 8 cliques 24.6 -> 22.2 us per
-        // iteration, 12: 33.2 -> 29.3, 16: 39.3 -> 36.6, 24: 56.1 -> 48.2 (T = 4), 64: T = 4 as before.
+        // One tile per wave while the launch is at most ~2 rounds of resident waves (3 per SIMD x 1024 SIMDs); beyond that
+        // waves take two tiles (and share one prologue: tile fetch, weight panel, pending Adam update), then four.
+        // Measured on 8..64 cliques of n = 2000, D = 15 with the iteration split over two parallel graph branches
+        // (scripts/time_grad.py, NFISAM_TILES_PER_BLOCK=1|2|4, us per iteration):
+        //   cliques   8      12     16     24     32     48     64
+        //   T = 1    16.8   21.5   28.5   41.9   55.0   82.2  109.4
+        //   T = 2    17.3   22.1   25.9   35.5   46.7   69.4   92.5
+        //   T = 4    25.9   27.3   29.1   36.7   44.6   61.9   81.6
+        // i.e. double T while the launch would exceed ~6k waves (8 tiles per wave only beyond 12k waves at T = 4).
         const auto waves = [&](int t) { return (long)n_cliques * ((tiles_c + t - 1) / t) * max_D; };
-        if (waves(1) > 3072) {
-            T = 2;
-            while (T < 8 && waves(T) > (T == 2 ? 4096 : 8192)) T *= 2;
-        }
+        while (T < 8 && waves(T) > (T < 4 ? 6144 : 12288)) T *= 2;
         return T;
     }
     if (tiles <= 256) return 1;                  // nsf_train_kernel spreads the dims over grid.z there: one tile per block

@@ -234,9 +234,12 @@ __device__ __forceinline__ void mfma_rows(const float* rows, int stride, cm_f32x
     }
 }
 
-// theta and the hidden activations of dim i for the lane's particle; xt = the wave's tile [rows][xs], rows 0..i loaded
+// theta and the hidden activations of dim i for the lane's particle; xt = the tile [rows][xs], rows 0..i loaded, the
+// lane's particle in column `col`; s0 = row stride of W0T (CondPanel::s0_of(i), or the pair kernel's clique-wide one).
+// `pan` may differ between lanes as long as the four lanes of an MFMA block agree (nsf_train3_kernel: two dims per wave;
+// `i` is then the larger of the two, the shorter dim's extra weights are zero).
 template <int K, int H>
-__device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const float* xt, int xs, int lane,
+__device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, int s0, const float* xt, int xs, int lane, int col,
                                                   float (&h1)[H], float (&h2)[H], float (&th)[Layout<K, H>::PoP]) {
     using CP = CondPanel<K, H>;
     constexpr int ST = CP::ST, GH = CP::GH, G2 = CP::G2, SP = (H >= 8) ? NSF_COND_SPLIT : 1;
@@ -250,13 +253,12 @@ __device__ __forceinline__ void cond_forward_mfma(const float* pan, int i, const
             a1[g][0] = *(const cm_f32x4*)(pan + CP::ob0 + 4 * g);
             if (SP == 2) a1[g][SP - 1] = zero;
         }
-        const int s0 = CP::s0_of(i);
         const float* w0 = pan + CP::oW0T + r * s0;
         for (int k0 = 0; k0 < i; k0 += 8) {
             float xk[8];
             cm_f32x4 a4[GH][2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int k = k0 + u; xk[u] = xt[(k < i ? k : i) * xs + lane]; }
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u; xk[u] = xt[(k < i ? k : i) * xs + col]; }
 #pragma unroll
             for (int g = 0; g < GH; ++g)
 #pragma unroll
@@ -344,5 +346,222 @@ __device__ __forceinline__ void cond_backward_mfma(const float* pan, int lane, c
                 const float h = h1[4 * g + u];
                 ga1[4 * g + u] = (SP == 2 ? t[g * SP][u] + t[g * SP + 1][u] : t[g][u]) * (1.0f - h * h);
             }
+    }
+}
+
+// =====================================================================================================================
+// Two dims per wave (nsf_train3_kernel: multi-layer flows and VJP launches in the latency regime).
+//
+// Lanes 0-31 of a wave run dim 2j, lanes 32-63 dim 2j+1 of the same 32 particles; the 4x4x1 MFMA blocks are four lanes
+// wide, so every block sits inside one dim and the only thing that differs between the halves is the panel a lane reads.
+// Panels are wave-private ((layer, dim) of the wave's own dims, all layers resident) with ONE row stride of W0T for the
+// whole clique (s0 = s0_of(D - 1): the layer-0 loop runs to the longer dim of the pair, the shorter one multiplies zeros)
+// and one more matrix for dL/dx of the layer input:
+//   W0N [4*ceil((D-1)/4)][ST]   W0N[k][j] = W0[k][j], zero rows for k >= i        backward, layer 0
+// Dim 0 has no conditioner (its PoP parameters ARE theta): its panel is all zeros with b2 = the parameters, so
+// theta = b2 + 0 * h2 exactly and db2 of the gradient GEMM is its gradient -- no second code path in the wave.
+template <int K, int H>
+struct PairPanel {
+    using CP = CondPanel<K, H>;
+    __host__ __device__ static constexpr int s0(int D) { return CP::s0_of(D > 1 ? D - 1 : 1); }
+    __host__ __device__ static constexpr int oW0N(int D) { return CP::oW0T + H * s0(D); }
+    __host__ __device__ static constexpr int rowsN(int D) { return (D - 1 + 3) & ~3; }
+    __host__ __device__ static constexpr int dump(int D) { return oW0N(D) + rowsN(D) * CP::ST; }   // second store of one-destination parameters
+    __host__ __device__ static constexpr int floats(int D) { return dump(D) + 4; }
+};
+constexpr int PAIR_MAX_D = 16;              // one 16-column operand tile for [x | 1] in the dW0 GEMM
+constexpr int PAIR_MAP_HEAD = 32;           // the table starts with the word offsets of the maps of D = 0 .. 31
+// PairPanel<K, H>::floats(D) for run-time K, H (the Adam kernel of the common unit addresses the panel image with it)
+__host__ __device__ constexpr int pair_panel_floats(int K, int H, int D) {
+    const int PoP = pop_of(K), ST = H | 4;
+    const int oW0T = PoP * ST + PoP + H * ST + H + H * (PoP + 4) + H * ST + H;
+    const int s0 = (((D > 1 ? D - 1 : 1) + 7) & ~7) + 4;
+    return oW0T + H * s0 + ((D - 1 + 3) & ~3) * ST + 4;
+}
+static_assert(pair_panel_floats(9, 8, 6) == PairPanel<9, 8>::floats(6) && pair_panel_floats(5, 4, 11) == PairPanel<5, 4>::floats(11) &&
+                  pair_panel_floats(16, 8, 16) == PairPanel<16, 8>::floats(16),
+              "run-time restatement of PairPanel::floats");
+
+// table[D] = offset of clique width D's map; map[jj] for the kernel-layout index jj of ONE layer (same packing as
+// build_panel_map; offsets counted from the first word of the LAYER's panels: dim i's panel starts i * floats(D) in).
+// The same layout exists in device memory ("panel image", behind the loss ring of the clique's workspace): the Adam
+// kernel writes every updated parameter to its one or two places there, and the training kernel's prologue becomes a
+// straight 16-byte copy instead of ~15 instructions per parameter in every one of the clique's blocks.
+template <int K, int H>
+static inline size_t pair_map_words() {
+    size_t n = PAIR_MAP_HEAD;
+    for (int D = 1; D <= PAIR_MAX_D; ++D) n += Layout<K, H>::count(D);
+    return n;
+}
+template <int K, int H>
+static inline void build_pair_map(uint32_t* table) {
+    using CP = CondPanel<K, H>;
+    using PP = PairPanel<K, H>;
+    using LY = Layout<K, H>;
+    constexpr int PoP = CP::PoP, ST = CP::ST;
+    size_t at = PAIR_MAP_HEAD;
+    for (int D = 0; D < PAIR_MAP_HEAD; ++D) table[D] = 0;
+    for (int D = 1; D <= PAIR_MAX_D; ++D) {
+        table[D] = (uint32_t)at;
+        uint32_t* map = table + at;
+        at += LY::count(D);
+        const int s0 = PP::s0(D), dump0 = PP::dump(D), PS = PP::floats(D);
+        for (int j = 0; j < PoP; ++j) map[j] = (uint32_t)(CP::ob2 + j) | ((uint32_t)dump0 << 16);
+        for (int i = 1; i < D; ++i) {
+            uint32_t* m = map + LY::off(i);
+            const int dump = i * PS + dump0;
+            for (int jj = 0; jj < LY::block(i); ++jj) {
+                int d0 = 0, d1 = dump0;
+                if (jj < LY::ob0(i)) {
+                    const int k = jj / H, j = jj - k * H;
+                    d0 = CP::oW0T + j * s0 + k;
+                    d1 = PP::oW0N(D) + k * ST + j;
+                } else if (jj < LY::oW1(i)) {
+                    d0 = CP::ob0 + (jj - LY::ob0(i));
+                } else if (jj < LY::ob1(i)) {
+                    const int e = jj - LY::oW1(i), k = e / H, j = e - k * H;
+                    d0 = CP::oW1T + j * ST + k;
+                    d1 = CP::oW1N + k * ST + j;
+                } else if (jj < LY::oW2(i)) {
+                    d0 = CP::ob1 + (jj - LY::ob1(i));
+                } else if (jj < LY::ob2(i)) {
+                    const int e = jj - LY::oW2(i), k = e / PoP, o = e - k * PoP;
+                    d0 = CP::oW2T + o * ST + k;
+                    d1 = CP::oW2N + k * CP::NS2 + o;
+                } else {
+                    d0 = CP::ob2 + (jj - LY::ob2(i));
+                }
+                const bool scaled = jj < LY::oW2(i);
+                (void)dump;
+                m[jj] = (uint32_t)(i * PS + d0) | (scaled ? PANEL_SCALED : 0u) | ((uint32_t)(i * PS + d1) << 16);
+            }
+        }
+    }
+}
+
+// One wave brings the panels of the dims iA = 2j and (if nd == 2) iA + 1, all L layers, into LDS: zero fill, then the
+// parameters through the map.  The map words of a chunk are loaded once and serve every layer; the loads of both dims and
+// up to four layers are in flight together (one memory round trip for a pair of D <= 8).
+// lay0 = the panels of layer 0 (dim 0's first); PS = floats per panel; pstride = floats between consecutive layers.
+template <int K, int H>
+__device__ __forceinline__ void stage_pair_panels(float* lay0, int PS, size_t pstride, const float* theta_generic, size_t layer_stride,
+                                                  const uint32_t* map_generic, int iA, int nd, int L, int lane) {
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    int j0[2], nj[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int i = iA + (hb < nd ? hb : 0);
+        j0[hb] = (i == 0) ? 0 : LY::off(i);
+        nj[hb] = (i == 0) ? LY::PoP : LY::block(i);
+    }
+    const int njmax = nj[nd - 1] > nj[0] ? nj[nd - 1] : nj[0];
+    gp t0 = (gp)theta_generic;
+    gu map = (gu)map_generic;
+    constexpr int U = 8, LB = 4;
+    for (int lb = 0; lb < L; lb += LB) {
+        for (int base = 0; base < njmax; base += 64 * U) {
+            uint32_t d[2][U];
+            float t[2][LB][U];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = base + 64 * u + lane;
+                    d[hb][u] = map[j0[hb] + (jj < nj[hb] ? jj : 0)];
+                }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const int l = (lb + q < L) ? lb + q : L - 1;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int jj = base + 64 * u + lane;
+                        t[hb][q][u] = t0[(size_t)l * layer_stride + j0[hb] + (jj < nj[hb] ? jj : 0)];
+                    }
+                }
+            if (base == 0) {
+                // zero fill while the loads are in flight (the wave's LDS operations execute in order: the parameters land
+                // on top); the two dims' panels of a layer are adjacent
+                const cm_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < LB && lb + q < L; ++q) {
+                    float* pq = lay0 + (size_t)(lb + q) * pstride + iA * PS;
+                    for (int e = 4 * lane; e < nd * PS; e += 256) *(cm_f32x4*)(pq + e) = z4;
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    if (lb + q < L && hb < nd) {
+                        float* pq = lay0 + (size_t)(lb + q) * pstride;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int jj = base + 64 * u + lane;
+                            if (jj < nj[hb]) {
+                                const float v = t[hb][q][u];
+                                pq[d[hb][u] >> 16] = v;
+                                pq[d[hb][u] & 0x7fffu] = (d[hb][u] & PANEL_SCALED) ? v * kTanhScale : v;
+                            }
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// The same panels out of the clique's panel image (device memory, maintained by the Adam kernel): a 16-byte copy.
+template <int K, int H>
+__device__ __forceinline__ void copy_pair_panels(float* lay0, int PS, size_t pstride, const float* image_generic, int iA, int nd,
+                                                 int L, int lane) {
+    typedef const __attribute__((address_space(1))) cm_f32x4* gv4;
+    const int n4 = (nd * PS) >> 2;                            // 16-byte words per layer (PS is a multiple of 4)
+    constexpr int U = 10;                                     // D <= 16: 2 x 1268 floats = 634 words = 10 per lane
+    for (int lb = 0; lb < L; lb += 4) {
+        cm_f32x4 v[4][U];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = (lb + q < L) ? lb + q : L - 1;
+            gv4 src = (gv4)(image_generic + (size_t)l * pstride + (size_t)iA * PS);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = lane + 64 * u;
+                v[q][u] = src[e < n4 ? e : 0];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (lb + q < L) {
+                cm_f32x4* dst = (cm_f32x4*)(lay0 + (size_t)(lb + q) * pstride + (size_t)iA * PS);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = lane + 64 * u;
+                    if (e < n4) dst[e] = v[q][u];
+                }
+            }
+        }
+    }
+}
+
+// dL/dx_k (k < 4 * NG4) of the lane's particle through layer 0 of the conditioner: gx[k] = sum_j W0[k][j] ga1[j]
+template <int K, int H, int NG4>
+__device__ __forceinline__ void cond_input_grad(const float* pan, int oW0N, int lane, const float (&ga1)[H], cm_f32x4 (&gx)[NG4], int ngroups) {
+    using CP = CondPanel<K, H>;
+    const float* rows = pan + oW0N + (lane & 3) * CP::ST;
+#pragma unroll
+    for (int g = 0; g < NG4; ++g) {
+        cm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (g < ngroups) {                                   // wave-uniform
+            cm_f32x4 a4[H / 4];
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q) a4[q] = *(const cm_f32x4*)(rows + 4 * g * CP::ST + 4 * q);
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma1(a4[q][u], ga1[4 * q + u], acc);
+        }
+        gx[g] = acc;
     }
 }

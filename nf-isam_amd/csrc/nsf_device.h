@@ -614,9 +614,10 @@ __device__ __forceinline__ void spline_train_fwd(float v, const float (&th)[PoP]
     rq_math<false>(vs, S.Xk, S.dx, S.Yk, S.dy, S.d0, S.d1, S.t, z, lad);
     if (!S.inside) { z = v; lad = 0.0f; }
 }
-// gth = dL/dtheta for upstream gz = dL/dz, gl = dL/dlogdet (pads of the layout are written 0)
+// gth = dL/dtheta for upstream gz = dL/dz, gl = dL/dlogdet (pads of the layout are written 0); returns dL/dx through the
+// spline's own argument (outside the interval the spline is the identity: gz itself) -- multi-layer kernels only
 template <int K, int PoP>
-__device__ __forceinline__ void spline_train_bwd(const SplineT<K>& S, float B, float gz_in, float gl_in, float (&gth)[PoP]) {
+__device__ __forceinline__ float spline_train_bwd(const SplineT<K>& S, float B, float gz_in, float gl_in, float (&gth)[PoP]) {
     using LY = Layout<K, 8>;
     const float gz = S.inside ? gz_in : 0.0f, gl = S.inside ? gl_in : 0.0f;     // outside the interval: identity, no parameter gradient
     const float w = S.dx, h = S.dy, d0 = S.d0, d1 = S.d1, t = S.t;
@@ -678,6 +679,7 @@ __device__ __forceinline__ void spline_train_bwd(const SplineT<K>& S, float B, f
         const bool gej2 = (j + 2 < K) ? S.sel[j + 2] : false;
         gth[LY::idv(j)] = gej2 ? 0.0f : (gej1 ? gd0 : (gej ? gd1 : 0.0f));
     }
+    return S.inside ? g_x : gz_in;
 }
 
 }  // namespace nsf

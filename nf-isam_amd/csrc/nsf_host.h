@@ -71,6 +71,7 @@ struct TrainArgs {
     int pair_dims;                  // nsf_train2_kernel: waves that share a SIMD take the cheapest dims (see the kernel)
     int chain, n_chains;            // nsf_train1_kernel: this launch covers the (clique, dim) groups g with (g / 8) % n_chains == chain
     const uint32_t* panel_map;      // nsf_train1_kernel: kernel-layout parameter index -> LDS word(s) of the conditioner panel (nsf_cond_mfma.h)
+    int pair_image;                 // nsf_train3_kernel: the clique's panel image is current (written by the previous iteration's Adam kernel)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
@@ -89,7 +90,12 @@ struct NsfUnitOps {
                 int L, int n, const float* Zt, float* St, hipStream_t s);
     int (*train)(const TrainArgs& a, int n_cliques, int max_n, int max_D, hipStream_t s);   // gradient kernel of an iteration
     int (*prepare)(int max_D);      // device-resident tables of the training kernels (idempotent; call once outside stream capture)
+    // nsf_train3_kernel (two dims per wave): LDS bytes of a launch (0: the launch does not fit that kernel) and the
+    // device-resident panel map + the offsets of each clique width's map in it (nsf_cond_mfma.h: build_pair_map)
+    size_t (*pair_lds)(int L, int max_D);
+    int (*pair_map)(const uint32_t** map, uint32_t* offsets /* [PAIR_MAP_OFFSETS] */);
 };
+constexpr int PAIR_MAP_OFFSETS = 17;
 #define NSF_DECLARE_UNIT(u) extern "C" const NsfUnitOps* nsf_unit_ops_u##u(int K, int H);
 NSF_UNITS(NSF_DECLARE_UNIT)
 

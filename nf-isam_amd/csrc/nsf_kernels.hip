@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "nsf_host.h"
+#include "nsf_cond_mfma.h"
 
 thread_local int nfisam_g_last_hip_error = 0;
 
@@ -27,6 +28,8 @@ struct AdamArgs {
     int max_n;              // largest n of the batch (number of slabs in every workspace)
     int few_copies;         // every clique has <= 8 gradient copies: one thread per parameter
     nfisam_train_state* mirror;   // bookkeeping kernel: host-pinned copy of the states (training plans) or nullptr
+    const uint32_t* pair_map;     // != nullptr: multi-layer launches of nsf_train3_kernel -- every updated parameter is also written to
+    uint32_t pair_off[PAIR_MAP_OFFSETS];   // the clique's PANEL IMAGE behind its loss ring (nsf_cond_mfma.h: build_pair_map)
     int close_chunk;        // > 0: fused-Adam launches (nsf_cond_mfma.h): apply the LAST iteration's pending update of a chunk of
                             // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
 };
@@ -84,6 +87,13 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     if (s_stop != 0 || t > a.cfg.max_iters) return;
 
     const AdamCoef kc = adam_coef(a.cfg.lr, a.cfg.beta1, a.cfg.beta2, a.cfg.eps, a.log_b1, a.log_b2, t, n);
+    // panel image of the two-dims-per-wave training kernel: [L][D][pair_panel_floats] behind the loss ring
+    float* img = nullptr;
+    const int Pk1 = P / a.L, img_layer = D * pair_panel_floats(a.K, a.H, D);
+    if (a.pair_map != nullptr && D <= PAIR_MAX_D) {
+        const size_t copies = a.slab ? (size_t)((a.max_n + a.slab - 1) / a.slab) : (size_t)1;
+        img = G + copies * (size_t)P + (size_t)LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+    }
     if (a.slab && n_tiles0 <= 8 && a.few_copies) {
         // few gradient copies (throughput launches: one copy per T tiles): one thread per parameter, the copies summed
         // in copy order (bitwise-reproducible), every load independent of the others
@@ -99,6 +109,13 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
             m[j] = mj;
             v[j] = vj;
             theta[j] = tj;
+            if (img != nullptr) {
+                const int l = j / Pk1, jj = j - l * Pk1;
+                const uint32_t d = a.pair_map[a.pair_off[D] + jj];
+                float* il = img + (size_t)l * img_layer;
+                il[d >> 16] = tj;
+                il[d & 0x7fffu] = (d & PANEL_SCALED) ? tj * kTanhScale : tj;
+            }
         }
         return;
     }
@@ -131,6 +148,13 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
             v[j] = vj;
             theta[j] = tj;
             if (!a.slab) G[j] = 0.0f;
+            if (img != nullptr) {
+                const int l = j / Pk1, jj = j - l * Pk1;
+                const uint32_t d = a.pair_map[a.pair_off[D] + jj];
+                float* il = img + (size_t)l * img_layer;
+                il[d >> 16] = tj;
+                il[d & 0x7fffu] = (d & PANEL_SCALED) ? tj * kTanhScale : tj;
+            }
         }
         __syncthreads();
         first = false;
@@ -520,7 +544,9 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     // + the fused-Adam launches' second set of gradient copies (64-particle tiles) and second state buffer (theta | m | v)
     const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3) * kcount(D, K, H) : 0;
-    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS + (size_t)FUSED_COUNTERS + fused;
+    // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
+    const size_t image = (L > 1 && H == 8 && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
+    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS + (size_t)FUSED_COUNTERS + fused + image;
 }
 
 // Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
@@ -549,10 +575,21 @@ static bool fused_adam_shape(int n_cliques, int max_n, int max_D, int L, int H, 
     return (max_n + sh.slab - 1) / sh.slab <= 8;              // nsf_adam_kernel's one-thread-per-parameter summation order
 }
 
+// Multi-layer training launches that go to nsf_train3_kernel keep a PANEL IMAGE per clique (behind the loss ring): the Adam
+// kernel of iteration j writes it, the gradient kernel of iteration j + 1 copies it (iteration 0 of a chunk stages from
+// the parameters themselves: whoever set them -- the caller, an earlier run -- did not go through the Adam kernel).
+static bool pair_image_shape(int max_D, int K, int H, int L, const TrainShape& sh) {
+    if (L < 2 || sh.tile != TILE2 || max_D > PAIR_MAX_D) return false;
+    const char* e = getenv("NFISAM_PAIR_IMAGE");
+    if (e != nullptr && e[0] == '0') return false;
+    const NsfUnitOps* ops = find_ops(K, H);
+    return ops != nullptr && ops->pair_lds(L, max_D) > 0;
+}
+
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
                         const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr,
-                        int chain = 0, int n_chains = 1) {
+                        int chain = 0, int n_chains = 1, bool pair_image = false) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
@@ -568,6 +605,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
     a.chain = chain; a.n_chains = n_chains;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
+    a.pair_image = (pair_image && iter_idx > 0) ? 1 : 0;
     const NsfUnitOps* ops = find_ops(K, H);
     if (ops == nullptr) return NFISAM_ERR_ARG;
     return ops->train(a, n_cliques, max_n, max_D, s);
@@ -589,14 +627,20 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
                         hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1) {
-    const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H));
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, sh);
     if (!fused && n_chains > 1) return NFISAM_ERR_ARG;
+    const bool image = !fused && pair_image_shape(max_D, K, H, L, sh);
     int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
-                          fused ? cfg : nullptr, host_cliques, chain, n_chains);
+                          fused ? cfg : nullptr, host_cliques, chain, n_chains, image);
     if (rc || fused) return rc;
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
     ad.iter_idx = iter_idx;
+    if (image) {
+        rc = find_ops(K, H)->pair_map(&ad.pair_map, ad.pair_off);
+        if (rc) return rc;
+    }
     // 32 parameters per block (x 8 tile-lanes); a few hundred small blocks spread the latency-bound work
     const size_t Pmax = (size_t)L * kcount(max_D, K, H);
     int ablocks = (int)((Pmax + 31) / 32);

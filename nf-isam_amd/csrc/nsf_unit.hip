@@ -850,7 +850,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
             }
         } else {
-            cond_forward_mfma<K, H>(pan, i, xt, XS, lane, h1, h2, th);
+            cond_forward_mfma<K, H>(pan, i, CP::s0_of(i), xt, XS, lane, lane, h1, h2, th);
             // operands of the gradient GEMMs, parked while the lanes are busy with the spline
             lds_rows_store<0, H, 0, H>(stg_lane, h2);
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
@@ -1421,6 +1421,352 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
 }
 
 // =============================================================================================
+// training / VJP kernel, TWO DIMS PER WAVE (multi-layer flows and VJP launches in the latency regime).
+//
+// The layers of a flow are sequential and every layer needs every dim of its input (src/flows/models.py:11-24), so a
+// block owns a particle tile through all layers and its waves meet at a barrier per layer: the time of a launch is
+// (2L - 1) x the time of ONE (layer, dim) unit on the slowest SIMD.  nsf_train2_kernel put one dim on a wave (two lanes
+// per particle, VALU conditioner with per-lane weights from LDS): D = 6 means six waves on four SIMDs, and a unit took
+// ~13 k cycles.  Here a wave is the dim-major kernel's unit (nsf_train1_kernel: conditioner on 4x4x1 MFMA chains, lean
+// spline, operand staging for the gradient GEMMs) with the two halves of the wave on two different dims of the same 32
+// particles (nsf_cond_mfma.h, PairPanel): D = 6 is three waves on three SIMDs, ~10 k cycles per unit.
+//   grid (32-particle tiles, cliques), block = W = min(ceil(D / 2), 8) waves; wave w owns the pairs w, w + W, ...
+//   LDS: ones | layer inputs [L][D][XS2] | dL/dx buffers 2 x [pair_g_rows(D)][XS2] | per wave: staging [16][XS] + h1 [H][XS] |
+//        panels [L][D][PairPanel::floats(D)] (each wave stages and reads only its own dims')
+// Same arguments, gradient sinks, loss ring and workspace layout as nsf_train2_kernel (a drop-in at the launch site).
+// =============================================================================================
+// rows of one dL/dx buffer: row k = the gradient through dim k's own spline argument, row D + i(i-1)/2 + k = dim i's
+// conditioner's contribution to input k < i.  Every row has ONE writer (plain stores, nothing to zero); the reader of
+// dim k adds its column of the triangle in a fixed order -- reproducible, and no LDS atomics in the wave's stream.
+__host__ __device__ static inline int pair_g_rows(int D) { return D + D * (D - 1) / 2; }
+__host__ __device__ static inline int pair_tile_floats(int L, int D, int g_tiles) {
+    return (ONES_ROW + (L * D + 2 * g_tiles * pair_g_rows(D)) * XS2 + 3) & ~3;
+}
+constexpr int PAIR_WAVE_FLOATS = (16 + 8) * XS;             // staging rows + h1 rows (H <= 8)
+static_assert(PAIR_MAP_OFFSETS == PAIR_MAX_D + 1, "one map per clique width 0 .. PAIR_MAX_D");
+struct PairMapOffsets { uint32_t at[PAIR_MAX_D + 1]; };     // word offset of clique width D's map in the table (kernel argument: no dependent load)
+
+template <int K, int H>
+__global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint32_t* pair_map, PairMapOffsets offs) {
+    using LY = Layout<K, H>;
+    using PP = PairPanel<K, H>;
+    constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;
+    constexpr int NS = TILE / 4, NSH = NS / 2;                // MFMA k-steps over the wave's 64 columns / over one dim's 32
+    constexpr int QH = H / 4;
+    static_assert((H == 8 || H == 4) && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H <= 8");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
+    const gfloat* x = (const gfloat*)(batched ? cp->x : a.single.x);
+    const float* kparams = batched ? cp->kparams : a.single.kparams;
+    gfloat* G = (gfloat*)(batched ? cp->kgrad : a.single.kgrad);
+    typedef __attribute__((address_space(1))) nfisam_train_state gstate;
+    gstate* st = (gstate*)(batched ? cp->state : a.single.state);
+    const int n = batched ? cp->n : a.single.n;
+    const int D = batched ? cp->D : a.single.D;
+    const int L = a.L;
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const int Pk = a.layer_stride > 0 ? a.layer_stride : LY::count(D);
+    const size_t gstride = (size_t)L * (size_t)Pk;
+    gfloat* ring = G + (slab ? (size_t)gridDim.x : (size_t)1) * gstride;   // loss ring behind the gradient copies
+    if (slab) G += (size_t)blockIdx.x * gstride;
+
+    const int p0 = blockIdx.x * TILE2;
+    if (p0 >= n) return;
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int lane = threadIdx.x & 63;
+    const int sub = lane >> 5, p = lane & 31;                  // which dim of the pair, which particle of the tile
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int npairs = (D + 1) >> 1;
+    const int gp = p0 + p;
+    const bool valid = gp < n;
+    const int DT = D * XS2;
+    const int PS = PP::floats(D), s0 = PP::s0(D), oW0N = PP::oW0N(D);
+
+    float* ones = smem;                                       // [ONES_ROW]
+    float* xs = ones + ONES_ROW;                              // [L][D][XS2] layer inputs, dimension-major
+    const int gt = a.g_tiles ? pair_g_rows(D) * XS2 : 0;
+    float* g0 = xs + L * DT;
+    float* g1 = g0 + gt;
+    float* stg = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)w * PAIR_WAVE_FLOATS;   // (sized for the launch's widest clique)
+    float* hrow = stg + 16 * XS;
+    float* panels = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)W * PAIR_WAVE_FLOATS;
+    const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);
+    const int r16 = lane & 15, kq = lane >> 4;
+    STAMP_DECL
+    STAMP(0);
+
+    // ---- prologue: own panels (all layers), the particle tile (every wave writes all of it: same values, no barrier) ----
+    {
+        const uint32_t* map = pair_map + offs.at[D];
+        const int lim = ((n - p0) < TILE2 ? (n - p0) : TILE2) * D;
+        const gfloat* xt = x + (size_t)p0 * D;
+        constexpr int XB = 8;                                 // D <= 16: 32 x 16 / 64 elements per lane
+        float xv[XB];
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int e = lane + 64 * u;
+            xv[u] = (e < lim) ? xt[e] : 0.0f;
+        }
+        const float* image = (const float*)(ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS);   // [L][D][PS], see build_pair_map
+        for (int j = w; j < npairs; j += W) {
+            if (a.pair_image)
+                copy_pair_panels<K, H>(panels, PS, (size_t)D * PS, image, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
+            else
+                stage_pair_panels<K, H>(panels, PS, (size_t)D * PS, kparams, (size_t)Pk, map, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
+        }
+        if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform
+        const float invD = 1.0f / (float)D;
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int e = lane + 64 * u;
+            if (e < D * TILE2) {
+                int pq = (int)(((float)e + 0.5f) * invD);
+                int k = e - pq * D;
+                if (k < 0) { k += D; pq -= 1; }
+                if (k >= D) { k -= D; pq += 1; }
+                xs[k * XS2 + pq] = xv[u];
+            }
+        }
+        ones[lane] = 1.0f;
+        if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
+        wave_lds_sync();
+    }
+    STAMP(1);
+
+    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    for (int l = 0; l + 1 < L; ++l) {
+        const float* xin = xs + l * DT;
+        float* xout = xs + (l + 1) * DT;
+        for (int j = w; j < npairs; j += W) {
+            const int i = 2 * j + sub;
+            const bool dim_ok = i < D;
+            const int ic = dim_ok ? i : D - 1;
+            const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
+            const float* pan = panels + ((size_t)l * D + ic) * PS;
+            float h1[H], h2[H], th[PoP];
+            cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
+            SplineT<K> S;
+            float z, lad;
+            spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
+            if (dim_ok) xout[i * XS2 + p] = z;
+        }
+        STAMP(10);
+        __syncthreads();
+        STAMP(11);
+    }
+
+    // ---- backward with recompute, last layer first ------------------------------------------
+    float lossv = 0.0f;
+    float* gcur = g0;
+    float* gprev = g1;
+    // dL/d(input k) of the layer above, for the lane's particle: own spline argument + the conditioners of the dims k+1 .. D-1
+    // (the loop starts behind the pair's FIRST dim; the second dim skips one term)
+    auto upstream = [&](const float* gb, int k, int first) {
+        float acc = gb[k * XS2 + p];
+        for (int src = first + 1; src < D; ++src) {
+            const float v = gb[(D + ((src * (src - 1)) >> 1) + (src > k ? k : 0)) * XS2 + p];
+            acc += (src > k) ? v : 0.0f;
+        }
+        return acc;
+    };
+    for (int l = L - 1; l >= 0; --l) {
+        const bool last = (l == L - 1);
+        const bool need_gx = (l > 0) || (a.gx != nullptr);
+        gfloat* Gl = G + (size_t)l * Pk;
+        const float* xin = xs + l * DT;
+        for (int j = w; j < npairs; j += W) {
+            const int i = 2 * j + sub;
+            const bool dim_ok = i < D;
+            const int ic = dim_ok ? i : D - 1;
+            const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
+            const float* pan = panels + ((size_t)l * D + ic) * PS;
+            float h1[H], h2[H], th[PoP], gth[PoP];
+            STAMP(2);
+            cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
+            // operands of the gradient GEMMs, parked while the lanes are busy with the spline
+            lds_rows_store<0, H, 0, H>(stg_lane, h2);
+            lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
+            STAMP(3);
+            SplineT<K> S;
+            float z, lad;
+            spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
+            STAMP(4);
+            float gz, gl;
+            if (a.nll_mode) {
+                gl = -1.0f;
+                gz = last ? z : upstream(gcur, ic, 2 * j);
+                if (valid && dim_ok) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+            } else {
+                gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
+                gz = last ? ((valid && dim_ok) ? a.gz[(size_t)gp * D + i] : 0.0f) : upstream(gcur, ic, 2 * j);
+            }
+            if (!valid || !dim_ok) { gz = 0.0f; gl = 0.0f; }
+            const float gxs = spline_train_bwd<K, PoP>(S, B, gz, gl, gth);
+            if (need_gx && dim_ok) gprev[i * XS2 + p] = gxs;
+            STAMP(5);
+            // ---- per-particle back-propagation through the conditioner (4x4x1 MFMA chains, nsf_cond_mfma.h) ----
+            float ga2[H], ga1[H];
+            cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
+            if (need_gx) {                                       // dL/dx_k of the layer input, k < i: zero rows of W0N beyond
+                constexpr int NG4 = (PAIR_MAX_D - 1 + 3) / 4;
+                cm_f32x4 gxk[NG4];
+                cond_input_grad<K, H, NG4>(pan, oW0N, lane, ga1, gxk, (imax + 3) >> 2);
+                float* tri = gprev + (D + ((ic * (ic - 1)) >> 1)) * XS2 + p;
+#pragma unroll
+                for (int g = 0; g < NG4; ++g)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * g + u < i && dim_ok) tri[(4 * g + u) * XS2] = gxk[g][u];
+            }
+            // ---- weight gradients on the matrix cores: the staging columns 0-31 are the first dim's particles, 32-63 the
+            //      second's -- two accumulator sets, the k-steps of a chain split between them (see nsf_train1_kernel) ----
+            STAMP(6);
+            const int iA = 2 * j, iB = 2 * j + 1;
+            const float* pa = stg + r16 * XS + kq;
+            float breg[NS], areg[NS];
+            {
+                wave_lds_sync();
+                const float* pah = ((r16 < H) ? stg + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) breg[s4] = pah[4 * s4];
+                wave_lds_sync();
+            }
+            f32x4 cacc[2][NT], c1[2], c0[2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                c1[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                c0[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 1; t <= NT; ++t) {
+                if (t == 1 && NT > 1) lds_rows_store<0, 16, 16, PoP>(stg_lane, gth);
+                if (t == 2 && NT > 2) lds_rows_store<0, 16, 32, PoP>(stg_lane, gth);
+                if (t == 3 && NT > 3) lds_rows_store<0, 16, 48, PoP>(stg_lane, gth);
+                if (t == NT) {
+                    lds_rows_store<0, H, 0, H>(stg_lane, ga2);
+                    lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) cacc[s4 / NSH][t - 1] = mfma4(areg[s4], breg[s4], cacc[s4 / NSH][t - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                wave_lds_sync();
+                if (t < NT) {
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+                    wave_lds_sync();
+                }
+            }
+            STAMP(7);
+            const bool merged = (imax <= 16 - (H + 1));
+            if (merged) {
+                // columns [h1 (H) | 1 | x_0 .. x_{i-1}] of both products in one 16-column operand (see nsf_train1_kernel)
+                const int kx = r16 - (H + 1);
+                const float* pbm[2];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int ih = 2 * j + hb;
+                    const bool one = (r16 == H) || kx >= ih;
+                    pbm[hb] = (one ? ones : ((r16 < H) ? hrow + r16 * XS + 32 * hb : xin + kx * XS2)) + kq;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c1[s4 / NSH] = mfma4(areg[s4], pbm[s4 / NSH][4 * (s4 % NSH)], c1[s4 / NSH]);
+                }
+            } else {
+                const float* pb0[2];
+                const float* pb1[2];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int ih = 2 * j + hb;
+                    pb0[hb] = ((r16 < ih) ? xin + r16 * XS2 : ones) + kq;       // input columns 0..15 (column i = bias)
+                    pb1[hb] = ((r16 < H) ? hrow + r16 * XS + 32 * hb : ones) + kq;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c1[s4 / NSH] = mfma4(areg[s4], pb1[s4 / NSH][4 * (s4 % NSH)], c1[s4 / NSH]);
+                    c0[s4 / NSH] = mfma4(areg[s4], pb0[s4 / NSH][4 * (s4 % NSH)], c0[s4 / NSH]);
+                }
+            }
+            wave_lds_sync();
+            // ---- the two dims' parameter-block gradients of this layer (C layout: col = lane&15, rows 4*(lane>>4)+r) ----
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int ih = hb ? iB : iA;
+                if (ih >= D) continue;
+                if (ih == 0) {                                  // the spline parameters of dim 0: db2 alone
+                    if (r16 == H) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gl[16 * t + 4 * kq], cacc[hb][t], slab);
+                    }
+                    continue;
+                }
+                gfloat* Gb = Gl + LY::off(ih);
+                gfloat* Gw2 = Gb + LY::oW2(ih);
+                if (r16 <= H) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw2[r16 * PoP + 16 * t + 4 * kq], cacc[hb][t], slab);
+                }
+                if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(ih))[r16 * H + 4 * kq], c1[hb], slab);
+                if (merged) {                                 // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
+                    const int k0 = (r16 == H) ? ih : r16 - (H + 1);
+                    if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < ih))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1[hb], slab);
+                } else if (kq >= QH && kq < 2 * QH && r16 <= ih) {
+                    gsink4(&Gb[r16 * H + 4 * (kq - QH)], c0[hb], slab);
+                }
+            }
+            STAMP(8);
+        }
+        STAMP(12);
+        __syncthreads();
+        STAMP(13);
+        float* tmp = gcur; gcur = gprev; gprev = tmp;
+    }
+
+    if (a.gx != nullptr) {   // gcur now holds dL/dx of layer 0's input
+        for (int e = threadIdx.x; e < D * TILE2; e += blockDim.x) {
+            const int pp = e / D, k = e - pp * D;
+            const int q = p0 + pp;
+            if (q < n) {
+                float acc = gcur[k * XS2 + pp];
+                for (int src = k + 1; src < D; ++src) acc += gcur[(D + ((src * (src - 1)) >> 1) + k) * XS2 + pp];
+                a.gx[(size_t)q * D + k] = acc;
+            }
+        }
+    }
+    STAMP(9);
+    if (a.nll_mode) {
+        const float tot = wave_sum(lossv);
+        if (lane == 0) {
+            gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                    ((blockIdx.x * 7 + w) & (LOSS_SLOTS - 1))]
+                                          : (gfloat*)a.loss_sum;
+            if (dst != nullptr) gsink(dst, tot, false);
+        }
+    }
+}
+
+// =============================================================================================
 // inference: forward (density direction)
 // =============================================================================================
 template <int K, int H>
@@ -1944,12 +2290,80 @@ static size_t block_weight_floats(const TrainArgs& a, int max_D, int W, int grou
     return wfloats;
 }
 
+// device-resident map of the pair kernel's panels (nsf_cond_mfma.h: build_pair_map), one per device and (K, H)
+template <int KK, int HH>
+struct PairMap {
+    static int get(const uint32_t** out, PairMapOffsets* offs) {
+        static const uint32_t* maps[16] = {nullptr};
+        static PairMapOffsets table;
+        int devn = 0;
+        HIP_TRY(hipGetDevice(&devn));
+        if (devn < 0 || devn >= 16) return NFISAM_ERR_ARG;
+        if (maps[devn] == nullptr) {
+            const size_t cnt = pair_map_words<KK, HH>();
+            std::vector<uint32_t> host(cnt);
+            build_pair_map<KK, HH>(host.data());
+            for (int D = 0; D <= PAIR_MAX_D; ++D) table.at[D] = host[D];
+            uint32_t* d = nullptr;
+            HIP_TRY(hipMalloc((void**)&d, cnt * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice));
+            maps[devn] = d;
+        }
+        if (out != nullptr) *out = maps[devn];
+        if (offs != nullptr) *offs = table;
+        return NFISAM_OK;
+    }
+};
+// LDS bytes of nsf_train3_kernel; 0: the launch does not fit it (too wide, or the panels of all layers exceed the CU's LDS)
+template <int KK, int HH>
+static size_t pair_kernel_lds(int L, int max_D) {
+    if constexpr (HH != 8) {
+        return 0;
+    } else {
+        const char* pe = getenv("NFISAM_PAIR");
+        if ((pe != nullptr && pe[0] == '0') || max_D > PAIR_MAX_D || max_D < 1) return 0;
+        const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
+        const size_t fl = (size_t)pair_tile_floats(L, max_D, 1) + (size_t)W * PAIR_WAVE_FLOATS +
+                          (size_t)L * max_D * PairPanel<KK, HH>::floats(max_D);
+        return fl * sizeof(float) <= 160 * 1024 ? fl * sizeof(float) : 0;
+    }
+}
+template <int KK, int HH>
+static int unit_pair_map(const uint32_t** map, uint32_t* offsets) {
+    if constexpr (HH != 8) {
+        return NFISAM_ERR_ARG;
+    } else {
+        PairMapOffsets o;
+        const int rc = PairMap<KK, HH>::get(map, &o);
+        if (rc == NFISAM_OK && offsets != nullptr) memcpy(offsets, o.at, sizeof(o.at));
+        return rc;
+    }
+}
+
 template <int KK, int HH>
 static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
     if constexpr (HH != 8) {
         return NFISAM_ERR_ARG;
     } else {
         const long tiles = (long)((max_n + TILE2 - 1) / TILE2) * n_cliques;
+        if (!(a.L == 1 && a.gx == nullptr)) {
+            // layers / dL/dx couple the dims of a tile: two dims per wave on the MFMA conditioner (nsf_train3_kernel)
+            const size_t lds3 = pair_kernel_lds<KK, HH>(a.L, max_D);
+            if (lds3 > 0) {
+                const uint32_t* map = nullptr;
+                PairMapOffsets offs;
+                int rc = PairMap<KK, HH>::get(&map, &offs);
+                if (rc) return rc;
+                a.g_tiles = 1;
+                a.xrows = max_D;
+                const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
+                rc = set_lds(nsf_train3_kernel<KK, HH>, lds3);
+                if (rc) return rc;
+                hipLaunchKernelGGL((nsf_train3_kernel<KK, HH>), dim3((max_n + TILE2 - 1) / TILE2, n_cliques), dim3(64 * W), lds3, s, a, map, offs);
+                HIP_TRY(hipGetLastError());
+                return NFISAM_OK;
+            }
+        }
         // L == 1 and no dL/dx requested: the dims of a tile never exchange data, so a small (latency-bound) launch
         // turns every (tile, dim) unit into its own single-wave block; big batches keep a tile's dims together.
         const bool independent_dims = (a.L == 1 && a.gx == nullptr);
@@ -2012,6 +2426,10 @@ struct PanelMap {
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4) {
+        if constexpr (HH == 8) {
+            const int rc = PairMap<KK, HH>::get(nullptr, nullptr);
+            if (rc) return rc;
+        }
         return max_D <= PANEL_MAP_MAX_D ? PanelMap<KK, HH>::get(max_D, nullptr) : NFISAM_OK;
     } else {
         return NFISAM_OK;
@@ -2127,7 +2545,8 @@ static int unit_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D
 }
 
 // ---- the unit's table -------------------------------------------------------------------------------------------
-#define NSF_OPS_ENTRY(k, h) {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>, unit_prepare<k, h>},
+#define NSF_OPS_ENTRY(k, h) \
+    {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>, unit_prepare<k, h>, pair_kernel_lds<k, h>, unit_pair_map<k, h>},
 static const NsfUnitOps g_unit_ops[] = {NSF_FOR_EACH_KH(NSF_OPS_ENTRY)};
 
 #define NSF_UNIT_FN_(u) nsf_unit_ops_u##u

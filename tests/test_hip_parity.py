@@ -786,3 +786,60 @@ def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels():
         # (the dim-major kernel stages W0 / W1 pre-multiplied by 2 log2(e) for its tanh: products rounded once more)
         assert np.abs(a - b).max() < 5e-5 * max(1e-3, np.abs(a).max()), (c, np.abs(a - b).max(), np.abs(a).max())
     np.testing.assert_allclose(res["0"][1], res[None][1], rtol=2e-6, atol=1e-5)
+
+
+def _train_layers(shapes, L, iters, window, use_graph, K=9, H=8, B=5.0, lr=0.01, early_stop=True):
+    probs = [make_problem(n, D, K, H, L, seed=900 + c, spread=1.0) for c, (n, D) in enumerate(shapes)]
+    tb = nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H, L) for (b, _), (_, D) in zip(probs, shapes)], K, H, B, L,
+                       lr=lr, max_iters=iters, average_window=window, loss_delta_tol=0.0, early_stop=early_stop)
+    done = tb.run(use_graph=use_graph)
+    torch.cuda.synchronize()
+    out = [[t.cpu().numpy().copy() for t in arr] for arr in (tb.kparams, tb.m, tb.v, tb.iter_loss)]
+    tb.close()
+    return done, out, probs
+
+
+@pytest.mark.parametrize("shapes,L,iters,window", [([(4096, 6)], 4, 23, 10), ([(300, 5), (1000, 7), (200, 2), (64, 1)], 2, 61, 50),
+                                                   ([(513, 7)], 3, 12, 5)], ids=["c2", "ragged-batch", "odd-D"])
+@pytest.mark.parametrize("use_graph", [True, False], ids=["hipgraph", "eager"])
+def test_multilayer_panel_image_equals_staging_from_the_parameters(shapes, L, iters, window, use_graph):
+    """Multi-layer training launches (nsf_train3_kernel, two dims per wave): from the second iteration of a chunk on the
+    blocks COPY their conditioner panels from the clique's panel image, which the Adam kernel keeps next to the loss ring
+    (nsf_cond_mfma.h: build_pair_map); `NFISAM_PAIR_IMAGE=0` makes every launch stage from the parameters instead.  Same
+    values by construction -- parameters, moments and the loss record must agree bit for bit (single-writer gradient
+    copies and dL/dx rows: nothing in the kernel depends on an order of arrival); full, partial and single chunks, cliques
+    of different widths in one launch, D = 1 and odd D."""
+    with _Env(NFISAM_PAIR_IMAGE="0"):
+        d0, ref, _ = _train_layers(shapes, L, iters, window, use_graph)
+    with _Env(NFISAM_PAIR_IMAGE=None):
+        d1, got, _ = _train_layers(shapes, L, iters, window, use_graph)
+        d2, again, _ = _train_layers(shapes, L, iters, window, use_graph)
+    assert d0 == d1 == d2 == [iters] * len(shapes)
+    for name, a, b, c2 in zip(("theta", "m", "v"), ref[:3], got[:3], again[:3]):
+        for c, (x, y, z) in enumerate(zip(a, b, c2)):
+            assert np.array_equal(x, y) and np.array_equal(y, z), (name, c, np.abs(x - y).max())
+    for x, y in zip(ref[3], got[3]):                        # the loss record goes through float atomics (order-dependent rounding)
+        np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
+
+
+def test_multilayer_training_follows_the_oracle():
+    """Eight Adam iterations of multi-layer flows through the training plan (gradient kernel + Adam kernel + panel image)
+    against the oracle's loop.  Three layers at this step size amplify rounding (the oracle in fp32 and in fp64 are 3e-2
+    apart in loss after 8 iterations, scripts/exp/ml_traj.py), so the yardstick is the fp64 trajectory and the bound is what
+    the fp32 oracle itself achieves against it: the first iterations must agree to 1e-4, every iteration to
+    3 x the fp32 oracle's own error + 1e-3."""
+    K, H, B, L, iters = 9, 8, 5.0, 3, 8
+    shapes = [(257, 4), (600, 6), (90, 7)]
+    done, out, probs = _train_layers(shapes, L, iters, 50, True, lr=0.02, early_stop=False)
+    assert done == [iters] * len(shapes)
+    for c, (n, D) in enumerate(shapes):
+        blob, x = probs[c]
+        b32, l32, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.02, max_iters=iters, early_stop=False, dtype=np.float32)
+        b64, l64, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.02, max_iters=iters, early_stop=False, dtype=np.float64)
+        got_l = out[3][c][:iters].astype(np.float64)
+        np.testing.assert_allclose(got_l[:3], l64[:3], atol=1e-4, rtol=1e-5)
+        assert np.all(np.abs(got_l - l64) <= 3.0 * np.abs(l32 - l64) + 1e-3), (c, np.abs(got_l - l64), np.abs(l32 - l64))
+        got = nh.unpack(torch.from_numpy(out[0][c]).to(DEV), D, K, H, L).cpu().numpy()
+        err, ref = np.abs(got - b64), np.abs(b32 - b64)
+        assert np.quantile(err, 0.99) <= 3.0 * np.quantile(ref, 0.99) + 2e-3, (c, np.quantile(err, 0.99), np.quantile(ref, 0.99))
+        assert err.max() < iters * 0.02 + 1e-3

@@ -234,7 +234,11 @@ typedef struct nfisam_clique {
  * particle; the dim-major kernel of one-layer flows writes one copy per block of 4 waves); the count is
  * the upper bound of all, plus -- for one-layer flows of <= 32 tiles of 64 -- the second set of copies
  * and the second (theta | m | v) buffer of the launches that apply the previous iteration's Adam update
- * themselves (nfisam_nsf_train_plan_run; no separate Adam launch per iteration).                  */
+ * themselves (nfisam_nsf_train_plan_run; no separate Adam launch per iteration); for multi-layer flows
+ * of hidden width 8 and D <= 16 (ABI 1310) the clique's PANEL IMAGE (the parameters in the order the
+ * multi-layer training kernel reads them from LDS, L x D panels; the Adam kernel keeps it current)
+ * and, for latency-bound sizes, the forward state that kernel parks between its two passes.
+ * Always allocate what this function returns -- the layout behind the gradient copies is the library's. */
 size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L);
 
 /* The gradient half of a training iteration on its own (forward + analytic backward + reduction into

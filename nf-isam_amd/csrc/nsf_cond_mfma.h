@@ -545,6 +545,44 @@ __device__ __forceinline__ void copy_pair_panels(float* lay0, int PS, size_t pst
     }
 }
 
+// Forward state of a (layer, dim, particle) that the backward pass needs (hidden activations + the spline's selected bin),
+// as NF floats: the multi-layer kernel parks it in device memory during the forward pass (one coalesced row per field)
+// instead of recomputing conditioner and spline in the backward pass.
+__host__ __device__ constexpr int pair_stash_fields(int K, int H) { return (2 * H + 2 * K + 12 + 3) & ~3; }   // whole 16-byte words
+template <int K, int H>
+__device__ __forceinline__ void stash_pack(const float (&h1)[H], const float (&h2)[H], const nsf::SplineT<K>& S,
+                                           float (&sv)[pair_stash_fields(K, H)]) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) { sv[q] = h1[q]; sv[H + q] = h2[q]; }
+#pragma unroll
+    for (int q = 0; q < K; ++q) { sv[2 * H + q] = S.ew[q]; sv[2 * H + K + q] = S.eh[q]; }
+    float* t = &sv[2 * H + 2 * K];
+    t[0] = S.iw; t[1] = S.ih; t[2] = S.Xk; t[3] = S.dx; t[4] = S.Yk; t[5] = S.dy; t[6] = S.d0; t[7] = S.d1;
+    t[8] = S.ud0; t[9] = S.ud1; t[10] = S.t;
+    int kc = 0;
+#pragma unroll
+    for (int j = 1; j < K; ++j) kc += S.sel[j] ? 1 : 0;
+    t[11] = __int_as_float(kc | (S.inside ? 256 : 0));
+#pragma unroll
+    for (int q = 2 * H + 2 * K + 12; q < pair_stash_fields(K, H); ++q) sv[q] = 0.0f;
+}
+template <int K, int H>
+__device__ __forceinline__ void stash_unpack(const float (&sv)[pair_stash_fields(K, H)], float (&h1)[H], float (&h2)[H],
+                                             nsf::SplineT<K>& S) {
+#pragma unroll
+    for (int q = 0; q < H; ++q) { h1[q] = sv[q]; h2[q] = sv[H + q]; }
+#pragma unroll
+    for (int q = 0; q < K; ++q) { S.ew[q] = sv[2 * H + q]; S.eh[q] = sv[2 * H + K + q]; }
+    const float* t = &sv[2 * H + 2 * K];
+    S.iw = t[0]; S.ih = t[1]; S.Xk = t[2]; S.dx = t[3]; S.Yk = t[4]; S.dy = t[5]; S.d0 = t[6]; S.d1 = t[7];
+    S.ud0 = t[8]; S.ud1 = t[9]; S.t = t[10];
+    const int f = __float_as_int(t[11]), kc = f & 255;
+    S.sel[0] = true;
+#pragma unroll
+    for (int j = 1; j < K; ++j) S.sel[j] = kc >= j;
+    S.inside = (f & 256) != 0;
+}
+
 // dL/dx_k (k < 4 * NG4) of the lane's particle through layer 0 of the conditioner: gx[k] = sum_j W0[k][j] ga1[j]
 template <int K, int H, int NG4>
 __device__ __forceinline__ void cond_input_grad(const float* pan, int oW0N, int lane, const float (&ga1)[H], cm_f32x4 (&gx)[NG4], int ngroups) {

@@ -71,6 +71,8 @@ struct TrainArgs {
     int pair_dims;                  // nsf_train2_kernel: waves that share a SIMD take the cheapest dims (see the kernel)
     int chain, n_chains;            // nsf_train1_kernel: this launch covers the (clique, dim) groups g with (g / 8) % n_chains == chain
     const uint32_t* panel_map;      // nsf_train1_kernel: kernel-layout parameter index -> LDS word(s) of the conditioner panel (nsf_cond_mfma.h)
+    int pair_ws;                    // nsf_train3_kernel: kgrad is a clique WORKSPACE (nfisam_nsf_grad_workspace_count): the forward state may be parked behind the panel image
+    int pair_stash;                 // launcher-side: park it (the launch is in the workspace's size bound)
     int pair_image;                 // nsf_train3_kernel: the clique's panel image is current (written by the previous iteration's Adam kernel)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     nfisam_adam_cfg adam;
@@ -96,6 +98,9 @@ struct NsfUnitOps {
     int (*pair_map)(const uint32_t** map, uint32_t* offsets /* [PAIR_MAP_OFFSETS] */);
 };
 constexpr int PAIR_MAP_OFFSETS = 17;
+// the clique workspace reserves room for the parked forward state of multi-layer launches up to this size (the
+// two-dims-per-wave kernel is chosen for latency-bound launches: train_tile)
+static inline bool pair_stash_fits(int n, int D) { return (long)((n + TILE2 - 1) / TILE2) * (long)D <= 1280; }
 #define NSF_DECLARE_UNIT(u) extern "C" const NsfUnitOps* nsf_unit_ops_u##u(int K, int H);
 NSF_UNITS(NSF_DECLARE_UNIT)
 

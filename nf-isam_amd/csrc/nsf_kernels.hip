@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-extern "C" int nfisam_abi_version(void) { return 1300; }
+extern "C" int nfisam_abi_version(void) { return 1310; }
 extern "C" int nfisam_last_hip_error(void) { return nfisam_g_last_hip_error; }
 
 // (K, H) -> launchers of the kernel unit that instantiates the pair (nsf_units.h), nullptr if none does
@@ -546,7 +546,11 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3) * kcount(D, K, H) : 0;
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && H == 8 && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
-    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS + (size_t)FUSED_COUNTERS + fused + image;
+    // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)
+    const size_t stash = (image > 0 && pair_stash_fits(n, D))
+                             ? (size_t)((n + TILE2 - 1) / TILE2) * (size_t)(L - 1) * (size_t)((D + 1) / 2) * pair_stash_fields(K, H) * 64
+                             : 0;
+    return tiles * (size_t)L * kcount(D, K, H) + (size_t)LOSS_RING * LOSS_SLOTS + (size_t)FUSED_COUNTERS + fused + image + stash;
 }
 
 // Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
@@ -606,6 +610,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
     a.pair_image = (pair_image && iter_idx > 0) ? 1 : 0;
+    a.pair_ws = 1;                                             // clique descriptors: kgrad is a workspace by contract
     const NsfUnitOps* ops = find_ops(K, H);
     if (ops == nullptr) return NFISAM_ERR_ARG;
     return ops->train(a, n_cliques, max_n, max_D, s);

@@ -1430,7 +1430,7 @@ __global__ void __launch_bounds__(512) nsf_train2_kernel(TrainArgs a) {
 // ~13 k cycles.  Here a wave is the dim-major kernel's unit (nsf_train1_kernel: conditioner on 4x4x1 MFMA chains, lean
 // spline, operand staging for the gradient GEMMs) with the two halves of the wave on two different dims of the same 32
 // particles (nsf_cond_mfma.h, PairPanel): D = 6 is three waves on three SIMDs, ~10 k cycles per unit.
-//   grid (32-particle tiles, cliques), block = W = min(ceil(D / 2), 8) waves; wave w owns the pairs w, w + W, ...
+//   grid (32-particle tiles, cliques), block = W = ceil(D / 2) <= 8 waves; wave w owns the dims 2w, 2w + 1
 //   LDS: ones | layer inputs [L][D][XS2] | dL/dx buffers 2 x [pair_g_rows(D)][XS2] | per wave: staging [16][XS] + h1 [H][XS] |
 //        panels [L][D][PairPanel::floats(D)] (each wave stages and reads only its own dims')
 // Same arguments, gradient sinks, loss ring and workspace layout as nsf_train2_kernel (a drop-in at the launch site).
@@ -1457,15 +1457,19 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     static_assert((H == 8 || H == 4) && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H <= 8");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const bool batched = a.cliques != nullptr;
-    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
-    const gfloat* x = (const gfloat*)(batched ? cp->x : a.single.x);
-    const float* kparams = batched ? cp->kparams : a.single.kparams;
-    gfloat* G = (gfloat*)(batched ? cp->kgrad : a.single.kgrad);
+    // the clique's descriptor in ONE scalar load: from the device array, or (single-clique calls) from the kernel-argument
+    // segment itself (TrainArgs is the first argument)
+    typedef const __attribute__((address_space(4))) nfisam_clique cclique;
+    typedef const __attribute__((address_space(4))) char cchar;
+    cclique* cp = (a.cliques != nullptr) ? (cclique*)(a.cliques + blockIdx.y)
+                                         : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TrainArgs, single));
+    const gfloat* x = (const gfloat*)cp->x;
+    const float* kparams = cp->kparams;
+    gfloat* G = (gfloat*)cp->kgrad;
     typedef __attribute__((address_space(1))) nfisam_train_state gstate;
-    gstate* st = (gstate*)(batched ? cp->state : a.single.state);
-    const int n = batched ? cp->n : a.single.n;
-    const int D = batched ? cp->D : a.single.D;
+    gstate* st = (gstate*)cp->state;
+    const int n = cp->n;
+    const int D = cp->D;
     const int L = a.L;
     const float B = a.B;
     const bool slab = a.slab != 0;
@@ -1504,6 +1508,7 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     STAMP_DECL
     STAMP(0);
 
+    const float* image = (const float*)(ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS);   // [L][D][PS], see build_pair_map
     // ---- prologue: own panels (all layers), the particle tile (every wave writes all of it: same values, no barrier) ----
     {
         const uint32_t* map = pair_map + offs.at[D];
@@ -1514,15 +1519,18 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
             const int e = lane + 64 * u;
-            xv[u] = (e < lim) ? xt[e] : 0.0f;
+            if (64 * u < D * TILE2) xv[u] = xt[e < lim ? e : 0];        // (wave-uniform guard; rows past n are zeroed below)
         }
-        const float* image = (const float*)(ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS);   // [L][D][PS], see build_pair_map
-        for (int j = w; j < npairs; j += W) {
+        if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
+            const int j = w;
             if (a.pair_image)
                 copy_pair_panels<K, H>(panels, PS, (size_t)D * PS, image, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
             else
                 stage_pair_panels<K, H>(panels, PS, (size_t)D * PS, kparams, (size_t)Pk, map, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
         }
+        // the state words were requested at kernel entry and are LOOKED AT only now, behind the prologue's own loads (the
+        // empty asm is a use in front of the branch: the compiler does not pull the wait up to the loads)
+        asm volatile("" : "+v"(st_stop), "+v"(st_step));
         if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform
         const float invD = 1.0f / (float)D;
 #pragma unroll
@@ -1533,7 +1541,7 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 int k = e - pq * D;
                 if (k < 0) { k += D; pq -= 1; }
                 if (k >= D) { k -= D; pq += 1; }
-                xs[k * XS2 + pq] = xv[u];
+                xs[k * XS2 + pq] = (e < lim) ? xv[u] : 0.0f;
             }
         }
         ones[lane] = 1.0f;
@@ -1542,11 +1550,19 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     }
     STAMP(1);
 
-    // ---- forward-only passes: layers 0 .. L-2 (the last layer is recomputed in backward) ---
+    // ---- forward-only passes: layers 0 .. L-2.  With a workspace behind kgrad (training plans) the wave parks what the
+    //      backward pass needs of each of them in device memory (NF coalesced rows of 64 floats; it stays in this XCD's L2) and
+    //      reads it back one layer ahead of its use; otherwise the backward pass recomputes conditioner and spline. ---
+    constexpr int NF = pair_stash_fields(K, H);
+    const bool stash = a.pair_stash != 0;
+    gfloat* stash_w = (gfloat*)image + (size_t)L * D * PS + (((size_t)blockIdx.x * (L - 1)) * npairs + w) * (NF * 64) + 4 * lane;
+    const size_t stash_layer = (size_t)npairs * (NF * 64);
+    float lossv = 0.0f;
     for (int l = 0; l + 1 < L; ++l) {
         const float* xin = xs + l * DT;
         float* xout = xs + (l + 1) * DT;
-        for (int j = w; j < npairs; j += W) {
+        if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
+            const int j = w;
             const int i = 2 * j + sub;
             const bool dim_ok = i < D;
             const int ic = dim_ok ? i : D - 1;
@@ -1558,14 +1574,27 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
             float z, lad;
             spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
             if (dim_ok) xout[i * XS2 + p] = z;
+            if (stash) {
+                float sv[NF];
+                stash_pack<K, H>(h1, h2, S, sv);
+                gvf4_t* dst = (gvf4_t*)(stash_w + (size_t)l * stash_layer);
+#pragma unroll
+                for (int f = 0; f < NF; f += 4) dst[(f >> 2) * 64] = vf4_t{sv[f], sv[f + 1], sv[f + 2], sv[f + 3]};
+                if (a.nll_mode && valid && dim_ok) lossv -= lad;
+            }
         }
         STAMP(10);
         __syncthreads();
         STAMP(11);
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(16 + (l & 7));
+#endif
     }
 
-    // ---- backward with recompute, last layer first ------------------------------------------
-    float lossv = 0.0f;
+    // ---- backward, last layer first ------------------------------------------
+    float nxt[NF];                                            // parked state of the next stage's layer, in flight during this stage's GEMMs
+#pragma unroll
+    for (int f = 0; f < NF; ++f) nxt[f] = 0.0f;
     float* gcur = g0;
     float* gprev = g1;
     // dL/d(input k) of the layer above, for the lane's particle: own spline argument + the conditioners of the dims k+1 .. D-1
@@ -1583,28 +1612,34 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
         const bool need_gx = (l > 0) || (a.gx != nullptr);
         gfloat* Gl = G + (size_t)l * Pk;
         const float* xin = xs + l * DT;
-        for (int j = w; j < npairs; j += W) {
+        if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
+            const int j = w;
             const int i = 2 * j + sub;
             const bool dim_ok = i < D;
             const int ic = dim_ok ? i : D - 1;
             const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
             const float* pan = panels + ((size_t)l * D + ic) * PS;
-            float h1[H], h2[H], th[PoP], gth[PoP];
+            float h1[H], h2[H], gth[PoP];
+            SplineT<K> S;
+            float z = 0.0f, lad = 0.0f;
             STAMP(2);
-            cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
-            // operands of the gradient GEMMs, parked while the lanes are busy with the spline
+            const bool parked = stash && !last;                // wave-uniform
+            if (parked) {
+                stash_unpack<K, H>(nxt, h1, h2, S);
+            } else {
+                float th[PoP];
+                cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
+                spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
+            }
+            // operands of the gradient GEMMs
             lds_rows_store<0, H, 0, H>(stg_lane, h2);
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
-            STAMP(3);
-            SplineT<K> S;
-            float z, lad;
-            spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
             STAMP(4);
             float gz, gl;
             if (a.nll_mode) {
                 gl = -1.0f;
                 gz = last ? z : upstream(gcur, ic, 2 * j);
-                if (valid && dim_ok) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
+                if (valid && dim_ok && !parked) lossv += (last ? 0.5f * z * z : 0.0f) - lad;
             } else {
                 gl = (a.gl != nullptr && valid) ? a.gl[gp] : 0.0f;
                 gz = last ? ((valid && dim_ok) ? a.gz[(size_t)gp * D + i] : 0.0f) : upstream(gcur, ic, 2 * j);
@@ -1630,6 +1665,14 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
             // ---- weight gradients on the matrix cores: the staging columns 0-31 are the first dim's particles, 32-63 the
             //      second's -- two accumulator sets, the k-steps of a chain split between them (see nsf_train1_kernel) ----
             STAMP(6);
+            if (stash && l > 0) {                                // the next stage's layer: requested now, used after the barrier
+                const gvf4_t* src = (const gvf4_t*)(stash_w + (size_t)(l - 1) * stash_layer);
+#pragma unroll
+                for (int f = 0; f < NF; f += 4) {
+                    const vf4_t v4 = src[(f >> 2) * 64];
+                    nxt[f] = v4.x; nxt[f + 1] = v4.y; nxt[f + 2] = v4.z; nxt[f + 3] = v4.w;
+                }
+            }
             const int iA = 2 * j, iB = 2 * j + 1;
             const float* pa = stg + r16 * XS + kq;
             float breg[NS], areg[NS];
@@ -1740,6 +1783,9 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
         STAMP(12);
         __syncthreads();
         STAMP(13);
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(24 + (l & 7));
+#endif
         float* tmp = gcur; gcur = gprev; gprev = tmp;
     }
 
@@ -2356,6 +2402,10 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
                 if (rc) return rc;
                 a.g_tiles = 1;
                 a.xrows = max_D;
+                {
+                    const char* se = getenv("NFISAM_PAIR_STASH");
+                    a.pair_stash = (a.pair_ws && a.L > 1 && pair_stash_fits(max_n, max_D) && !(se != nullptr && se[0] == '0')) ? 1 : 0;
+                }
                 const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
                 rc = set_lds(nsf_train3_kernel<KK, HH>, lds3);
                 if (rc) return rc;

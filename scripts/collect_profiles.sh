@@ -21,6 +21,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_IN
            "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES"; do
   rocprofv3 --pmc $set --output-format csv -d $out/c3_pmc$i -- $B --no-regimes > /dev/null 2> $out/c3_pmc$i.err
   rocprofv3 --pmc $set --output-format csv -d $out/b64_pmc$i -- python3 $GRAFT_REPO_ROOT/scripts/run_c3.py scaling > /dev/null 2> $out/b64_pmc$i.err
+  rocprofv3 --pmc $set --output-format csv -d $out/c2_pmc$i -- python3 $GRAFT_REPO_ROOT/scripts/run_c3.py c2 > /dev/null 2> $out/c2_pmc$i.err
   i=$((i+1))
 done
 cd $GRAFT_REPO_ROOT
@@ -47,7 +48,8 @@ def summarize(prefix):
     return res
 c3 = summarize("c3")
 b64 = summarize("b64")
-json.dump(dict(c3=c3, b64=b64), open(out + "/pmc_means.json", "w"), indent=1)
+c2 = summarize("c2")
+json.dump(dict(c3=c3, b64=b64, c2=c2), open(out + "/pmc_means.json", "w"), indent=1)
 for pre in ("c3_trace", "all_trace", "c3_chains_trace"):
     for f in glob.glob(out + "/%s/*/*kernel_stats.csv" % pre):
         os.system("cp %s %s/%s_kernel_stats.csv" % (f, out, pre))

@@ -42,11 +42,17 @@ def train_batch(shapes, n, iters, seed0):
 
 if __name__ == "__main__":
     c3 = BM.C3_SHAPES   # D = 6 8 8 10 10 12 12 12
-    only = sys.argv[1] if len(sys.argv) > 1 else ""          # "c3" | "scaling" | "" (both)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""          # "c3" | "scaling" | "c2" | "" (the first two)
     out = {}
     if only in ("", "c3"):
         out["C3"] = train_batch(c3, 2000, 500, 100)
     plaza_shape = [(3, 2, 3)] * 64          # D = 3 + 6 + 6 = 15
     if only in ("", "scaling"):
         out["scaling_shape_64x_n2000_D15"] = train_batch(plaza_shape, 2000, 300, 200)
+    if only == "c2":                        # BASELINE config[1]: one clique, D = 6, n = 4096, four layers (profiling target)
+        L = 4
+        prob, _ = BM.regime_problem("C2_single_clique_n4096_D6_L4", seed0=7)
+        w = BM.Workload(prob, L, dev)
+        r, _ = w.record(300, 20, torch.cuda.synchronize)
+        out["C2"] = r
     print(json.dumps(out))

@@ -23,7 +23,8 @@ Prints ONE JSON line on rank 0 (driver contract), including
                  (157.3 TFLOP/s = f32 MFMA peak = f32 packed-VALU peak); the binding resource is VALU issue.
   regimes      : the same live measurement for the other regimes of the path: C2 (BASELINE config[1]: one
                  clique, 4 stacked layers), one Plaza1-shaped clique (n = 2000, D = 15: the latency regime of the
-                 real datasets) and a batch of 64 such cliques (the throughput regime / scaling shape).
+                 real datasets), a batch of 64 such cliques (the throughput regime / scaling shape), and the last two with
+                 hidden_dim 16 (the reference's parameter grids sweep it, src/slam/NFiSAM.py:589-609).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
                  the reference) timed on the host cores on a bounded sample of the same workload, next to the
                  TRUE reference's figures measured in the build container (profiles/r02_cpu_reference_vs_port.json).
@@ -146,8 +147,15 @@ def c3_problem(seed0):
     return out
 
 
+REGIME_HIDDEN = {"plaza_clique_n2000_D15_H16": 16, "batch64_n2000_D15_H16": 16}     # hidden_dim of a regime (default H)
+
+
 def regime_problem(name, seed0):
     """-> (list of (x, blob), L)"""
+    if name in REGIME_HIDDEN:                # the same cliques with hidden_dim 16 (the reference's grids sweep it: NFiSAM.py:589-609)
+        h = REGIME_HIDDEN[name]
+        base, L = regime_problem(name[:-4], seed0)
+        return [(x, init_blob_np(x.shape[1], K, h, L, seed0 + c)) for c, (x, _) in enumerate(base)], L
     if name == "C2_single_clique_n4096_D6_L4":
         s, circ = c2_clique(4096, seed0)
         x, _, _ = normalize(s, circ)
@@ -169,19 +177,20 @@ def regime_problem(name, seed0):
 class Workload:
     """Device-resident clique batch + the two timed things: whole iterations, and the gradient kernel alone."""
 
-    def __init__(self, problem, L, dev):
+    def __init__(self, problem, L, dev, hidden=None):
         import torch
         import nfisam_hip as nh
         self.torch, self.nh, self.L, self.dev = torch, nh, L, dev
+        self.H = H if hidden is None else hidden
         self.xs = [torch.from_numpy(x).to(dev) for x, _ in problem]
-        self.kp0 = [nh.pack(torch.from_numpy(b).to(dev), x.shape[1], K, H, L) for x, b in problem]
+        self.kp0 = [nh.pack(torch.from_numpy(b).to(dev), x.shape[1], K, self.H, L) for x, b in problem]
         self.n_samples = sum(int(x.shape[0]) for x, _ in problem)
-        self.flop_per_launch = sum(flops_per_sample_iter(x.shape[1], K, H, L) * x.shape[0] for x, _ in problem)
+        self.flop_per_launch = sum(flops_per_sample_iter(x.shape[1], K, self.H, L) * x.shape[0] for x, _ in problem)
 
     def batch(self, iters):
         """`iters` fixed iterations: the window early-stop rule is armed with a tolerance of 0 (never fires) and a window
         of `iters`, so that the hipGraph chunk length divides `iters` and every iteration is a graph replay."""
-        return self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, H, B, self.L, lr=LR, max_iters=iters,
+        return self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, self.H, B, self.L, lr=LR, max_iters=iters,
                                   average_window=iters, loss_delta_tol=0.0, early_stop=True)
 
     def time_iterations(self, iters, warmup, barrier, reduce_max=None):
@@ -226,7 +235,7 @@ class Workload:
         branches, nfisam_nsf_train_chains -- which shortens the ITERATION, `gpu_us_per_iteration_events`, not the kernel.)
         -> (us per launch, chains of the plan)"""
         torch = self.torch
-        tbk = self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, H, B, self.L, lr=LR, max_iters=10 ** 6,
+        tbk = self.nh.TrainBatch(self.xs, [p.clone() for p in self.kp0], K, self.H, B, self.L, lr=LR, max_iters=10 ** 6,
                                  early_stop=False)
         chains = tbk.chains()
         for _ in range(20):
@@ -252,7 +261,7 @@ class Workload:
         kus, chains = self.time_gradient_kernel()
         ach = self.flop_per_launch / (kus * 1e-6) / 1e12
         return dict(cliques=len(self.xs), D=[int(x.shape[1]) for x in self.xs] if len(self.xs) <= 8 else int(self.xs[0].shape[1]),
-                    particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, iterations=iters, replays=self.replays,
+                    particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, hidden_dim=self.H, iterations=iters, replays=self.replays,
                     us_per_iteration=1e6 * dt / iters, gpu_us_per_iteration_events=1e3 * gpu_ms / iters,
                     samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus, launches_per_training_iteration=chains,
                     flop_per_launch=self.flop_per_launch, achieved_tflops=ach, frac_of_fp32_peak=ach / FP32_PEAK_TFLOPS,
@@ -427,9 +436,10 @@ def main():
 
     regimes = {}
     if rank == 0 and world == 1 and not args.no_regimes:
-        for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15"):
+        for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15", "plaza_clique_n2000_D15_H16",
+                     "batch64_n2000_D15_H16"):
             prob, L = regime_problem(name, seed0=7)
-            regimes[name], _ = Workload(prob, L, dev).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
+            regimes[name], _ = Workload(prob, L, dev, REGIME_HIDDEN.get(name)).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
 
     if rank == 0:
         total = world * wl.n_samples * args.steps

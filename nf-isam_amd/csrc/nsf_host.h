@@ -182,11 +182,12 @@ static inline int dim_major_waves(int n_cliques, int max_n, int max_D, int T) {
     const int v = e != nullptr ? atoi(e) : 4;
     return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
 }
-// hidden widths the dim-major kernel is instantiated for ([ga2 | ga1] must fit one 16-row MFMA operand tile)
+// hidden widths the dim-major kernel is instantiated for (H <= 8: [ga2 | ga1] share one 16-row MFMA operand tile;
+// H = 16: one tile each and separate bias chains)
 static inline bool dim_major_hidden(int H) {
     const char* e = getenv("NFISAM_GRAD");
     if (e != nullptr && strcmp(e, "butterfly") == 0) return false;
-    return H == 8 || H == 4;
+    return H == 8 || H == 4 || H == 16;
 }
 // smallest launch ((tile, dim) units) that goes to the dim-major kernel; NFISAM_DIM_MAJOR_MIN overrides (experiments)
 static inline long dim_major_min_units() {
@@ -197,7 +198,8 @@ static inline bool is_dim_major(int n_cliques, int max_n, int max_D, int L, int 
     const long tiles = (long)((max_n + TILE - 1) / TILE) * n_cliques;
     // four waves' LDS rows + the weight panel must fit next to each other (160 KB per CU): D <= 96; wider cliques take
     // the tile-major kernels
-    return tile == TILE && L == 1 && dim_major_hidden(H) && dim_major_enabled() && max_D <= 96 &&
+    // (H = 16: D <= 80 -- the panel and the h1 rows are twice as big)
+    return tile == TILE && L == 1 && dim_major_hidden(H) && dim_major_enabled() && max_D <= (H == 16 ? 80 : 96) &&
            tiles * max_D > dim_major_min_units();
 }
 
@@ -227,6 +229,7 @@ static inline int tiles_per_block(int n_cliques, int max_n, int max_D, int L, in
         while (T < 8 && waves(T) > (T < 4 ? 6144 : 12288)) T *= 2;
         return T;
     }
+    if (!use_mfma_grad(H)) return 1;             // nsf_train_kernel sweeps several tiles per block on its MFMA gradient path only
     if (tiles <= 256) return 1;                  // nsf_train_kernel spreads the dims over grid.z there: one tile per block
     if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 8) return atoi(e);
     const int W = max_D < 4 ? max_D : 4;

@@ -670,7 +670,7 @@ struct Train1Few { nfisam_clique c[TRAIN1_KERNARG_CLIQUES]; };
 constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);   // kernel-argument offset of `few` (asserted on the host)
 
 template <int K, int H>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(H == 16 ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
@@ -678,7 +678,8 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
     constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
-    static_assert((H == 8 || H == 4) && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H <= 8");
+    static_assert((H == 16 || H == 8 || H == 4) && NT <= 4, "H <= 8: ga2|ga1 share one 16-row operand tile; H = 16: one tile each, bias chains");
+    constexpr bool WIDE_H = (H == 16);                        // no spare column for the bias in [h | 1]: db2 / db1 come from chains against a constant 1
     constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -762,8 +763,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
 #endif
     f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cb2[NT], cb1 = {0.f, 0.f, 0.f, 0.f};                 // WIDE_H only
 #pragma unroll
-    for (int t = 0; t < NT; ++t) cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) { cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float r0 = 0.0f, lossv = 0.0f;
 
     // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
@@ -903,12 +905,19 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 if (t == 2 && NT > 2) lds_rows_store<0, 16, 32, PoP>(stg_lane, gth);
                 if (t == 3 && NT > 3) lds_rows_store<0, 16, 48, PoP>(stg_lane, gth);
                 if (t == NT) {
-                    lds_rows_store<0, H, 0, H>(stg_lane, ga2);
-                    lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                    if constexpr (WIDE_H) {
+                        lds_rows_store<0, 16, 0, H>(stg_lane, ga2);
+                    } else {
+                        lds_rows_store<0, H, 0, H>(stg_lane, ga2);
+                        lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) cacc[t - 1] = mfma4(areg[s4], breg[s4], cacc[t - 1]);
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    cacc[t - 1] = mfma4(areg[s4], breg[s4], cacc[t - 1]);
+                    if constexpr (WIDE_H) cb2[t - 1] = mfma4(areg[s4], 1.0f, cb2[t - 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 wave_lds_sync();
                 if (t < NT) {
@@ -917,7 +926,28 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                     wave_lds_sync();
                 }
             }
-            if (merged) {
+            if constexpr (WIDE_H) {
+                // ga2 (16 rows) x [h1]: dW1t, and x 1: db1; then ga1 (16 rows) x [x_0 .. x_{i-1} | 1]: dW0t | db0
+                const float* pb1 = hrow + r16 * XS + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+                wave_lds_sync();
+                lds_rows_store<0, 16, 0, H>(stg_lane, ga1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    c1 = mfma4(areg[s4], pb1[4 * s4], c1);
+                    cb1 = mfma4(areg[s4], 1.0f, cb1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wave_lds_sync();
+                const float* pb0 = ((r16 < i) ? xt + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c0 = mfma4(areg[s4], pb0[4 * s4], c0);
+                }
+            } else if (merged) {
                 // i <= 16 - (H + 1): the columns [h1 (H) | 1 | x_0 .. x_{i-1}] of BOTH products fit one 16-column operand
                 // (they share the bias column): one MFMA chain instead of two.  Rows 0..H-1 (ga2) x columns 0..H give
                 // dW1t | db1, rows H.. (ga1) x columns H.. give db0 | dW0t; the cross terms are not used.
@@ -945,13 +975,13 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 f32x4 cx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) cx = mfma4(areg[s4], pb0[4 * s4], cx);
-                if (kq >= QH && kq < 2 * QH && cab <= i) {
-                    float* dst = &ctacc[(cab - 16) * H + 4 * (kq - QH)];
+                if ((WIDE_H || (kq >= QH && kq < 2 * QH)) && cab <= i) {
+                    float* dst = &ctacc[(cab - 16) * H + 4 * (WIDE_H ? kq : kq - QH)];
                     if (slab) {
                         if (tt > 0) { cx.x += dst[0]; cx.y += dst[1]; cx.z += dst[2]; cx.w += dst[3]; }
                         dst[0] = cx.x; dst[1] = cx.y; dst[2] = cx.z; dst[3] = cx.w;
                     } else {
-                        gsink4(&Gb[cab * H + 4 * (kq - QH)], cx, false);
+                        gsink4(&Gb[cab * H + 4 * (WIDE_H ? kq : kq - QH)], cx, false);
                     }
                 }
             }
@@ -976,7 +1006,15 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                     if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[r16 * PoP + 16 * t + 4 * kq] = cacc[t];
             }
             if (kq < QH && r16 <= H) *(f32x4*)&(frag + LY::oW1(i))[r16 * H + 4 * kq] = c1;
-            if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
+            if constexpr (WIDE_H) {                           // the bias rows (every column of a bias chain holds the same sums) + dW0t | db0
+                if (r16 == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[H * PoP + 16 * t + 4 * kq] = cb2[t];
+                    *(f32x4*)&(frag + LY::oW1(i))[H * H + 4 * kq] = cb1;
+                }
+                if (r16 <= i) *(f32x4*)&frag[r16 * H + 4 * kq] = c0;
+            } else if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
                 const int k0 = (r16 == H) ? i : r16 - (H + 1);
                 if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) *(f32x4*)&frag[k0 * H + 4 * (kq - QH)] = c1;
             } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
@@ -1006,7 +1044,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         gfloat* Gw = Gb + LY::oW2(i);
         {
             // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
-            constexpr int TOT = (H + 1) * PoP;
+            constexpr int TOT = (WIDE_H ? H : H + 1) * PoP;     // (H = 16: the bias row comes from its own chain, below)
             static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
             if (r16 <= H) {
 #pragma unroll
@@ -1024,7 +1062,15 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             }
         }
         if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
-        if (merged) {
+        if constexpr (WIDE_H) {
+            if (r16 == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[H * PoP + 16 * t + 4 * kq], cb2[t], false);
+                gsink4(&(Gb + LY::oW1(i))[H * H + 4 * kq], cb1, false);
+            }
+            if (r16 <= i) gsink4(&Gb[r16 * H + 4 * kq], c0, false);
+        } else if (merged) {
             const int k0 = (r16 == H) ? i : r16 - (H + 1);
             if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1, false);
         } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
@@ -2475,7 +2521,7 @@ struct PanelMap {
 };
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
-    if constexpr (HH == 8 || HH == 4) {
+    if constexpr (HH == 8 || HH == 4 || HH == 16) {
         if constexpr (HH == 8) {
             const int rc = PairMap<KK, HH>::get(nullptr, nullptr);
             if (rc) return rc;
@@ -2488,7 +2534,7 @@ static int unit_prepare(int max_D) {
 
 template <int KK, int HH>
 static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
-    if constexpr (HH != 8 && HH != 4) {
+    if constexpr (HH != 8 && HH != 4 && HH != 16) {
         return NFISAM_ERR_ARG;
     } else {
         // one wave = one dim x T tiles, dim-major blocks (nsf_train1_kernel)

@@ -1,7 +1,7 @@
 """One-off (GPU): cProfile of eight Plaza1 replicas in lock-step (first 40 updates)."""
 import cProfile, pstats, os, sys, io
 __file__ = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "scripts", "run_plaza1.py")
-sys.argv = ["run_plaza1.py", "40"]
+sys.argv = ["run_plaza1.py", os.environ.get("UPDATES", "40")]
 os.environ["REPLICAS"] = "8"; os.environ["EVERY"] = "1000"
 pr = cProfile.Profile()
 pr.enable()
@@ -11,5 +11,5 @@ except SystemExit:
     pass
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
+print(s.getvalue()[:16000])

@@ -595,15 +595,16 @@ def _train_ragged(shapes, iters, window, use_graph, K=9, H=8, B=5.0, lr=0.01):
                                                  ([(512, 6)], 7, 1), ([(700, 9), (640, 9)], 9, 4)],
                          ids=["plaza-clique", "ragged-batch", "chunks-of-one", "odd-chunks"])
 @pytest.mark.parametrize("use_graph", [True, False], ids=["hipgraph", "eager"])
-def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, iters, window, use_graph):
+@pytest.mark.parametrize("H", [8, 16], ids=["h8", "h16"])
+def test_fused_adam_launches_equal_the_separate_adam_kernel_bit_for_bit(shapes, iters, window, use_graph, H):
     """The Adam update applied at the start of the next gradient launch (nsf_cond_mfma.h; chunk-closing update by
     nsf_adam_kernel) leaves exactly the parameters and moments of gradient kernel + Adam kernel per iteration: full
     chunks, a final partial chunk (130 = 50 + 50 + 30), chunks of one, odd chunk lengths (the two state buffers
     alternate with the iteration's parity), ragged batches with D > 16 and a single-tile clique."""
     with _Env(NFISAM_FUSED_ADAM="0"):
-        d0, ref = _train_ragged(shapes, iters, window, use_graph)
+        d0, ref = _train_ragged(shapes, iters, window, use_graph, H=H)
     with _Env(NFISAM_FUSED_ADAM=None):
-        d1, got = _train_ragged(shapes, iters, window, use_graph)
+        d1, got = _train_ragged(shapes, iters, window, use_graph, H=H)
     assert d0 == d1 == [iters] * len(shapes)
     for name, a, b in zip(("theta", "m", "v"), ref[:3], got[:3]):
         for c, (x, y) in enumerate(zip(a, b)):
@@ -710,12 +711,15 @@ def test_wide_cliques_train_against_the_oracle(D):
     tb.close()
 
 
-def test_mfma_conditioner_matches_the_scalar_path_conditioner():
+@pytest.mark.parametrize("H", [8, 16])
+def test_mfma_conditioner_matches_the_scalar_path_conditioner(H):
     """Dim-major training kernel (conditioner as v_mfma_f32_4x4x1 chains fed from the LDS weight panel, panel staged
     through the host-built map) against the tile-major wide kernel (`NFISAM_DIM_MAJOR=0`: VALU conditioner with
-    scalar-path weights) -- same fp32 products, different summation order; shapes with one tile, partial tiles, D > 16."""
-    K, H, B = 9, 8, 5.0
-    for n, D in ((2000, 15), (333, 17), (64, 2), (1000, 24), (130, 1)):
+    scalar-path weights) -- same fp32 products, different summation order; shapes with one tile, partial tiles, D > 16.
+    hidden_dim 16: the dim-major kernel's own gradient path (ga2 and ga1 as separate operand tiles, db2 / db1 from chains
+    against a constant 1) against the wide kernel's butterfly reduction."""
+    K, B = 9, 5.0
+    for n, D in ((2000, 15), (333, 17), (64, 2), (1000, 24), (130, 1), (5000, 35)):
         blob, x = make_problem(n, D, K, H, 1, seed=77 + D)
         res = {}
         for mode in ("0", None):
@@ -727,7 +731,12 @@ def test_mfma_conditioner_matches_the_scalar_path_conditioner():
         a, b = res["0"], res[None]
         assert abs(a[0] - b[0]) < 2e-5 * max(1.0, abs(a[0])), (n, D, a[0], b[0])
         scale = max(1e-3, float(np.abs(a[2]).max()))
-        assert np.abs(a[2] - b[2]).max() < 2e-5 * scale, (n, D, np.abs(a[2] - b[2]).max(), scale)      # m_1 = 0.1 * gradient
+        # m_1 = 0.1 * gradient.  A particle whose coordinate sits on a knot may fall into neighbouring bins in the two kernels
+        # (different summation order in theta); that moves every parameter of ONE dim by ~1e-4 of the gradient scale
+        # (scripts/exp/h16_err.py: both kernels are equally far from the fp64 oracle there), so the bulk is held tightly and
+        # the tail loosely
+        d = np.abs(a[2] - b[2])
+        assert np.quantile(d, 0.95) < 2e-5 * scale and d.max() < 5e-4 * scale, (n, D, np.quantile(d, 0.95), d.max(), scale)
 
 
 @pytest.mark.parametrize("H", [4, 8, 16])
@@ -750,7 +759,7 @@ def test_every_kernel_instantiation_against_the_oracle(H):
             kg, _, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
             assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L, (K, H, L)
             grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3, atol=2e-5 * L)
-        # L = 1: inverse of forward, and the training path (the dim-major kernel for H = 8, the wide kernel otherwise)
+        # L = 1: inverse of forward, and the training path (the dim-major kernel: every hidden_dim)
         blob1, x1 = make_problem(n, D, K, H, 1, seed=17 * K + H + 1)
         kp1 = kpack(blob1, D, K, H, 1)
         xb = nh.inverse(nh.forward(dev(x1), kp1, K, H, B, 1)[0], None, kp1, K, H, B, 1)
@@ -766,11 +775,12 @@ def test_every_kernel_instantiation_against_the_oracle(H):
         tb.close()
 
 
-def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels():
+@pytest.mark.parametrize("H", [8, 16])
+def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels(H):
     """24 cliques of D = 18..20, n = 2000: the dim-major kernel sweeps several tiles per wave (T > 1) and accumulates the
     dW0 rows 16.. in its own LDS rows across them; first Adam moments (0.1 x gradient) and losses against the tile-major
     wide kernel (`NFISAM_DIM_MAJOR=0`), which shares no code with that path."""
-    K, H, B = 9, 8, 5.0
+    K, B = 9, 5.0
     shapes = [(2000, 18 + (c % 3)) for c in range(24)]
     res = {}
     for mode in ("0", None):
@@ -784,7 +794,8 @@ def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels():
             tb.close()
     for c, (a, b) in enumerate(zip(res["0"][0], res[None][0])):
         # (the dim-major kernel stages W0 / W1 pre-multiplied by 2 log2(e) for its tanh: products rounded once more)
-        assert np.abs(a - b).max() < 5e-5 * max(1e-3, np.abs(a).max()), (c, np.abs(a - b).max(), np.abs(a).max())
+        d, sc = np.abs(a - b), max(1e-3, np.abs(a).max())      # (bulk / tail: see test_mfma_conditioner_matches_the_scalar_path_conditioner)
+        assert np.quantile(d, 0.95) < 5e-5 * sc and d.max() < 5e-4 * sc, (c, np.quantile(d, 0.95), d.max(), sc)
     np.testing.assert_allclose(res["0"][1], res[None][1], rtol=2e-6, atol=1e-5)
 
 
@@ -843,3 +854,28 @@ def test_multilayer_training_follows_the_oracle():
         err, ref = np.abs(got - b64), np.abs(b32 - b64)
         assert np.quantile(err, 0.99) <= 3.0 * np.quantile(ref, 0.99) + 2e-3, (c, np.quantile(err, 0.99), np.quantile(ref, 0.99))
         assert err.max() < iters * 0.02 + 1e-3
+
+
+@pytest.mark.parametrize("H", [4, 16])
+def test_big_batches_of_other_hidden_widths_train_on_both_kernel_families(H):
+    """64 cliques of n = 2000: the launch-shape helpers (tiles per gradient copy, copies per workspace) must agree between
+    the gradient, Adam and bookkeeping launches for hidden widths 4 and 16 on the dim-major kernel AND on the tile-major
+    kernel they fall back to (`NFISAM_DIM_MAJOR=0`; H = 16 with D > 80): first loss and a 20-iteration descent of every
+    clique against a single-clique run of the same problem."""
+    K, B, n, D = 9, 5.0, 2000, 7
+    probs = [make_problem(n, D, K, H, 1, seed=1200 + c, spread=1.0) for c in range(64)]
+    single = nh.TrainBatch([dev(probs[5][1])], [kpack(probs[5][0], D, K, H)], K, H, B, 1, lr=0.01, max_iters=20, early_stop=False)
+    assert single.run(use_graph=True) == [20]
+    ref = single.iter_loss[0].cpu().numpy()[:20]
+    single.close()
+    for mode in ("0", None):
+        with _Env(NFISAM_DIM_MAJOR=mode):
+            tb = nh.TrainBatch([dev(x) for _, x in probs], [kpack(b, D, K, H) for b, _ in probs], K, H, B, 1, lr=0.01, max_iters=20,
+                               early_stop=False)
+            assert tb.run(use_graph=True) == [20] * 64
+            il = tb.iter_loss[5].cpu().numpy()[:20]
+            tb.close()
+        # (two kernel families = two summation orders: the trajectories drift apart by rounding, ~1e-2 after 20 iterations)
+        np.testing.assert_allclose(il[:5], ref[:5], rtol=1e-4, atol=5e-4, err_msg=str((H, mode)))
+        np.testing.assert_allclose(il, ref, atol=3e-2, err_msg=str((H, mode)))
+        assert il[19] < il[0] - 1.0

@@ -650,7 +650,7 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
     const size_t Pmax = (size_t)L * kcount(max_D, K, H);
     int ablocks = (int)((Pmax + 31) / 32);
     if (ablocks < 1) ablocks = 1;
-    if (ablocks > 256) ablocks = 256;
+    if (ablocks > 1024) ablocks = 1024;   // one pass for up to 32 k parameters (C2: 275 blocks; a second pass is a second memory round trip)
     ad.few_copies = (ad.slab != 0 && (max_n + ad.slab - 1) / ad.slab <= 8) ? 1 : 0;
     if (ad.few_copies) ablocks = (int)((Pmax + 255) / 256);
     hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
@@ -683,7 +683,7 @@ static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_cliq
         ad.few_copies = ((max_n + ad.slab - 1) / ad.slab <= 8) ? 1 : 0;
         int ablocks = ad.few_copies ? (int)((Pmax + 255) / 256) : (int)((Pmax + 31) / 32);
         if (ablocks < 1) ablocks = 1;
-        if (ablocks > 256) ablocks = 256;
+        if (ablocks > 1024) ablocks = 1024;
         hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
         HIP_TRY(hipGetLastError());
     }

@@ -1567,6 +1567,9 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
             const int e = lane + 64 * u;
             if (64 * u < D * TILE2) xv[u] = xt[e < lim ? e : 0];        // (wave-uniform guard; rows past n are zeroed below)
         }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(14);
+#endif
         if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
             const int j = w;
             if (a.pair_image)
@@ -1576,8 +1579,14 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
         }
         // the state words were requested at kernel entry and are LOOKED AT only now, behind the prologue's own loads (the
         // empty asm is a use in front of the branch: the compiler does not pull the wait up to the loads)
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(3);
+#endif
         asm volatile("" : "+v"(st_stop), "+v"(st_step));
         if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return;      // block-uniform
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(15);
+#endif
         const float invD = 1.0f / (float)D;
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
@@ -1737,11 +1746,18 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 c1[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 c0[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            // A generation of the 16 staging rows is read into registers completely; the NEXT one is written and its reads are
+            // issued BEFORE this one's MFMAs, so that the LDS round trip runs under the 16 x 32 MFMA cycles (a lone wave per
+            // SIMD has nothing else to hide it under); the last chains' second operands are requested the same way.
+            const bool merged = (imax <= 16 - (H + 1));
             lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
             wave_lds_sync();
 #pragma unroll
             for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
             wave_lds_sync();
+            float anext[NS], bm[NS];
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) bm[s4] = 0.0f;
 #pragma unroll
             for (int t = 1; t <= NT; ++t) {
                 if (t == 1 && NT > 1) lds_rows_store<0, 16, 16, PoP>(stg_lane, gth);
@@ -1751,34 +1767,33 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                     lds_rows_store<0, H, 0, H>(stg_lane, ga2);
                     lds_rows_store<H, H, 0, H>(stg_lane, ga1);
                 }
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) anext[s4] = pa[4 * s4];
+                if (t == NT && merged) {
+                    // columns [h1 (H) | 1 | x_0 .. x_{i-1}] of both products in one 16-column operand (see nsf_train1_kernel)
+                    const int kx = r16 - (H + 1);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int ih = 2 * j + hb;
+                        const bool one = (r16 == H) || kx >= ih;
+                        const float* pbm = (one ? ones : ((r16 < H) ? hrow + r16 * XS + 32 * hb : xin + kx * XS2)) + kq;
+#pragma unroll
+                        for (int s = 0; s < NSH; ++s) bm[hb * NSH + s] = pbm[4 * s];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) cacc[s4 / NSH][t - 1] = mfma4(areg[s4], breg[s4], cacc[s4 / NSH][t - 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 wave_lds_sync();
-                if (t < NT) {
 #pragma unroll
-                    for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
-                    wave_lds_sync();
-                }
+                for (int s4 = 0; s4 < NS; ++s4) areg[s4] = anext[s4];
             }
             STAMP(7);
-            const bool merged = (imax <= 16 - (H + 1));
             if (merged) {
-                // columns [h1 (H) | 1 | x_0 .. x_{i-1}] of both products in one 16-column operand (see nsf_train1_kernel)
-                const int kx = r16 - (H + 1);
-                const float* pbm[2];
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    const int ih = 2 * j + hb;
-                    const bool one = (r16 == H) || kx >= ih;
-                    pbm[hb] = (one ? ones : ((r16 < H) ? hrow + r16 * XS + 32 * hb : xin + kx * XS2)) + kq;
-                }
-#pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) {
-                    areg[s4] = pa[4 * s4];
-                    c1[s4 / NSH] = mfma4(areg[s4], pbm[s4 / NSH][4 * (s4 % NSH)], c1[s4 / NSH]);
-                }
+                for (int s4 = 0; s4 < NS; ++s4) c1[s4 / NSH] = mfma4(areg[s4], bm[s4], c1[s4 / NSH]);
             } else {
                 const float* pb0[2];
                 const float* pb1[2];
@@ -1790,7 +1805,6 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) {
-                    areg[s4] = pa[4 * s4];
                     c1[s4 / NSH] = mfma4(areg[s4], pb1[s4 / NSH][4 * (s4 % NSH)], c1[s4 / NSH]);
                     c0[s4 / NSH] = mfma4(areg[s4], pb0[s4 / NSH][4 * (s4 % NSH)], c0[s4 / NSH]);
                 }
@@ -2412,8 +2426,12 @@ static size_t pair_kernel_lds(int L, int max_D) {
     if constexpr (HH != 8) {
         return 0;
     } else {
+        // Narrow cliques stay with nsf_train2_kernel: up to four dims are one wave per SIMD there too, and its units get
+        // cheaper with the dim (measured, us per iteration split / pair: D 3, L 4: 28.8 / 30.6; D 4: 30.8 / 31.3; D 5: 33.9 /
+        // 33.6; D 6 (C2): 39.1 / 34.1; D 8, L 3: 36.5 / 31.1).  NFISAM_PAIR=0 | 1 forces one of them (A/B, tests).
         const char* pe = getenv("NFISAM_PAIR");
-        if ((pe != nullptr && pe[0] == '0') || max_D > PAIR_MAX_D || max_D < 1) return 0;
+        const int min_D = (pe != nullptr && pe[0] == '1') ? 1 : 6;
+        if ((pe != nullptr && pe[0] == '0') || max_D > PAIR_MAX_D || max_D < min_D) return 0;
         const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
         const size_t fl = (size_t)pair_tile_floats(L, max_D, 1) + (size_t)W * PAIR_WAVE_FLOATS +
                           (size_t)L * max_D * PairPanel<KK, HH>::floats(max_D);

@@ -25,7 +25,7 @@ assert nh.lib().nfisam_debug_read_stamps(buf) == 0
 st = np.array(buf[:], dtype=np.int64).reshape(64, 32)
 for w in range((D + 1) // 2):
     t = st[w]
-    ev = [("prologue", t[1])] + [("fwd L%d" % l, t[16 + l]) for l in range(L - 1)] + [("bwd L%d" % l, t[24 + l]) for l in range(L - 1, -1, -1)] + [("end", t[9])]
+    ev = [("args+issue", t[14]), ("panels", t[3]), ("state", t[15]), ("x tile -> prologue end", t[1])] + [("fwd L%d" % l, t[16 + l]) for l in range(L - 1)] + [("bwd L%d" % l, t[24 + l]) for l in range(L - 1, -1, -1)] + [("end", t[9])]
     prev, out = t[0], []
     for name, v in ev:
         out.append("%s=%d" % (name, v - prev)); prev = v

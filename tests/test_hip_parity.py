@@ -530,31 +530,33 @@ def test_kernel_families_agree_on_random_shapes():
             blob, x = make_problem(n, D, K, H, L, seed=1000 + case)
             kp = kpack(blob, D, K, H, L)
             res = {}
-            for fam in ("split", "wide"):
-                os.environ["NFISAM_TRAIN"] = fam
+            for fam in ("split", "pair", "wide"):       # pair = nsf_train3_kernel forced on every shape it can hold (default: D >= 6)
+                os.environ["NFISAM_TRAIN"] = "wide" if fam == "wide" else "split"
+                os.environ["NFISAM_PAIR"] = "1" if fam == "pair" else "0"
                 kg, gx, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
                 tb = nh.TrainBatch([dev(x)], [kp.clone()], K, H, B, L, lr=0.01, max_iters=2, early_stop=False)
                 tb.step()
                 torch.cuda.synchronize()
                 res[fam] = (nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gx.cpu().numpy() / n, loss.item() / n,
                             float(tb.iter_loss[0][0]), nh.unpack(tb.kparams[0], D, K, H, L).cpu().numpy())
-            a, b = res["split"], res["wide"]
-            scale = max(1.0, float(np.abs(b[0]).max()))
-            assert np.abs(a[0] - b[0]).max() < 6e-5 * L * scale, (case, n, D, K, L)
-            # dL/dx is per particle: a particle whose intermediate z sits on a knot may fall into neighbouring bins in the
-            # two kernels (the slope of log dz/dx jumps there), so the bulk is checked tightly and the tail loosely
-            gx_err, gx_max = np.abs(a[1] - b[1]), max(1.0, float(np.abs(b[1]).max()))
-            assert np.quantile(gx_err, 0.98) < 6e-5 * L * gx_max and gx_err.max() < 0.05 * gx_max, (case, n, D, K, L)
-            assert abs(a[2] - b[2]) < 2e-4 * L and abs(a[3] - b[3]) < 3e-4 * L, (case, a[2], b[2], a[3], b[3])
-            # one Adam step from identical gradients (up to rounding): parameters move by +-lr at most, equally
-            assert np.quantile(np.abs(a[4] - b[4]), 0.98) < 2e-3, (case, n, D, K, L)
-            if n * D * L <= 4000:
-                lossc, gradc, _, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
-                assert abs(a[2] + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L
-                grad_close(a[0], gradc, rtol=2e-3, atol=2e-5 * L)
-                ex = np.abs(a[1] - gxc)
-                assert np.quantile(ex, 0.98) < 2e-3 * np.abs(gxc).max() + 2e-5 * L and ex.max() < 0.05 * max(1.0, np.abs(gxc).max())
+            for a, b in ((res["split"], res["wide"]), (res["pair"], res["wide"])):
+                scale = max(1.0, float(np.abs(b[0]).max()))
+                assert np.abs(a[0] - b[0]).max() < 6e-5 * L * scale, (case, n, D, K, L)
+                # dL/dx is per particle: a particle whose intermediate z sits on a knot may fall into neighbouring bins in the
+                # two kernels (the slope of log dz/dx jumps there), so the bulk is checked tightly and the tail loosely
+                gx_err, gx_max = np.abs(a[1] - b[1]), max(1.0, float(np.abs(b[1]).max()))
+                assert np.quantile(gx_err, 0.98) < 6e-5 * L * gx_max and gx_err.max() < 0.05 * gx_max, (case, n, D, K, L)
+                assert abs(a[2] - b[2]) < 2e-4 * L and abs(a[3] - b[3]) < 3e-4 * L, (case, a[2], b[2], a[3], b[3])
+                # one Adam step from identical gradients (up to rounding): parameters move by +-lr at most, equally
+                assert np.quantile(np.abs(a[4] - b[4]), 0.98) < 2e-3, (case, n, D, K, L)
+                if n * D * L <= 4000:
+                    lossc, gradc, _, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+                    assert abs(a[2] + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L
+                    grad_close(a[0], gradc, rtol=2e-3, atol=2e-5 * L)
+                    ex = np.abs(a[1] - gxc)
+                    assert np.quantile(ex, 0.98) < 2e-3 * np.abs(gxc).max() + 2e-5 * L and ex.max() < 0.05 * max(1.0, np.abs(gxc).max())
     finally:
+        os.environ.pop("NFISAM_PAIR", None)
         if old is None:
             os.environ.pop("NFISAM_TRAIN", None)
         else:

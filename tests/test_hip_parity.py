@@ -697,11 +697,11 @@ def test_parallel_graph_branches_leave_the_same_bits(chains):
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("D", [64, 96, 100, 130])
-def test_wide_cliques_train_against_the_oracle(D):
-    """Very wide cliques: up to D = 96 the dim-major kernel (its LDS rows grow with D), beyond it the tile-major kernels;
-    three training iterations against the float64 oracle either way."""
-    K, H, B, n = 5, 8, 5.0, 130
+@pytest.mark.parametrize("D,H", [(64, 8), (96, 8), (100, 8), (130, 8), (80, 16), (81, 16)])
+def test_wide_cliques_train_against_the_oracle(D, H):
+    """Very wide cliques: up to D = 96 (hidden_dim 16: D = 80) the dim-major kernel (its LDS rows grow with D), beyond it the
+    tile-major kernels; three training iterations against the float64 oracle either way."""
+    K, B, n = 5, 5.0, 130
     blob, x = make_problem(n, D, K, H, 1, seed=D, spread=1.0)
     tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, 1)], K, H, B, 1, lr=0.01, max_iters=3, average_window=3,
                        loss_delta_tol=0.0, early_stop=True)
@@ -881,3 +881,23 @@ def test_big_batches_of_other_hidden_widths_train_on_both_kernel_families(H):
         np.testing.assert_allclose(il[:5], ref[:5], rtol=1e-4, atol=5e-4, err_msg=str((H, mode)))
         np.testing.assert_allclose(il, ref, atol=3e-2, err_msg=str((H, mode)))
         assert il[19] < il[0] - 1.0
+
+
+def test_multilayer_launch_beyond_the_slab_limit_uses_atomics_and_still_trains():
+    """n = 5000, D = 6, L = 2: 157 tiles of 32 -- more than the 128 gradient copies a workspace holds, so the multi-layer kernel
+    accumulates into ONE copy with float atomics (order-dependent rounding) while the panel image and the parked forward
+    state work as in the slab case; ten iterations against the split kernel (`NFISAM_PAIR=0`) and the float64 oracle."""
+    K, H, B, L, n, D, iters = 9, 8, 5.0, 2, 5000, 6, 10
+    blob, x = make_problem(n, D, K, H, L, seed=4242, spread=1.0)
+    res = {}
+    for pair in ("0", None):
+        with _Env(NFISAM_PAIR=pair):
+            tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, L)], K, H, B, L, lr=0.01, max_iters=iters, early_stop=False)
+            assert tb.run(use_graph=True) == [iters]
+            res[pair] = (tb.iter_loss[0].cpu().numpy()[:iters].astype(np.float64), nh.unpack(tb.kparams[0], D, K, H, L).cpu().numpy())
+            tb.close()
+    b64, l64, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.01, max_iters=iters, early_stop=False, dtype=np.float64)
+    for pair in ("0", None):
+        np.testing.assert_allclose(res[pair][0][:4], l64[:4], atol=2e-4, rtol=1e-5, err_msg=str(pair))
+        np.testing.assert_allclose(res[pair][0], l64, atol=2e-2, err_msg=str(pair))       # (fp32 vs fp64 trajectories drift: 6e-3 after 9 iterations)
+        assert np.quantile(np.abs(res[pair][1] - b64), 0.98) < 3e-3, pair

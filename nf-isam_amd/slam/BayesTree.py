@@ -21,6 +21,7 @@ class BayesTreeNode(object):
         else:
             raise ValueError("The frontal must be either the set of all frontal variables, or a frontal variable")
         self.separator = set(separator) if separator else set()
+        self._hash = None               # cached __hash__ (the Bayes-tree bookkeeping hashes a clique ~1000 times per update)
         self.parent = parent
         self.children: List["BayesTreeNode"] = list(children) if children else []
 
@@ -38,6 +39,7 @@ class BayesTreeNode(object):
 
     def add_frontal(self, frontal: Variable) -> "BayesTreeNode":
         self.frontal.add(frontal)
+        self._hash = None
         return self
 
     def remove_child(self, child: "BayesTreeNode") -> "BayesTreeNode":
@@ -88,8 +90,12 @@ class BayesTreeNode(object):
         return isinstance(other, BayesTreeNode) and self.frontal == other.frontal and self.separator == other.separator
 
     def __hash__(self) -> int:
-        # order-independent over the two variable sets (consistent with __eq__); no sorting, no strings
-        return hash(frozenset(self.frontal)) ^ (hash(frozenset(self.separator)) * 1000003)
+        # order-independent over the two variable sets (consistent with __eq__); no sorting, no strings.  The sets are only
+        # ever changed through add_frontal (which drops the cached value) -- and never while the clique is a dict key.
+        h = self._hash
+        if h is None:
+            h = self._hash = hash(frozenset(self.frontal)) ^ (hash(frozenset(self.separator)) * 1000003)
+        return h
 
 
 class BayesTree(object):

@@ -458,7 +458,7 @@ class NFiSAM(FactorGraphSolver):
         model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, prep["circular"],
                                                   prep["means"], prep["stds"])
         clique_name = ''.join([str(var.name) for var in prep["clique"].vars])
-        self._temp_training_loss[clique_name] = [float(v) for v in prep["iter_loss"].cpu().numpy().astype(np.float64)]
+        self._temp_training_loss[clique_name] = prep["iter_loss"].cpu().numpy().astype(np.float64).tolist()
         self.last_fit_iterations = prep["iters"]
         self.last_fit_retried = bool(prep.get("retried", False))
         return model

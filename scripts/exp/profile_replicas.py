@@ -11,5 +11,5 @@ except SystemExit:
     pass
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
+pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(70)
 print(s.getvalue()[:16000])

@@ -294,6 +294,34 @@ int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam
 int nfisam_nsf_train_plan_run(nfisam_train_plan* plan, int32_t* iters_run, nfisam_stream_t stream);
 int nfisam_nsf_train_plan_destroy(nfisam_train_plan* plan);
 
+/* Stepping a graph plan by hand (ABI 1320; the slot scheduler of slam/ReplicaNFiSAM.py: independent runs whose cliques
+ * enter and leave ONE batched launch sequence as they finish -- the reference trains the cliques of its eight dataset
+ * variants one after the other, example/slam/plaza_dataset/run_nfisam.py:11-21):
+ *   begin    orders the plan's stream behind `stream` and restarts the chunk count of the host mirror;
+ *   enqueue  appends ONE chunk of `average_window` iterations (non-blocking: enqueue a few ahead);
+ *   peek     copies the host mirror, out[n_cliques]: each clique's state as of the last chunk closed and, in
+ *            reserved[0], the number of chunks closed since `begin` (-1: a chunk closed during the copy, look again);
+ *   stream   the plan's stream: a clique that has stopped (or reached max_iters) is not written by any launch any more,
+ *            so the caller may re-initialise its slot for a NEW problem of the same (n, D) -- batch, parameters, zeroed
+ *            moments / workspace / loss record and, LAST, the zeroed state -- with copies enqueued on this stream, i.e.
+ *            between two chunks;
+ *   refill   does exactly that for slot `clique` from the caller's device buffers x [n,D] / kparams (ordered behind
+ *            `stream`; they must stay alive until the copies have run);
+ *   feed     a thread of the library keeps `depth` chunks enqueued ahead of the last one closed, so that the caller's
+ *            thread never sits in the graph launch (~0.3 ms per chunk); depth 0 pauses it (returns once it is outside a
+ *            launch); `enqueued` = chunks enqueued since `begin`: a slot refilled when this read E trains from chunk
+ *            E + 1 on at the latest, i.e. its mirror entry is its own once more than E chunks have closed;
+ *   end      pauses the feeder and orders `stream` behind everything enqueued on the plan.                */
+int nfisam_nsf_train_plan_begin(nfisam_train_plan* plan, nfisam_stream_t stream);
+int nfisam_nsf_train_plan_enqueue(nfisam_train_plan* plan);
+int nfisam_nsf_train_plan_feed(nfisam_train_plan* plan, int depth);
+long nfisam_nsf_train_plan_enqueued(const nfisam_train_plan* plan);
+int nfisam_nsf_train_plan_peek(const nfisam_train_plan* plan, nfisam_train_state* out);
+nfisam_stream_t nfisam_nsf_train_plan_stream(nfisam_train_plan* plan);
+int nfisam_nsf_train_plan_refill(nfisam_train_plan* plan, int clique, const float* x, const float* kparams,
+                                 nfisam_stream_t stream);
+int nfisam_nsf_train_plan_end(nfisam_train_plan* plan, nfisam_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,10 @@
 // kernels that do not depend on (K, H) at compile time: Adam, per-chunk bookkeeping (loss record + window early stop),
 // training-batch normalisation, the elementwise spline of `flows.utils`.  The (K, H)-templated kernels live in the
 // kernel units (nsf_unit.hip, nsf_units.h) and are reached through `NsfUnitOps`.  Written for CDNA4 only.
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <time.h>
 #include <vector>
 
 #include "nsf_host.h"
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-extern "C" int nfisam_abi_version(void) { return 1310; }
+extern "C" int nfisam_abi_version(void) { return 1320; }
 extern "C" int nfisam_last_hip_error(void) { return nfisam_g_last_hip_error; }
 
 // (K, H) -> launchers of the kernel unit that instantiates the pair (nsf_units.h), nullptr if none does
@@ -790,15 +794,38 @@ struct nfisam_train_plan {
                                            // writes it (last word written: reserved[0] = chunks closed in this run)
     nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
     bool ahead = false;                    // the previous run left a chunk enqueued behind its early stop
+    // hand-stepped runs (nfisam_nsf_train_plan_begin ..): a feeder thread keeps `feed_depth` chunks enqueued ahead of the
+    // last one closed, so that the caller's thread (Python, in the replica scheduler) never sits in hipGraphLaunch
+    int device = 0;
+    std::thread feeder;
+    std::atomic<int> feed_depth{0};        // 0: paused
+    std::atomic<int> feed_busy{0};         // the feeder is inside a launch
+    std::atomic<int> feed_quit{0};
+    std::atomic<int> feed_error{0};
+    std::atomic<long> enqueued{0};         // chunks enqueued since `begin`
+    std::atomic<int> refills{0};           // slots refilled since the feeder's last launch (their mirror entries still say "stopped")
+    std::vector<hipEvent_t> slot_ev;       // nfisam_nsf_train_plan_refill: orders a slot's copies behind the caller's stream
+    hipEvent_t ev_end = nullptr;           // `end` records this one: the caller's stream may still hold the wait on it when the next
+                                           // `begin` records p->ev -- re-recording an event a stream still waits for ties that wait to
+                                           // the NEW record on this runtime (the stream then waits for itself)
+    std::mutex enqueue_mu;                 // a chunk's graph launch and a slot's refill must not interleave on the stream: a graph
+                                           // launch is not one atomic enqueue for a second thread (a state reset landed mid-chunk)
 };
 
 extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p == nullptr) return NFISAM_OK;
+    if (p->feeder.joinable()) {
+        p->feed_depth.store(0);
+        p->feed_quit.store(1);
+        p->feeder.join();
+    }
     if (p->cap) (void)hipStreamSynchronize(p->cap);       // a chunk enqueued ahead of an early stop may still be draining
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->ev) (void)hipEventDestroy(p->ev);
     for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
+    if (p->ev_end) (void)hipEventDestroy(p->ev_end);
     for (hipStream_t st : p->side) (void)hipStreamDestroy(st);
     if (p->cap) (void)hipStreamDestroy(p->cap);
     if (p->hst) (void)hipHostFree(p->hst);
@@ -817,6 +844,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     p->host.assign(host_cliques, host_cliques + n_cliques);
     p->dev = dev_cliques;
     p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
+    (void)hipGetDevice(&p->device);
     p->chunk = chunk_length(cfg);
     if (hipHostMalloc((void**)&p->hst, sizeof(nfisam_train_state) * (size_t)n_cliques,
                       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -987,6 +1015,132 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     }
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;
+}
+
+// ---- stepping a plan by hand (slam.ReplicaNFiSAM's slot scheduler) ---------------------------------------------------------
+// A graph plan as a conveyor of chunks: the caller enqueues chunks ahead, looks at the host mirror without blocking, and
+// swaps a finished clique's slot for a new problem BETWEEN chunks by enqueueing the re-initialisation (new batch, fresh
+// parameters, zeroed moments / state / loss record) on the plan's own stream.  A stopped clique's launches exit early and
+// nothing writes its buffers, so the slot may wait any number of chunks for its refill.
+extern "C" int nfisam_nsf_train_plan_begin(nfisam_train_plan* p, nfisam_stream_t stream) {
+    if (p == nullptr || p->exec == nullptr) return NFISAM_ERR_ARG;
+    if (p->feeder.joinable()) {                          // (a feeder left running by a caller that skipped `end`)
+        p->feed_depth.store(0);
+        while (p->feed_busy.load() != 0) __builtin_ia32_pause();
+    }
+    hipStream_t user = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(p->ev, user));              // order after prior work on the caller's stream
+    HIP_TRY(hipStreamWaitEvent(p->cap, p->ev, 0));
+    if (p->ahead) { HIP_TRY(hipStreamSynchronize(p->cap)); p->ahead = false; }
+    for (int c = 0; c < p->n_cliques; ++c) p->hst[c].reserved[0] = 0;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    p->enqueued.store(0);
+    p->refills.store(0);
+    p->feed_error.store(0);
+    return NFISAM_OK;
+}
+extern "C" int nfisam_nsf_train_plan_enqueue(nfisam_train_plan* p) {
+    if (p == nullptr || p->exec == nullptr) return NFISAM_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->enqueue_mu);
+    const hipError_t e = hipGraphLaunch(p->exec, p->cap);
+    if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+    p->ahead = true;                                   // (until `end` has seen the stream drained)
+    p->enqueued.fetch_add(1);
+    return NFISAM_OK;
+}
+// Feeder: keeps `depth` chunks enqueued ahead of the last one closed (depth 0 pauses it; the call returns once the feeder
+// is outside hipGraphLaunch).  Launching a chunk's graph costs ~0.3 ms of host time per 0.8 ms of device time.
+static void feeder_main(nfisam_train_plan* p) {
+    (void)hipSetDevice(p->device);
+    const struct timespec nap = {0, 20000};
+    while (p->feed_quit.load() == 0) {
+        const int depth = p->feed_depth.load();
+        if (depth > 0 && p->feed_error.load() == 0) {
+            const volatile nfisam_train_state* m = p->hst;
+            const long closed = m[0].reserved[0];
+            // a chunk is worth launching while some slot trains: as of the last closed chunk, or refilled since the last launch
+            bool work = p->refills.load() > 0;
+            for (int c = 0; c < p->n_cliques && !work; ++c) work = (m[c].stop == 0 && m[c].step < p->cfg.max_iters);
+            if (work && p->enqueued.load() - closed < depth) {
+                p->feed_busy.store(1);
+                if (p->feed_depth.load() > 0) {          // (a pause that arrived meanwhile wins)
+                    std::lock_guard<std::mutex> lk(p->enqueue_mu);
+                    p->refills.store(0);
+                    const hipError_t e = hipGraphLaunch(p->exec, p->cap);
+                    if (e != hipSuccess) p->feed_error.store((int)e);
+                    else { p->ahead = true; p->enqueued.fetch_add(1); }
+                }
+                p->feed_busy.store(0);
+            }
+        }
+        nanosleep(&nap, nullptr);                        // (also lets a refill waiting for the lock go first)
+    }
+}
+extern "C" int nfisam_nsf_train_plan_feed(nfisam_train_plan* p, int depth) {
+    if (p == nullptr || p->exec == nullptr || depth < 0) return NFISAM_ERR_ARG;
+    if (p->feed_error.load() != 0) { nfisam_g_last_hip_error = p->feed_error.load(); return NFISAM_ERR_LAUNCH; }
+    p->feed_depth.store(depth);
+    if (depth > 0 && !p->feeder.joinable()) p->feeder = std::thread(feeder_main, p);
+    if (depth == 0)
+        while (p->feed_busy.load() != 0) __builtin_ia32_pause();
+    return NFISAM_OK;
+}
+extern "C" long nfisam_nsf_train_plan_enqueued(const nfisam_train_plan* p) { return p != nullptr ? p->enqueued.load() : 0; }
+// Slot c gets a new problem of the same shape: batch and parameters copied from the caller's buffers (ordered behind
+// `stream`), moments / workspace / loss record and -- last -- the state zeroed, all on the plan's stream, i.e. between chunks.
+extern "C" int nfisam_nsf_train_plan_refill(nfisam_train_plan* p, int c, const float* x, const float* kparams,
+                                            nfisam_stream_t stream) {
+    if (p == nullptr || p->exec == nullptr || c < 0 || c >= p->n_cliques || x == nullptr || kparams == nullptr) return NFISAM_ERR_ARG;
+    const nfisam_clique& q = p->host[(size_t)c];
+    std::lock_guard<std::mutex> lk(p->enqueue_mu);
+    // (the slot's own event: p->ev belongs to begin / end)
+    if (p->slot_ev.size() != (size_t)p->n_cliques) p->slot_ev.assign((size_t)p->n_cliques, nullptr);
+    if (p->slot_ev[(size_t)c] == nullptr) HIP_TRY(hipEventCreateWithFlags(&p->slot_ev[(size_t)c], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->slot_ev[(size_t)c], (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(p->cap, p->slot_ev[(size_t)c], 0));
+    const size_t pk = (size_t)p->L * kcount(q.D, p->K, p->H) * sizeof(float);
+    HIP_TRY(hipMemcpyAsync((void*)q.x, x, (size_t)q.n * q.D * sizeof(float), hipMemcpyDeviceToDevice, p->cap));
+    HIP_TRY(hipMemcpyAsync(q.kparams, kparams, pk, hipMemcpyDeviceToDevice, p->cap));
+    HIP_TRY(hipMemsetAsync(q.adam_m, 0, pk, p->cap));
+    HIP_TRY(hipMemsetAsync(q.adam_v, 0, pk, p->cap));
+    HIP_TRY(hipMemsetAsync(q.kgrad, 0, nfisam_nsf_grad_workspace_count(p->max_n, q.D, p->K, p->H, p->L) * sizeof(float), p->cap));
+    HIP_TRY(hipMemsetAsync(q.iter_loss, 0, (size_t)(p->cfg.max_iters > 0 ? p->cfg.max_iters : 1) * sizeof(float), p->cap));
+    HIP_TRY(hipMemsetAsync(q.state, 0, sizeof(nfisam_train_state), p->cap));
+    p->refills.fetch_add(1);
+    return NFISAM_OK;
+}
+extern "C" int nfisam_nsf_train_plan_peek(const nfisam_train_plan* p, nfisam_train_state* out) {
+    if (p == nullptr || out == nullptr) return NFISAM_ERR_ARG;
+    if (p->feed_error.load() != 0) { nfisam_g_last_hip_error = p->feed_error.load(); return NFISAM_ERR_LAUNCH; }   // the feeder's launch failed
+    const volatile nfisam_train_state* m = p->hst;
+    for (int c = 0; c < p->n_cliques; ++c) {
+        // the sequence word is written last (system-scope release): read it first, the state behind an acquire fence, and
+        // again -- a chunk closing in between gives a torn copy that the next look repairs, so it is reported as not closed
+        const int s0 = m[c].reserved[0];
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        nfisam_train_state t;
+        t.step = m[c].step; t.stop = m[c].stop; t.have_avg = m[c].have_avg; t.loss_avg = m[c].loss_avg; t.domain_err = m[c].domain_err;
+        memset(t.reserved, 0, sizeof(t.reserved));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        t.reserved[0] = (m[c].reserved[0] == s0) ? s0 : -1;
+        out[c] = t;
+    }
+    return NFISAM_OK;
+}
+extern "C" nfisam_stream_t nfisam_nsf_train_plan_stream(nfisam_train_plan* p) {
+    return p != nullptr ? (nfisam_stream_t)p->cap : nullptr;
+}
+extern "C" int nfisam_nsf_train_plan_end(nfisam_train_plan* p, nfisam_stream_t stream) {
+    if (p == nullptr || p->exec == nullptr) return NFISAM_ERR_ARG;
+    if (p->feeder.joinable()) {                          // pause the feeder (it stays for the next `begin`)
+        p->feed_depth.store(0);
+        while (p->feed_busy.load() != 0) __builtin_ia32_pause();
+    }
+    hipStream_t user = (hipStream_t)stream;
+    if (p->ev_end == nullptr) HIP_TRY(hipEventCreateWithFlags(&p->ev_end, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->ev_end, p->cap));        // the caller's stream continues behind everything enqueued here
+    HIP_TRY(hipStreamWaitEvent(user, p->ev_end, 0));
+    return NFISAM_OK;
 }
 
 extern "C" int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,

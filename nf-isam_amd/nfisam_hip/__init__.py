@@ -23,6 +23,8 @@ EXPORTS = [
     "nfisam_nsf_kparam_count", "nfisam_nsf_layout_map", "nfisam_nsf_forward", "nfisam_nsf_inverse",
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
+    "nfisam_nsf_train_plan_begin", "nfisam_nsf_train_plan_enqueue", "nfisam_nsf_train_plan_peek", "nfisam_nsf_train_plan_stream",
+    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
     "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
@@ -79,6 +81,8 @@ def lib():
         _lib.nfisam_nsf_param_count.restype = C.c_size_t
         _lib.nfisam_nsf_kparam_count.restype = C.c_size_t
         _lib.nfisam_nsf_grad_workspace_count.restype = C.c_size_t
+        _lib.nfisam_nsf_train_plan_stream.restype = C.c_void_p
+        _lib.nfisam_nsf_train_plan_enqueued.restype = C.c_long
         for name in EXPORTS:
             getattr(_lib, name)   # raises AttributeError if the ABI is incomplete
     return _lib
@@ -361,6 +365,48 @@ class TrainBatch:
         _check(rc, "nfisam_nsf_train_plan_run")
         return self.last_iters
 
+    # ---- stepping the plan by hand (nfisam_nsf_train_plan_begin / enqueue / peek / stream / end) ----------------------
+    def begin(self):
+        """Start a hand-stepped run of the (graph) plan: chunks are enqueued with `enqueue`, looked at with `peek`."""
+        self.prepare(True)
+        _check(lib().nfisam_nsf_train_plan_begin(self._plan, _stream()), "nfisam_nsf_train_plan_begin")
+        if getattr(self, "_plan_stream", None) is None:
+            self._plan_stream = torch.cuda.ExternalStream(int(lib().nfisam_nsf_train_plan_stream(self._plan)), device=self.device)
+            self._peek = (TrainState * self.nc)()
+
+    def enqueue(self):
+        """Append one chunk of iterations to the plan's stream (non-blocking)."""
+        _check(lib().nfisam_nsf_train_plan_enqueue(self._plan), "nfisam_nsf_train_plan_enqueue")
+
+    def peek(self):
+        """-> (chunks closed since `begin`, [(step, stop, domain_err) per clique]) as of the last closed chunk; chunks = -1
+        when a chunk closed while the mirror was being copied (look again)."""
+        _check(lib().nfisam_nsf_train_plan_peek(self._plan, self._peek), "nfisam_nsf_train_plan_peek")
+        seq = min(int(s.reserved[0]) for s in self._peek)
+        return seq, [(int(s.step), int(s.stop), int(s.domain_err)) for s in self._peek]
+
+    def feed(self, depth):
+        """The library's feeder thread keeps `depth` chunks enqueued ahead of the last closed one (0: pause)."""
+        _check(lib().nfisam_nsf_train_plan_feed(self._plan, int(depth)), "nfisam_nsf_train_plan_feed")
+
+    def enqueued(self):
+        return int(lib().nfisam_nsf_train_plan_enqueued(self._plan))
+
+    def refill(self, c, x, kparams):
+        """Slot c gets a NEW problem of the same shape: batch, fresh parameters, zeroed moments / workspace / loss record and
+        -- last -- state, enqueued on the plan's stream behind the chunks already there (the slot's old clique must have
+        stopped: nothing writes its buffers any more).  `x` / `kparams` (float32, contiguous, produced on the current stream)
+        must stay alive until the copies have run -- keep a reference as long as the slot trains them."""
+        if x.shape != self.xs[c].shape or kparams.numel() != self.kparams[c].numel() or x.dtype != torch.float32 or \
+                kparams.dtype != torch.float32 or not x.is_contiguous() or not kparams.is_contiguous() or x.device != self.device:
+            raise ValueError("refill needs a contiguous float32 batch and parameters of the slot's shape on the plan's device")
+        _check(lib().nfisam_nsf_train_plan_refill(self._plan, int(c), C.c_void_p(x.data_ptr()), C.c_void_p(kparams.data_ptr()),
+                                                  _stream()), "nfisam_nsf_train_plan_refill")
+
+    def end(self):
+        """The current stream continues behind everything enqueued on the plan."""
+        _check(lib().nfisam_nsf_train_plan_end(self._plan, _stream()), "nfisam_nsf_train_plan_end")
+
     def reset(self, kparams=None):
         """Re-initialise Adam moments / state / loss record in place (pointers stay valid, so a
         prepared plan can be re-run)."""
@@ -374,6 +420,7 @@ class TrainBatch:
         if getattr(self, "_plan", None) is not None:
             lib().nfisam_nsf_train_plan_destroy(self._plan)
             self._plan = None
+            self._plan_stream = None
 
     def __del__(self):
         try:

@@ -4,11 +4,12 @@ The shipped large examples use the `pose_first` ordering, whose working tree per
 (SURVEY.md §0.4): a parent needs its child's samples, so the cliques of one run are trained strictly one after the other
 and a single clique (n = 2000, D = 15: 945 waves) cannot fill 256 CUs — the launch is latency-bound.  The reference
 itself loops over eight dataset variants one after the other (example/slam/plaza_dataset/run_nfisam.py:11-21).
-Independent runs (seeds, noise / data-association variants, datasets) have no such dependency: here R solvers are
-stepped together, each one runs its own host bookkeeping and clique simulation up to its next
-`fit_clique_density_model`, and the R pending cliques are trained by ONE batched launch sequence (grid.y = replica,
-`NFiSAM.train_prepared`).  That moves the training from the latency regime (one clique per launch) to the throughput
-regime without changing any replica's result: every replica owns its random streams (numpy, python,
+Independent runs (seeds, noise / data-association variants, datasets) have no such dependency: here R solvers share
+ONE batched training plan (grid.y = replica): each one runs its own host bookkeeping and clique simulation up to its next
+`fit_clique_density_model`, its clique trains in the replica's slot of the plan while the other replicas' cliques train
+next to it or their host steps run (`_update_in_slots`; in lock-step batches with `NFISAM_REPLICA_SLOTS=0`).  That moves
+the training from the latency regime (one clique per launch) to the throughput regime without changing
+any replica's result: every replica owns its random streams (numpy, python,
 torch host + device generator states are swapped in and out around its turns), its batch, parameters, Adam state and
 early-stop decision, so replica r reproduces the sequential run with seed r — bit for bit when both use the same
 kernel family (`NFISAM_TRAIN`), to kernel rounding (loss 5e-4) otherwise.
@@ -16,9 +17,10 @@ Replicas may hold different graphs: a replica that has fewer cliques to train in
 later batches of that update.
 """
 import contextlib
+import os
 import random
 import time
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -117,14 +119,172 @@ class ReplicaNFiSAM:
             s.add_factor(factor)
         return self
 
-    # ---- one incremental update of every replica -----------------------------------------------------------------
-    def update(self, timers: List[List[float]] = None) -> List[Dict]:
-        """`update_physical_and_working_graphs` + `incremental_inference` of all replicas
-        (reference per replica: FactorGraphSolver.py:803-808).  -> posterior samples per replica."""
+    # ---- training without lock-step: one slot per replica in ONE batched plan ----------------------------------------
+    def _update_in_slots(self, timers, prof) -> list:
+        """One incremental update of all replicas with their cliques trained in SLOTS of one batched training plan.
+        -> the handles of the replicas' posterior walks (launched as each replica finishes its upward pass).
+
+        In lock-step (the loop in `update`) a batch trains until its SLOWEST clique stops -- 1263 iterations on Plaza1 where
+        the average clique needs 681 -- and the host work of all replicas sits between two batches with the GPU idle.  Here
+        the plan of R same-shaped cliques runs as a conveyor of chunks (`TrainBatch.begin / feed / peek`: the library's
+        feeder thread keeps two chunks enqueued ahead): replica r owns slot r; when the mirror shows its clique stopped, its
+        trained parameters are taken out, the replica does its host step (wrap the model, eliminate, simulate and prepare
+        its next clique) while the other slots keep training, and the new clique goes into the slot between two chunks
+        (`TrainBatch.refill`).  Graph updates at the start and posterior walks at the end are interleaved the same way.
+        Every clique runs exactly its own number of iterations and is trained by the same kernels on the same launch shape
+        as in the batch, so the results are bit-identical to lock-step (and to the sequential runs).  A clique of another
+        shape than the plan's (a wider clique every few dozen updates) is trained on its own, blocking."""
         R = len(self.solvers)
-        timers = timers if timers is not None else [[] for _ in range(R)]
+        depth = max(1, int(os.environ.get("NFISAM_SLOT_DEPTH", "2")))
+        done, fits = [False] * R, [0] * R
+        owner: List[Optional[dict]] = [None] * R         # the prepared fit in slot r
+        loaded_at, refill_seq = [0.0] * R, [0] * R
+        gens: List[object] = [None] * R
+        handles: List[object] = [None] * R
+        state = {"trainer": None, "key": None}
+        if len(self._streams) < R:
+            self._streams = [torch.cuda.Stream() for _ in range(R)]
+
+        def shape_key(prep):
+            return (prep["n"], prep["D"], prep["cfg"], str(prep["device"]))
+
+        def graph_step(r):
+            t0 = time.time()
+            with self.turn(r) as s:
+                s.update_physical_and_working_graphs(timer=timers[r])
+                gens[r] = s.fit_tree_steps(timer=timers[r])
+            prof["graphs"] += time.time() - t0
+
+        def host_step(r):
+            """replica r: finish its previous clique, simulate / prepare the next one -> prep or None (upward pass done)"""
+            t0 = time.time()
+            with self.turn(r):
+                try:
+                    prep = next(gens[r])
+                except StopIteration:
+                    prep = None
+            prof["simulate+prepare"] += time.time() - t0
+            return prep
+
+        def open_plan(prep):
+            state["key"] = shape_key(prep)
+            state["trainer"] = self._slot_plan(prep, R)
+            state["trainer"].begin()
+            state["trainer"].feed(depth)
+
+        def place(r, prep):
+            while prep is not None:
+                if state["trainer"] is None:
+                    open_plan(prep)
+                if shape_key(prep) == state["key"]:
+                    tb = state["trainer"]
+                    tb.refill(r, prep["training_data"], prep["kp0"])
+                    # (read AFTER the refill is enqueued: every chunk launched from now on is behind it)
+                    owner[r], refill_seq[r], loaded_at[r] = prep, tb.enqueued(), time.time()
+                    return
+                t0 = time.time()                           # another shape: on its own, blocking (rare)
+                self.solvers[0].train_prepared([prep])
+                dt = time.time() - t0
+                prof["train"] += dt
+                timers[r].append(dt)
+                fits[r] += 1
+                prep = host_step(r)
+            done[r] = True
+            t0 = time.time()                               # upward pass finished: this replica's posterior walk, on its own stream
+            with self.turn(r) as s:
+                self._streams[r].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._streams[r]):
+                    handles[r] = s.posterior_launch()
+            prof["posterior"] += time.time() - t0
+
+        def harvest_ready():
+            """Replicas whose clique has stopped: take the result out, do the host step, refill.  -> any progress"""
+            tb = state["trainer"]
+            busy = [r for r in range(R) if owner[r] is not None]
+            if tb is None or not busy:
+                return False
+            seq, states = tb.peek()
+            if seq < 0:
+                return False
+            ready = [r for r in busy if seq > refill_seq[r] and (states[r][1] != 0 or states[r][0] >= tb.cfg.max_iters)]
+            for r in ready:
+                prep, owner[r] = owner[r], None
+                step, _, err = states[r]
+                if err:                                    # non-finite loss: the batch path's handling (one retry from fresh parameters)
+                    self.solvers[0].train_prepared([prep])
+                else:
+                    prep["trained"], prep["iters"], prep["iter_loss"] = tb.kparams[r].clone(), step, tb.iter_loss[r].clone()
+                timers[r].append((time.time() - loaded_at[r]) / max(1, len(busy)))
+                fits[r] += 1
+                place(r, host_step(r))
+            return bool(ready)
+
+        # the shape of the plan: the one of the previous update if there is one (then the replicas start training one by one
+        # while the others' graphs are still being updated), else the shape most replicas start with
+        last = self.__dict__.get("_slot_last")
+        if last is not None:
+            state["trainer"], state["key"] = last
+            state["trainer"].begin()
+            state["trainer"].feed(depth)
+            for r in range(R):
+                graph_step(r)
+                place(r, host_step(r))
+                harvest_ready()
+        else:
+            for r in range(R):
+                graph_step(r)
+            first = [host_step(r) for r in range(R)]
+            shapes = [shape_key(p) for p in first if p is not None]
+            if shapes:
+                key = max(set(shapes), key=shapes.count)
+                open_plan(next(p for p in first if p is not None and shape_key(p) == key))
+            for r in range(R):
+                place(r, first[r])
+        t_progress = time.time()
+        while not all(done):
+            if harvest_ready():
+                t_progress = time.time()
+            else:
+                t0 = time.time()
+                time.sleep(2e-5)
+                prof["train"] += time.time() - t0
+                if t0 - t_progress > float(os.environ.get("NFISAM_SLOT_WATCHDOG_S", "60")):
+                    tb = state["trainer"]             # a wedged conveyor must not hang the caller for ever
+                    raise RuntimeError("replica slots: no clique finished for %.0f s (chunks enqueued %d, mirror %r, waiting %r)" % (
+                        t0 - t_progress, tb.enqueued(), tb.peek(), [(r, refill_seq[r]) for r in range(R) if owner[r] is not None]))
+        if state["trainer"] is not None:
+            state["trainer"].end()
+            self._slot_last = (state["trainer"], state["key"])
+            prof["chunks"] = prof.get("chunks", 0) + state["trainer"].enqueued()
+        self.last_batches = [sum(1 for f in fits if f > k) for k in range(max(fits) if fits else 0)]
+        return handles
+
+    def _slot_plan(self, prep, R):
+        """The R-slot training plan for cliques shaped like `prep` (kept for the following updates)."""
+        from nfisam_hip import TrainBatch
+        a = self.solvers[0]._args
+        K, H, B, L = prep["cfg"]
+        key = (prep["n"], prep["D"], prep["cfg"], str(prep["device"]), R)
+        plans = self.__dict__.setdefault("_slot_plans", {})
+        tb = plans.get(key)
+        if tb is None:
+            while len(plans) >= 2:                          # (a run's cliques have one shape, rarely two)
+                plans.pop(next(iter(plans))).close()
+            dev = prep["device"]
+            tb = TrainBatch([torch.zeros(prep["n"], prep["D"], dtype=torch.float32, device=dev) for _ in range(R)],
+                            [torch.zeros_like(prep["kp0"]) for _ in range(R)], K, H, B, L, lr=a.learning_rate,
+                            max_iters=a.flow_iterations, average_window=a.average_window, loss_delta_tol=a.loss_delta_tol,
+                            early_stop=True)
+            # empty slots must look finished: a zeroed state would train the zero problem
+            tb.states[:, 1] = 1
+            plans[key] = tb
+        return tb
+
+    def _update_in_lock_step(self, timers, prof) -> list:
+        """All replicas step together; the R pending cliques are trained by ONE batched launch sequence per round
+        (`NFISAM_REPLICA_SLOTS=0`; what `_update_in_slots` is measured against)."""
+        R = len(self.solvers)
         gens = []
-        prof = self.__dict__.setdefault("profile", {"graphs": 0.0, "simulate+prepare": 0.0, "train": 0.0, "posterior": 0.0})
         t_ph = time.time()
         for r in range(R):
             with self.turn(r) as s:
@@ -166,6 +326,21 @@ class ReplicaNFiSAM:
                 self._streams[r].wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._streams[r]):
                     handles.append(s.posterior_launch())
+        prof["posterior"] += time.time() - t_ph
+        return handles
+
+    # ---- one incremental update of every replica -----------------------------------------------------------------
+    def update(self, timers: List[List[float]] = None) -> List[Dict]:
+        """`update_physical_and_working_graphs` + `incremental_inference` of all replicas
+        (reference per replica: FactorGraphSolver.py:803-808).  -> posterior samples per replica."""
+        R = len(self.solvers)
+        timers = timers if timers is not None else [[] for _ in range(R)]
+        prof = self.__dict__.setdefault("profile", {"graphs": 0.0, "simulate+prepare": 0.0, "train": 0.0, "posterior": 0.0})
+        if R >= 2 and os.environ.get("NFISAM_REPLICA_SLOTS", "1") != "0":
+            handles = self._update_in_slots(timers, prof)
+        else:
+            handles = self._update_in_lock_step(timers, prof)
+        t_ph = time.time()
         out = []
         for r in range(R):
             s = self.solvers[r]

@@ -11,6 +11,7 @@ Tolerances (the kernels use 1-ulp hardware exp2/log2/rcp, fp32 t
 """
 import glob
 import os
+import time
 
 import numpy as np
 import pytest
@@ -901,3 +902,62 @@ def test_multilayer_launch_beyond_the_slab_limit_uses_atomics_and_still_trains()
         np.testing.assert_allclose(res[pair][0][:4], l64[:4], atol=2e-4, rtol=1e-5, err_msg=str(pair))
         np.testing.assert_allclose(res[pair][0], l64, atol=2e-2, err_msg=str(pair))       # (fp32 vs fp64 trajectories drift: 6e-3 after 9 iterations)
         assert np.quantile(np.abs(res[pair][1] - b64), 0.98) < 3e-3, pair
+
+
+@pytest.mark.timeout(120)
+def test_plan_as_a_conveyor_of_chunks_trains_every_slot_like_a_plan_of_its_own():
+    """`TrainBatch.begin / feed / peek / refill / end` (nfisam_nsf_train_plan_begin ..: the slot scheduler of
+    slam.ReplicaNFiSAM): four slots, each training a sequence of problems that enter between two chunks as the previous one
+    stops; the library's feeder thread launches the chunks.  Every problem must come out with the iterations, parameters and
+    loss record of a plan of its own, bit for bit (a refill that interleaved with a chunk's graph launch once activated a
+    slot mid-chunk), over several begin .. end cycles of one plan; empty slots and run-ahead chunks change nothing."""
+    K, H, B, L, R, n, D, per_slot, cycles = 9, 8, 5.0, 1, 4, 1000, 7, 3, 3
+    kw = dict(lr=0.02, max_iters=400, average_window=50, loss_delta_tol=0.02, early_stop=True)
+
+    def problem(i):
+        blob, x = make_problem(n, D, K, H, L, seed=3000 + i, spread=0.6 + 0.3 * (i % 4))
+        return dev(x), kpack(blob, D, K, H, L)
+    ref = {}
+    for i in range(R * per_slot * cycles):
+        x, kp = problem(i)
+        tb1 = nh.TrainBatch([x], [kp.clone()], K, H, B, L, **kw)
+        it = tb1.run(use_graph=True)
+        ref[i] = (it[0], tb1.kparams[0].clone(), tb1.iter_loss[0].clone())
+        tb1.close()
+    assert len({v[0] for v in ref.values()}) > 1                 # the problems stop at different iterations
+    tb = nh.TrainBatch([torch.zeros(n, D, device=DEV) for _ in range(R)], [torch.zeros_like(problem(0)[1]) for _ in range(R)],
+                       K, H, B, L, **kw)
+    tb.states[:, 1] = 1                                          # empty slots look finished
+    nxt = 0
+    for cyc in range(cycles):
+        tb.begin()
+        tb.feed(2)
+        owner, seq0, keep, left = [None] * R, [0] * R, [None] * R, [per_slot] * R
+
+        def load(r):
+            nonlocal nxt
+            keep[r] = problem(nxt)                               # (the sources stay alive while the slot trains them)
+            tb.refill(r, *keep[r])
+            owner[r], seq0[r] = nxt, tb.enqueued()
+            nxt += 1
+            left[r] -= 1
+        for r in range(R):
+            load(r)
+        t_last = time.time()
+        while any(o is not None for o in owner):
+            seq, st = tb.peek()
+            for r in range(R):
+                if seq >= 0 and owner[r] is not None and seq > seq0[r] and (st[r][1] != 0 or st[r][0] >= kw["max_iters"]):
+                    i, owner[r] = owner[r], None
+                    assert st[r][0] == ref[i][0], (cyc, r, i, st[r][0], ref[i][0])
+                    assert torch.equal(tb.kparams[r], ref[i][1]), (cyc, r, i)
+                    np.testing.assert_allclose(tb.iter_loss[r].cpu().numpy(), ref[i][2].cpu().numpy(), rtol=3e-6, atol=1e-6)
+                    if left[r] > 0:
+                        load(r)
+                    t_last = time.time()
+            assert time.time() - t_last < 20, "the conveyor stalled"
+            time.sleep(2e-5)
+        tb.end()
+        torch.cuda.synchronize()
+        assert tb.enqueued() < 200                               # no chunks launched for an idle conveyor
+    tb.close()

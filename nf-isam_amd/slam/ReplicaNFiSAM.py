@@ -57,6 +57,7 @@ class _ReplicaSolver(NFiSAM):
                 raise NotImplementedError("replica batching trains on the full batch (training_set_frac = 1)")
             yield prep
             model = self.finish_fit(prep)
+            model.posterior_static()      # device constants of the tree walk: now, while other replicas train, not in the serial tail
             self._clique_density_model[clique] = model
             new_separator_factor = None
             if clique.separator:
@@ -120,11 +121,13 @@ class ReplicaNFiSAM:
         return self
 
     # ---- training without lock-step: one slot per replica in ONE batched plan ----------------------------------------
-    def _update_in_slots(self, timers, prof) -> list:
-        """One incremental update of all replicas with their cliques trained in SLOTS of one batched training plan.
-        -> the handles of the replicas' posterior walks (launched as each replica finishes its upward pass).
+    def _update_in_slots(self, timers, prof, steps=None, on_update=None) -> list:
+        """One incremental update of all replicas (`steps` None) -- or a whole sequence of them, every replica at its own pace
+        -- with their cliques trained in SLOTS of one batched training plan.
+        -> `steps` None: the handles of the replicas' posterior walks (launched as each replica finishes its upward pass);
+           else: per replica the list of posterior samples per step.
 
-        In lock-step (the loop in `update`) a batch trains until its SLOWEST clique stops -- 1263 iterations on Plaza1 where
+        In lock-step (`_update_in_lock_step`) a batch trains until its SLOWEST clique stops -- 1263 iterations on Plaza1 where
         the average clique needs 681 -- and the host work of all replicas sits between two batches with the GPU idle.  Here
         the plan of R same-shaped cliques runs as a conveyor of chunks (`TrainBatch.begin / feed / peek`: the library's
         feeder thread keeps two chunks enqueued ahead): replica r owns slot r; when the mirror shows its clique stopped, its
@@ -133,10 +136,17 @@ class ReplicaNFiSAM:
         (`TrainBatch.refill`).  Graph updates at the start and posterior walks at the end are interleaved the same way.
         Every clique runs exactly its own number of iterations and is trained by the same kernels on the same launch shape
         as in the batch, so the results are bit-identical to lock-step (and to the sequential runs).  A clique of another
-        shape than the plan's (a wider clique every few dozen updates) is trained on its own, blocking."""
+        shape than the plan's (a wider clique every few dozen updates) is trained on its own, blocking.
+        With `steps` (`run_incrementally`) a replica that has its posterior goes straight on to its next update: the
+        replicas drift apart and nobody waits for the slowest one of an update."""
         R = len(self.solvers)
         depth = max(1, int(os.environ.get("NFISAM_SLOT_DEPTH", "2")))
-        done, fits = [False] * R, [0] * R
+        free_running = steps is not None
+        n_steps = len(steps) if free_running else 1
+        done, fits = [False] * R, [0] * R                # done: upward pass of the current step finished (posterior launched)
+        finished = [False] * R                           # all steps of the replica finished
+        step_idx, t_step = [0] * R, [0.0] * R
+        results: List[list] = [[] for _ in range(R)]
         owner: List[Optional[dict]] = [None] * R         # the prepared fit in slot r
         loaded_at, refill_seq = [0.0] * R, [0] * R
         gens: List[object] = [None] * R
@@ -151,6 +161,12 @@ class ReplicaNFiSAM:
         def graph_step(r):
             t0 = time.time()
             with self.turn(r) as s:
+                if free_running:
+                    vs, fs = steps[step_idx[r]]
+                    for v in vs:
+                        s.add_node(v)
+                    for f in fs:
+                        s.add_factor(f)
                 s.update_physical_and_working_graphs(timer=timers[r])
                 gens[r] = s.fit_tree_steps(timer=timers[r])
             prof["graphs"] += time.time() - t0
@@ -196,6 +212,13 @@ class ReplicaNFiSAM:
                 with torch.cuda.stream(self._streams[r]):
                     handles[r] = s.posterior_launch()
             prof["posterior"] += time.time() - t0
+            if not free_running:
+                finished[r] = True
+
+        def start_step(r):
+            done[r], t_step[r] = False, time.time()
+            graph_step(r)
+            place(r, host_step(r))
 
         def harvest_ready():
             """Replicas whose clique has stopped: take the result out, do the host step, refill.  -> any progress"""
@@ -219,16 +242,38 @@ class ReplicaNFiSAM:
                 place(r, host_step(r))
             return bool(ready)
 
+        def collect_ready():
+            """(free running) replicas whose posterior walk has finished: take the samples, go on to the next update"""
+            progress = False
+            for r in range(R):
+                if handles[r] is None or finished[r] or not handles[r]["stream"].query():
+                    continue
+                t0 = time.time()
+                s = self.solvers[r]
+                s._samples = s.posterior_collect(handles[r], timer=timers[r])
+                handles[r] = None
+                prof["posterior"] += time.time() - t0
+                results[r].append(s._samples)
+                if on_update is not None:
+                    on_update(r, step_idx[r], s._samples, time.time() - t_step[r])
+                step_idx[r] += 1
+                if step_idx[r] < n_steps:
+                    start_step(r)
+                else:
+                    finished[r] = True
+                progress = True
+            return progress
+
         # the shape of the plan: the one of the previous update if there is one (then the replicas start training one by one
         # while the others' graphs are still being updated), else the shape most replicas start with
         last = self.__dict__.get("_slot_last")
-        if last is not None:
-            state["trainer"], state["key"] = last
-            state["trainer"].begin()
-            state["trainer"].feed(depth)
+        if last is not None or free_running:
+            if last is not None:
+                state["trainer"], state["key"] = last
+                state["trainer"].begin()
+                state["trainer"].feed(depth)
             for r in range(R):
-                graph_step(r)
-                place(r, host_step(r))
+                start_step(r)
                 harvest_ready()
         else:
             for r in range(R):
@@ -241,8 +286,11 @@ class ReplicaNFiSAM:
             for r in range(R):
                 place(r, first[r])
         t_progress = time.time()
-        while not all(done):
-            if harvest_ready():
+        while not all(finished):
+            moved = harvest_ready()
+            if free_running:
+                moved = collect_ready() or moved
+            if moved:
                 t_progress = time.time()
             else:
                 t0 = time.time()
@@ -257,7 +305,19 @@ class ReplicaNFiSAM:
             self._slot_last = (state["trainer"], state["key"])
             prof["chunks"] = prof.get("chunks", 0) + state["trainer"].enqueued()
         self.last_batches = [sum(1 for f in fits if f > k) for k in range(max(fits) if fits else 0)]
-        return handles
+        return results if free_running else handles
+
+    def run_incrementally(self, steps, on_update=None, timers: List[List[float]] = None) -> List[list]:
+        """All replicas through the same sequence of incremental steps [(new variables, new factors), ..] (reference:
+        `run_incrementally`, FactorGraphSolver.py:760-933, one solver; its drivers loop over dataset variants one after the
+        other, example/slam/plaza_dataset/run_nfisam.py:11-21), every replica at its OWN pace: a replica that has the
+        posterior of step k stages step k + 1 at once, while the other replicas' cliques keep training in their slots of the
+        shared plan -- no replica waits for the slowest one of an update.  -> per replica the posterior samples of every
+        step; `on_update(replica, step, samples, seconds)` is called as results arrive."""
+        R = len(self.solvers)
+        timers = timers if timers is not None else [[] for _ in range(R)]
+        prof = self.__dict__.setdefault("profile", {"graphs": 0.0, "simulate+prepare": 0.0, "train": 0.0, "posterior": 0.0})
+        return self._update_in_slots(timers, prof, steps=list(steps), on_update=on_update)
 
     def _slot_plan(self, prep, R):
         """The R-slot training plan for cliques shaped like `prep` (kept for the following updates)."""

@@ -29,6 +29,35 @@ if replicas > 1:
     rep = ReplicaNFiSAM(args, [seed + r for r in range(replicas)])
     walls, fit_iters = [], 0
     t_all = time.time()
+    if os.environ.get("FREE", "1") != "0":
+        # every replica at its own pace (ReplicaNFiSAM.run_incrementally): no barrier per update
+        per = [[] for _ in range(replicas)]
+        last = [None] * replicas
+
+        def on_update(r, k, samples, seconds):
+            global fit_iters
+            per[r].append(seconds)
+            last[r] = samples
+            fit_iters += sum(int(np.count_nonzero(v)) for v in rep.solvers[r]._temp_training_loss.values())
+        rep.run_incrementally(steps[:max_updates], on_update=on_update)
+        total = time.time() - t_all
+        rm = []
+        for s, o in zip(rep.solvers, last):
+            poses = [v for v in s.physical_vars if str(v.name).startswith("X")]
+            err = np.array([o[v][:, :2].mean(0) - truth[v][:2] for v in poses])
+            rm.append(float(np.sqrt((err ** 2).sum(1).mean())))
+        n_up = len(per[0])
+        print("free-running replicas: %.2f s for %d replicas x %d updates = %.2f ms per replica-update, traj RMSE %s" %
+              (total, replicas, n_up, 1e3 * total / (replicas * n_up), " ".join("%.2f" % r for r in rm)), flush=True)
+        summary = dict(replicas=replicas, updates=n_up, total_s=total, schedule="free-running (run_incrementally)",
+                       wall_per_replica_update_mean=float(total / (replicas * n_up)),
+                       wall_per_replica_update_median=float(total / (replicas * n_up)),
+                       own_seconds_per_update_median=float(np.median(np.concatenate([np.array(p) for p in per]))),
+                       training_sample_iters=float(2000 * fit_iters), final_rmse=rm, seconds_by_phase=getattr(rep, 'profile', None))
+        print(json.dumps(summary))
+        if out_json:
+            json.dump(dict(summary=summary, per_replica_seconds=per), open(out_json, "w"))
+        sys.exit(0)
     for i, (vs, fs) in enumerate(steps[:max_updates]):
         for v in vs: rep.add_node(v)
         for f in fs: rep.add_factor(f)

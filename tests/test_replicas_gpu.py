@@ -119,3 +119,47 @@ def test_replicas_with_default_kernels_match_in_distribution(tmp_path):
         a = np.hstack([res[v][:, :2] for v in order])
         b = np.hstack([out[r][v][:, :2] for v in order])
         assert MMDb(a, b) < 0.12
+
+
+def test_free_running_replicas_reproduce_sequential_runs(tmp_path):
+    """`ReplicaNFiSAM.run_incrementally`: every replica goes through the incremental steps at its own pace (its cliques train in
+    its slot of the shared plan while the others are anywhere in their own updates).  Each replica still reproduces the
+    sequential run with its seed bit for bit, step by step."""
+    from slam.NFiSAM import NFiSAM
+    from slam.ReplicaNFiSAM import ReplicaNFiSAM
+    steps = _steps(tmp_path)[:5]
+    seeds = [31, 32, 33, 34]
+    old = os.environ.get("NFISAM_TRAIN")
+    os.environ["NFISAM_TRAIN"] = "split"
+    try:
+        seq = []
+        for s in seeds:
+            random.seed(s); np.random.seed(s); torch.manual_seed(s)
+            solver = NFiSAM(_args())
+            per_step = []
+            for vs, fs in steps:
+                for v in vs:
+                    solver.add_node(v)
+                for f in fs:
+                    solver.add_factor(f)
+                solver.update_physical_and_working_graphs()
+                res = solver.incremental_inference()
+                per_step.append(np.hstack([res[v] for v in solver.elimination_ordering]))
+            seq.append(per_step)
+        rep = ReplicaNFiSAM(_args(), seeds)
+        seen = {}
+
+        def on_update(r, k, samples, seconds):        # called before replica r stages its next step: its ordering is step k's
+            seen[(r, k)] = np.hstack([samples[v] for v in rep.solvers[r].elimination_ordering])
+        out = rep.run_incrementally(steps, on_update=on_update)
+        assert sorted(seen) == [(r, k) for r in range(len(seeds)) for k in range(len(steps))]
+        for r in range(len(seeds)):
+            assert len(out[r]) == len(steps)
+            for k in range(len(steps)):
+                np.testing.assert_array_equal(seen[(r, k)], seq[r][k])
+        assert not np.array_equal(seen[(0, len(steps) - 1)], seen[(1, len(steps) - 1)])     # the replicas really are different runs
+    finally:
+        if old is None:
+            os.environ.pop("NFISAM_TRAIN", None)
+        else:
+            os.environ["NFISAM_TRAIN"] = old

@@ -23,7 +23,7 @@ args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000
                   device_simulation=os.environ.get("DEVSIM", "1") != "0")
 replicas = int(os.environ.get("REPLICAS", "1"))
 if replicas > 1:
-    # R independent runs (seeds SEED .. SEED+R-1) in lock-step: every update trains R cliques per batched launch
+    # R independent runs (seeds SEED .. SEED+R-1) on one GPU, their cliques in the R slots of one batched training plan
     # (slam.ReplicaNFiSAM; the reference loops over its dataset variants one after the other, run_nfisam.py:11-21)
     from slam.ReplicaNFiSAM import ReplicaNFiSAM
     rep = ReplicaNFiSAM(args, [seed + r for r in range(replicas)])

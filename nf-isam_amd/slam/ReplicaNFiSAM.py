@@ -266,6 +266,27 @@ class ReplicaNFiSAM:
 
         # the shape of the plan: the one of the previous update if there is one (then the replicas start training one by one
         # while the others' graphs are still being updated), else the shape most replicas start with
+        try:
+            return self._drive_slots(locals())
+        except BaseException:
+            if state["trainer"] is not None:              # no feeder left launching chunks behind an exception; the plan is
+                try:                                       # dropped (its slots may hold half-trained cliques)
+                    state["trainer"].end()
+                    torch.cuda.synchronize()
+                finally:
+                    self.__dict__.pop("_slot_last", None)
+                    for tb in self.__dict__.pop("_slot_plans", {}).values():
+                        tb.close()
+            raise
+
+    def _drive_slots(self, env):
+        """The scheduler loop of `_update_in_slots` (`env`: its state and closures; split off so that the caller can clean up
+        behind an exception)."""
+        state, finished, fits, handles, results, owner, refill_seq = (env[k] for k in (
+            "state", "finished", "fits", "handles", "results", "owner", "refill_seq"))
+        start_step, graph_step, host_step, shape_key, open_plan, place, harvest_ready, collect_ready = (env[k] for k in (
+            "start_step", "graph_step", "host_step", "shape_key", "open_plan", "place", "harvest_ready", "collect_ready"))
+        free_running, depth, prof, R = env["free_running"], env["depth"], env["prof"], env["R"]
         last = self.__dict__.get("_slot_last")
         if last is not None or free_running:
             if last is not None:

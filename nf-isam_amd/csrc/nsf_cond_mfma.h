@@ -512,36 +512,29 @@ __device__ __forceinline__ void stage_pair_panels(float* lay0, int PS, size_t ps
     }
 }
 
-// The same panels out of the clique's panel image (device memory, maintained by the Adam kernel): a 16-byte copy.
-template <int K, int H>
-__device__ __forceinline__ void copy_pair_panels(float* lay0, int PS, size_t pstride, const float* image_generic, int iA, int nd,
-                                                 int L, int lane) {
+// The same panels out of the clique's panel image (device memory, maintained by the Adam kernel): 16-byte copies, ONE layer
+// at a time -- the prologue brings layer 0, every forward stage requests the next layer's panels before its arithmetic and
+// drops them into LDS behind it (the wave's panels are its own: no barrier), so only the first layer's round trip is exposed.
+constexpr int PAIR_PANEL_WORDS = 10;                          // D <= 16: 2 x 1268 floats = 634 16-byte words = 10 per lane
+__device__ __forceinline__ void load_pair_panels(const float* image_generic, size_t pstride, int PS, int iA, int nd, int l, int lane,
+                                                 cm_f32x4 (&v)[PAIR_PANEL_WORDS]) {
     typedef const __attribute__((address_space(1))) cm_f32x4* gv4;
-    const int n4 = (nd * PS) >> 2;                            // 16-byte words per layer (PS is a multiple of 4)
-    constexpr int U = 10;                                     // D <= 16: 2 x 1268 floats = 634 words = 10 per lane
-    for (int lb = 0; lb < L; lb += 4) {
-        cm_f32x4 v[4][U];
+    const int n4 = (nd * PS) >> 2;                            // 16-byte words (PS is a multiple of 4)
+    gv4 src = (gv4)(image_generic + (size_t)l * pstride + (size_t)iA * PS);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int l = (lb + q < L) ? lb + q : L - 1;
-            gv4 src = (gv4)(image_generic + (size_t)l * pstride + (size_t)iA * PS);
+    for (int u = 0; u < PAIR_PANEL_WORDS; ++u) {
+        const int e = lane + 64 * u;
+        v[u] = src[e < n4 ? e : 0];
+    }
+}
+__device__ __forceinline__ void store_pair_panels(float* lay0, size_t pstride, int PS, int iA, int nd, int l, int lane,
+                                                  const cm_f32x4 (&v)[PAIR_PANEL_WORDS]) {
+    const int n4 = (nd * PS) >> 2;
+    cm_f32x4* dst = (cm_f32x4*)(lay0 + (size_t)l * pstride + (size_t)iA * PS);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = lane + 64 * u;
-                v[q][u] = src[e < n4 ? e : 0];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (lb + q < L) {
-                cm_f32x4* dst = (cm_f32x4*)(lay0 + (size_t)(lb + q) * pstride + (size_t)iA * PS);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = lane + 64 * u;
-                    if (e < n4) dst[e] = v[q][u];
-                }
-            }
-        }
+    for (int u = 0; u < PAIR_PANEL_WORDS; ++u) {
+        const int e = lane + 64 * u;
+        if (e < n4) dst[e] = v[u];
     }
 }
 

@@ -1572,9 +1572,11 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
 #endif
         if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
             const int j = w;
-            if (a.pair_image)
-                copy_pair_panels<K, H>(panels, PS, (size_t)D * PS, image, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
-            else
+            if (a.pair_image) {                                // layer 0 now, layer l + 1 under forward stage l
+                cm_f32x4 pv[PAIR_PANEL_WORDS];
+                load_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, 0, lane, pv);
+                store_pair_panels(panels, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, 0, lane, pv);
+            } else
                 stage_pair_panels<K, H>(panels, PS, (size_t)D * PS, kparams, (size_t)Pk, map, 2 * j, (2 * j + 1 < D) ? 2 : 1, L, lane);
         }
         // the state words were requested at kernel entry and are LOOKED AT only now, behind the prologue's own loads (the
@@ -1623,12 +1625,15 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
             const int ic = dim_ok ? i : D - 1;
             const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
             const float* pan = panels + ((size_t)l * D + ic) * PS;
+            cm_f32x4 pnext[PAIR_PANEL_WORDS];
+            if (a.pair_image) load_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
             float h1[H], h2[H], th[PoP];
             cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
             SplineT<K> S;
             float z, lad;
             spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
             if (dim_ok) xout[i * XS2 + p] = z;
+            if (a.pair_image) store_pair_panels(panels, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
             if (stash) {
                 float sv[NF];
                 stash_pack<K, H>(h1, h2, S, sv);

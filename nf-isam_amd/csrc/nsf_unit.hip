@@ -3,11 +3,14 @@
 // (Makefile: -DNSF_UNIT=u); see nsf_host.h for how the units fit together.
 //
 // Work decomposition:
-//   training   latency regime   nsf_train2_kernel (two lanes per particle) / nsf_train_kernel: block = W waves over ONE
-//                               particle tile, wave w owns the dims w, w+W, ... of every layer (in the density
-//                               direction all D conditioners depend only on the layer input, src/flows/flows.py:77-83);
-//                               layers are sequential: layer inputs live in LDS and waves meet at __syncthreads()
-//              throughput       nsf_train1_kernel: one wave = one dim x T tiles, dim-major blocks
+//   training   one layer        nsf_train1_kernel: one wave = one dim x T tiles, dim-major blocks, Adam fused into the next launch
+//                               (every real NF-iSAM run; hidden_dim 4 / 8 / 16)
+//              layers / dL/dx   tile-major: a block = W waves over ONE particle tile through all layers (in the density direction
+//                               all D conditioners depend only on the layer input, src/flows/flows.py:77-83; layers are
+//                               sequential: layer inputs live in LDS and waves meet at __syncthreads()):
+//                               nsf_train3_kernel (two dims per wave, MFMA conditioner; latency regime, D 6..16),
+//                               nsf_train2_kernel (two lanes per particle; latency regime, other D),
+//                               nsf_train_kernel (one lane per particle; big launches, hidden_dim != 8, A/B)
 //   inverse    one wave per 64 particles, dims sequential (true data dependence, flows.py:115-137)
 //   walk       whole Bayes tree root -> leaves in one launch
 #include <stddef.h>

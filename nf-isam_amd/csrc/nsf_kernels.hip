@@ -793,7 +793,7 @@ struct nfisam_train_plan {
     nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
                                            // writes it (last word written: reserved[0] = chunks closed in this run)
     nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
-    bool ahead = false;                    // the previous run left a chunk enqueued behind its early stop
+    std::atomic<bool> ahead{false};        // the previous run left a chunk enqueued behind its early stop (the feeder thread sets it too)
     // hand-stepped runs (nfisam_nsf_train_plan_begin ..): a feeder thread keeps `feed_depth` chunks enqueued ahead of the
     // last one closed, so that the caller's thread (Python, in the replica scheduler) never sits in hipGraphLaunch
     int device = 0;
@@ -938,6 +938,10 @@ static int wait_chunk(const nfisam_train_plan* p, int k) {
 
 extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_run, nfisam_stream_t stream) {
     if (p == nullptr) return NFISAM_ERR_ARG;
+    if (p->feeder.joinable()) {                          // a hand-stepped run's feeder must not launch into this one
+        p->feed_depth.store(0);
+        while (p->feed_busy.load() != 0) __builtin_ia32_pause();
+    }
     hipStream_t user = (hipStream_t)stream;
     hipStream_t work = user;
     const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;

@@ -135,12 +135,13 @@ class ReplicaNFiSAM:
         its next clique) while the other slots keep training, and the new clique goes into the slot between two chunks
         (`TrainBatch.refill`).  Graph updates at the start and posterior walks at the end are interleaved the same way.
         Every clique runs exactly its own number of iterations and is trained by the same kernels on the same launch shape
-        as in the batch, so the results are bit-identical to lock-step (and to the sequential runs).  A clique of another
-        shape than the plan's (a wider clique every few dozen updates) is trained on its own, blocking.
+        as in the batch, so the results are bit-identical to lock-step (and to the sequential runs).  Cliques of another
+        shape than the plan's wait for the next idle moment and are trained together, blocking (`train_odd`).
         With `steps` (`run_incrementally`) a replica that has its posterior goes straight on to its next update: the
         replicas drift apart and nobody waits for the slowest one of an update."""
         R = len(self.solvers)
         depth = max(1, int(os.environ.get("NFISAM_SLOT_DEPTH", "2")))
+        odd: List[tuple] = []                            # (replica, prepared fit) of another shape than the plan's
         free_running = steps is not None
         n_steps = len(steps) if free_running else 1
         done, fits = [False] * R, [0] * R                # done: upward pass of the current step finished (posterior launched)
@@ -198,13 +199,8 @@ class ReplicaNFiSAM:
                     # (read AFTER the refill is enqueued: every chunk launched from now on is behind it)
                     owner[r], refill_seq[r], loaded_at[r] = prep, tb.enqueued(), time.time()
                     return
-                t0 = time.time()                           # another shape: on its own, blocking (rare)
-                self.solvers[0].train_prepared([prep])
-                dt = time.time() - t0
-                prof["train"] += dt
-                timers[r].append(dt)
-                fits[r] += 1
-                prep = host_step(r)
+                odd.append((r, prep))                      # another shape: waits for the next idle moment (see train_odd)
+                return
             done[r] = True
             t0 = time.time()                               # upward pass finished: this replica's posterior walk, on its own stream
             with self.turn(r) as s:
@@ -214,6 +210,21 @@ class ReplicaNFiSAM:
             prof["posterior"] += time.time() - t0
             if not free_running:
                 finished[r] = True
+
+        def train_odd():
+            """Cliques of another shape than the plan's, collected since the last idle moment: ONE batched (ragged) training
+            of all of them, blocking -- runs whose cliques keep changing shape (Manhattan) end up in lock-step batches this
+            way, runs with one dominant shape (Plaza) train the odd clique every few dozen updates on its own."""
+            batch, odd[:] = list(odd), []
+            t0 = time.time()
+            self.solvers[0].train_prepared([p for _, p in batch])
+            dt = time.time() - t0
+            prof["train"] += dt
+            for r, _ in batch:
+                timers[r].append(dt / len(batch))
+                fits[r] += 1
+            for r, _ in batch:
+                place(r, host_step(r))
 
         def start_step(r):
             done[r], t_step[r] = False, time.time()
@@ -312,6 +323,9 @@ class ReplicaNFiSAM:
             if free_running:
                 moved = collect_ready() or moved
             if moved:
+                t_progress = time.time()
+            elif env["odd"]:
+                env["train_odd"]()
                 t_progress = time.time()
             else:
                 t0 = time.time()

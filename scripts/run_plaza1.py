@@ -65,7 +65,7 @@ if replicas > 1:
         outs = rep.update()
         walls.append(time.time() - t0)
         fit_iters += sum(int(np.count_nonzero(v)) for s in rep.solvers for v in s._temp_training_loss.values())
-        if i % int(os.environ.get('EVERY', '10')) == 0 or i == len(steps) - 1:
+        if i % int(os.environ.get('EVERY', '10')) == 0 or i == min(len(steps), max_updates) - 1:
             rm = []
             for s, o in zip(rep.solvers, outs):
                 poses = [v for v in s.physical_vars if str(v.name).startswith("X")]
@@ -102,7 +102,7 @@ for i, (vs, fs) in enumerate(steps[:max_updates]):
     rmse_ = float(np.sqrt((err_ ** 2).sum(1).mean()))
     rows.append(dict(update=i, rmse=rmse_, wall=dt, graph=timer[0], sampling=samp, fitting=fit, posterior=timer[-1],
                      cliques_trained=len(iters), iterations=sum(iters), n_vars=len(solver.physical_vars)))
-    if i % int(os.environ.get('EVERY', '10')) == 0 or i == len(steps) - 1:
+    if i % int(os.environ.get('EVERY', '10')) == 0 or i == min(len(steps), max_updates) - 1:
         poses = [v for v in solver.physical_vars if str(v.name).startswith("X")]
         err = np.array([samples[v][:, :2].mean(0) - truth[v][:2] for v in poses])
         print("update %3d: %.3f s (graph %.3f, sampling %.3f, fit %.3f [%d cliques, %d it], posterior %.3f) vars %d "

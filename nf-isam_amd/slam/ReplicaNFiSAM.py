@@ -277,8 +277,53 @@ class ReplicaNFiSAM:
 
         # the shape of the plan: the one of the previous update if there is one (then the replicas start training one by one
         # while the others' graphs are still being updated), else the shape most replicas start with
+        def drive():
+            last = self.__dict__.get("_slot_last")
+            if last is not None or free_running:
+                if last is not None:
+                    state["trainer"], state["key"] = last
+                    state["trainer"].begin()
+                    state["trainer"].feed(depth)
+                for r in range(R):
+                    start_step(r)
+                    harvest_ready()
+            else:
+                for r in range(R):
+                    graph_step(r)
+                first = [host_step(r) for r in range(R)]
+                shapes = [shape_key(p) for p in first if p is not None]
+                if shapes:
+                    key = max(set(shapes), key=shapes.count)
+                    open_plan(next(p for p in first if p is not None and shape_key(p) == key))
+                for r in range(R):
+                    place(r, first[r])
+            t_progress = time.time()
+            while not all(finished):
+                moved = harvest_ready()
+                if free_running:
+                    moved = collect_ready() or moved
+                if moved:
+                    t_progress = time.time()
+                elif odd:
+                    train_odd()
+                    t_progress = time.time()
+                else:
+                    t0 = time.time()
+                    time.sleep(2e-5)
+                    prof["train"] += time.time() - t0
+                    if t0 - t_progress > float(os.environ.get("NFISAM_SLOT_WATCHDOG_S", "60")):
+                        tb = state["trainer"]             # a wedged conveyor must not hang the caller for ever
+                        raise RuntimeError("replica slots: no clique finished for %.0f s (chunks enqueued %d, mirror %r, waiting %r)" % (
+                            t0 - t_progress, tb.enqueued(), tb.peek(), [(r, refill_seq[r]) for r in range(R) if owner[r] is not None]))
+            if state["trainer"] is not None:
+                state["trainer"].end()
+                self._slot_last = (state["trainer"], state["key"])
+                prof["chunks"] = prof.get("chunks", 0) + state["trainer"].enqueued()
+            self.last_batches = [sum(1 for f in fits if f > k) for k in range(max(fits) if fits else 0)]
+            return results if free_running else handles
+
         try:
-            return self._drive_slots(locals())
+            return drive()
         except BaseException:
             if state["trainer"] is not None:              # no feeder left launching chunks behind an exception; the plan is
                 try:                                       # dropped (its slots may hold half-trained cliques)
@@ -289,58 +334,6 @@ class ReplicaNFiSAM:
                     for tb in self.__dict__.pop("_slot_plans", {}).values():
                         tb.close()
             raise
-
-    def _drive_slots(self, env):
-        """The scheduler loop of `_update_in_slots` (`env`: its state and closures; split off so that the caller can clean up
-        behind an exception)."""
-        state, finished, fits, handles, results, owner, refill_seq = (env[k] for k in (
-            "state", "finished", "fits", "handles", "results", "owner", "refill_seq"))
-        start_step, graph_step, host_step, shape_key, open_plan, place, harvest_ready, collect_ready = (env[k] for k in (
-            "start_step", "graph_step", "host_step", "shape_key", "open_plan", "place", "harvest_ready", "collect_ready"))
-        free_running, depth, prof, R = env["free_running"], env["depth"], env["prof"], env["R"]
-        last = self.__dict__.get("_slot_last")
-        if last is not None or free_running:
-            if last is not None:
-                state["trainer"], state["key"] = last
-                state["trainer"].begin()
-                state["trainer"].feed(depth)
-            for r in range(R):
-                start_step(r)
-                harvest_ready()
-        else:
-            for r in range(R):
-                graph_step(r)
-            first = [host_step(r) for r in range(R)]
-            shapes = [shape_key(p) for p in first if p is not None]
-            if shapes:
-                key = max(set(shapes), key=shapes.count)
-                open_plan(next(p for p in first if p is not None and shape_key(p) == key))
-            for r in range(R):
-                place(r, first[r])
-        t_progress = time.time()
-        while not all(finished):
-            moved = harvest_ready()
-            if free_running:
-                moved = collect_ready() or moved
-            if moved:
-                t_progress = time.time()
-            elif env["odd"]:
-                env["train_odd"]()
-                t_progress = time.time()
-            else:
-                t0 = time.time()
-                time.sleep(2e-5)
-                prof["train"] += time.time() - t0
-                if t0 - t_progress > float(os.environ.get("NFISAM_SLOT_WATCHDOG_S", "60")):
-                    tb = state["trainer"]             # a wedged conveyor must not hang the caller for ever
-                    raise RuntimeError("replica slots: no clique finished for %.0f s (chunks enqueued %d, mirror %r, waiting %r)" % (
-                        t0 - t_progress, tb.enqueued(), tb.peek(), [(r, refill_seq[r]) for r in range(R) if owner[r] is not None]))
-        if state["trainer"] is not None:
-            state["trainer"].end()
-            self._slot_last = (state["trainer"], state["key"])
-            prof["chunks"] = prof.get("chunks", 0) + state["trainer"].enqueued()
-        self.last_batches = [sum(1 for f in fits if f > k) for k in range(max(fits) if fits else 0)]
-        return results if free_running else handles
 
     def run_incrementally(self, steps, on_update=None, timers: List[List[float]] = None) -> List[list]:
         """All replicas through the same sequence of incremental steps [(new variables, new factors), ..] (reference:

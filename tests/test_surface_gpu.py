@@ -219,6 +219,45 @@ def test_fit_with_validation_split_and_multilayer():
         NFiSAM(NFiSAMArgs(flow_type="NSF_AR_CS")).fit_clique_density_model(clique, samples, [L0, X0], None)
 
 
+def test_multilayer_fit_through_the_training_plan_on_both_multilayer_kernels():
+    """`flow_number = 3` (src/slam/NFiSAM.py:387-390) with the full batch as the training set: the fit runs as a training plan of
+    the two-dims-per-wave kernel (D = 6: its panel image and parked forward state come into play from the second iteration
+    of a chunk on) and, with `NFISAM_PAIR=0`, of the split kernel.  Same early-stop rule on the same batch: the loss records
+    stay within rounding-amplified noise of each other, both fits pass the window rule, and the model samples."""
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    samples = ring_clique(2000, np.random.RandomState(3))
+    L0, X0 = R2Variable("L0", VariableType.Landmark), SE2Variable("X0")
+    clique = FakeClique(frontal=[X0], separator=[L0])
+    res = {}
+    for pair in ("0", None):
+        old = os.environ.get("NFISAM_PAIR")
+        if pair is None:
+            os.environ.pop("NFISAM_PAIR", None)
+        else:
+            os.environ["NFISAM_PAIR"] = pair
+        try:
+            np.random.seed(5); torch.manual_seed(5)
+            solver = NFiSAM(NFiSAMArgs(flow_iterations=400, num_knots=9, learning_rate=0.01, flow_number=3, loss_delta_tol=0.01))
+            model = solver.fit_clique_density_model(clique, samples, [L0, X0], None)
+            loss = np.array(solver._temp_training_loss["".join(str(v.name) for v in clique.vars)])
+            it = solver.last_fit_iterations
+            xs = model.conditional_sample_given_observation(conditional_dim=6, sample_number=64)
+            res[pair] = (it, loss[:it].copy(), xs)
+        finally:
+            if old is None:
+                os.environ.pop("NFISAM_PAIR", None)
+            else:
+                os.environ["NFISAM_PAIR"] = old
+    for it, loss, xs in res.values():
+        assert 100 <= it <= 400 and it % 50 == 0 and np.all(np.isfinite(loss)) and loss[-1] < loss[0] - 1.0
+        assert len(model.flows) == 3 and xs.shape == (64, 6) and np.all(np.isfinite(xs))
+    a, b = res["0"][1], res[None][1]
+    np.testing.assert_allclose(a[:5], b[:5], atol=2e-3)                # same initialisation, same first steps
+    m = min(len(a), len(b))
+    assert abs(a[m - 1] - b[m - 1]) < 0.15, (a[m - 1], b[m - 1])       # (trajectories drift apart by rounding, the fits agree)
+
+
 def test_device_normalisation_matches_reference_golden():
     """nfisam_normalize_columns (f-3) against the vectors produced by the reference's
     NFiSAM.normalize_training_samples (tests/golden/make_golden.py), float32 input."""

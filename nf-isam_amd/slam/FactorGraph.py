@@ -8,18 +8,20 @@ from slam.Variables import Variable, VariableType
 
 class FactorGraph(object):
     def __init__(self) -> None:
-        self._vars: List[Variable] = []
-        self._factors: List = []
+        self._vars: List[Variable] = []       # insertion order (the orderings are derived from it)
+        self._var_set: Set[Variable] = set()  # membership: the incremental solver rebuilds sub graphs of hundreds of variables
+        self._factors: List = []              # every update -- a list scan per add was 11 M __eq__ calls on Plaza1
 
     def add_node(self, var: Variable) -> "FactorGraph":
-        if var in self._vars:
+        if var in self._var_set:
             raise KeyError("The node has already existed in the graph")
         self._vars.append(var)
+        self._var_set.add(var)
         return self
 
     def add_factor(self, factor) -> "FactorGraph":
         for v in factor.vars:
-            if v not in self._vars:
+            if v not in self._var_set:
                 raise KeyError("factor %s refers to a variable that is not in the graph: %s" % (factor, v.name))
         self._factors.append(factor)
         return self

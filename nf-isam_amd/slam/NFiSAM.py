@@ -565,8 +565,10 @@ class NFiSAM(FactorGraphSolver):
             stack.extend(c.children)
         rows, cols, obs, cfg, device, max_D = [], [], [], None, None, 1
         rmap = self._reverse_ordering_map
+        models = []                            # kept alive by the handle: the walk reads their parameters until it is collected
         for clique in cliques:
             model = self._clique_density_model[clique]
+            models.append(model)
             e = model.__dict__.get("_post_entry")
             if e is None:
                 st = model.posterior_static()
@@ -596,11 +598,17 @@ class NFiSAM(FactorGraphSolver):
         K, H, B, L = cfg
         S = _nh.posterior_walk_raw(table, np.concatenate(cols), np.concatenate(obs), total_dim, num_samples, max_D,
                                    K, H, B, L, device)
-        return dict(S=S, pcol=pcol, order=list(order), start=start, stream=torch.cuda.current_stream())
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        return dict(S=S, pcol=pcol, order=list(order), start=start, stream=torch.cuda.current_stream(), keep=models, done=done)
 
-    def posterior_collect(self, handle, timer: List = None):
-        """Second half: wait for the walk, one D2H copy, per-variable views of the sample matrix."""
-        with torch.cuda.stream(handle["stream"]):
+    def posterior_collect(self, handle, timer: List = None, copy_stream=None):
+        """Second half: wait for the walk, one D2H copy, per-variable views of the sample matrix (in the elimination ordering
+        of the launch).  `copy_stream`: copy behind the walk's event on that stream instead of the walk's own (which may
+        already hold the caller's NEXT walk: slam.ReplicaNFiSAM)."""
+        if copy_stream is not None:
+            copy_stream.wait_event(handle["done"])
+        with torch.cuda.stream(copy_stream if copy_stream is not None else handle["stream"]):
             S = handle["S"].cpu().numpy()
         pcol = handle["pcol"]
         samples = {v: S[:, pcol[v]:pcol[v] + v.dim] for v in handle["order"]}

@@ -152,9 +152,14 @@ class ReplicaNFiSAM:
         loaded_at, refill_seq = [0.0] * R, [0] * R
         gens: List[object] = [None] * R
         handles: List[object] = [None] * R
+        pending: List[list] = [[] for _ in range(R)]     # (free running) posterior walks in flight: (step, handle, step start)
+        want_next = [False] * R                          # (free running) the replica's next step is to be staged
         state = {"trainer": None, "key": None}
         if len(self._streams) < R:
             self._streams = [torch.cuda.Stream() for _ in range(R)]
+        if free_running and len(self.__dict__.setdefault("_copy_streams", [])) < R:
+            self._copy_streams = [torch.cuda.Stream() for _ in range(R)]
+        self.fit_iterations = self.__dict__.get("fit_iterations") or [0] * R
 
         def shape_key(prep):
             return (prep["n"], prep["D"], prep["cfg"], str(prep["device"]))
@@ -210,6 +215,13 @@ class ReplicaNFiSAM:
             prof["posterior"] += time.time() - t0
             if not free_running:
                 finished[r] = True
+            else:
+                # the walk is in flight: the replica goes straight on to its next step (the samples are taken out when the walk's
+                # event has fired; the random draws of the walk are made, in the replica's stream, before anything of the next step)
+                pending[r].append((step_idx[r], handles[r], t_step[r]))
+                handles[r] = None
+                step_idx[r] += 1
+                want_next[r] = step_idx[r] < n_steps
 
         def train_odd():
             """Cliques of another shape than the plan's, collected since the last idle moment: ONE batched (ragged) training
@@ -220,9 +232,10 @@ class ReplicaNFiSAM:
             self.solvers[0].train_prepared([p for _, p in batch])
             dt = time.time() - t0
             prof["train"] += dt
-            for r, _ in batch:
+            for r, p in batch:
                 timers[r].append(dt / len(batch))
                 fits[r] += 1
+                self.fit_iterations[r] += int(p["iters"])
             for r, _ in batch:
                 place(r, host_step(r))
 
@@ -248,31 +261,34 @@ class ReplicaNFiSAM:
                     self.solvers[0].train_prepared([prep])
                 else:
                     prep["trained"], prep["iters"], prep["iter_loss"] = tb.kparams[r].clone(), step, tb.iter_loss[r].clone()
+                self.fit_iterations[r] += int(prep["iters"])
                 timers[r].append((time.time() - loaded_at[r]) / max(1, len(busy)))
                 fits[r] += 1
                 place(r, host_step(r))
             return bool(ready)
 
         def collect_ready():
-            """(free running) replicas whose posterior walk has finished: take the samples, go on to the next update"""
+            """(free running) stage the next step of replicas that have launched their posterior; take out the samples of walks
+            that have finished (in step order), call `on_update`.  -> any progress"""
             progress = False
             for r in range(R):
-                if handles[r] is None or finished[r] or not handles[r]["stream"].query():
-                    continue
-                t0 = time.time()
-                s = self.solvers[r]
-                s._samples = s.posterior_collect(handles[r], timer=timers[r])
-                handles[r] = None
-                prof["posterior"] += time.time() - t0
-                results[r].append(s._samples)
-                if on_update is not None:
-                    on_update(r, step_idx[r], s._samples, time.time() - t_step[r])
-                step_idx[r] += 1
-                if step_idx[r] < n_steps:
+                if want_next[r]:
+                    want_next[r] = False
                     start_step(r)
-                else:
+                    progress = True
+                while pending[r] and pending[r][0][1]["done"].query():
+                    k, handle, t_start = pending[r].pop(0)
+                    t0 = time.time()
+                    s = self.solvers[r]
+                    s._samples = s.posterior_collect(handle, timer=timers[r], copy_stream=self._copy_streams[r])
+                    prof["posterior"] += time.time() - t0
+                    results[r].append(s._samples)
+                    if on_update is not None:
+                        on_update(r, k, s._samples, time.time() - t_start)
+                    progress = True
+                if not finished[r] and step_idx[r] >= n_steps and done[r] and not pending[r] and not want_next[r]:
                     finished[r] = True
-                progress = True
+                    progress = True
             return progress
 
         # the shape of the plan: the one of the previous update if there is one (then the replicas start training one by one

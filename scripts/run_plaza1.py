@@ -35,12 +35,11 @@ if replicas > 1:
         last = [None] * replicas
 
         def on_update(r, k, samples, seconds):
-            global fit_iters
             per[r].append(seconds)
             last[r] = samples
-            fit_iters += sum(int(np.count_nonzero(v)) for v in rep.solvers[r]._temp_training_loss.values())
         rep.run_incrementally(steps[:max_updates], on_update=on_update)
         total = time.time() - t_all
+        fit_iters = sum(rep.fit_iterations)
         rm = []
         for s, o in zip(rep.solvers, last):
             poses = [v for v in s.physical_vars if str(v.name).startswith("X")]

@@ -149,8 +149,8 @@ def test_free_running_replicas_reproduce_sequential_runs(tmp_path):
         rep = ReplicaNFiSAM(_args(), seeds)
         seen = {}
 
-        def on_update(r, k, samples, seconds):        # called before replica r stages its next step: its ordering is step k's
-            seen[(r, k)] = np.hstack([samples[v] for v in rep.solvers[r].elimination_ordering])
+        def on_update(r, k, samples, seconds):        # `samples`: in the elimination ordering of step k (replica r may be a step ahead by now)
+            seen[(r, k)] = np.hstack(list(samples.values()))
         out = rep.run_incrementally(steps, on_update=on_update)
         assert sorted(seen) == [(r, k) for r in range(len(seeds)) for k in range(len(steps))]
         for r in range(len(seeds)):

@@ -98,7 +98,7 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
         if self._norm_cache is None or self._norm_cache[0] != str(device):
             mean = torch.as_tensor(self.samples_mean, dtype=torch.float32).to(device).contiguous()
             std = torch.as_tensor(self.samples_std, dtype=torch.float32).to(device).contiguous()
-            circ = torch.as_tensor(np.asarray(self.circular_dim_list, dtype=np.uint8)).to(device).contiguous()
+            circ, = _nh.upload(np.asarray(self.circular_dim_list, dtype=np.uint8), device=device)
             self._norm_cache = (str(device), mean, std, circ)
         return self._norm_cache[1:]
 
@@ -164,7 +164,7 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
         z = torch.randn(int(sample_number), conditional_dim, device=device, dtype=torch.float32)
         x_s = None
         if obs_row is not None and len(obs_row) > 0:
-            x_s = torch.as_tensor(np.asarray(obs_row, dtype=np.float32)).to(device).reshape(1, -1) \
+            x_s = _nh.upload(np.asarray(obs_row, dtype=np.float32).reshape(-1), device=device)[0].reshape(1, -1) \
                 .expand(int(sample_number), -1).contiguous()
         return self.inverse_given_separator(z, x_s)
 
@@ -300,6 +300,26 @@ class NFiSAM(FactorGraphSolver):
                              "hidden_dim in {4, 8, 16} (nf-isam_amd/csrc/nsf_units.h)" % (a.num_knots, a.hidden_dim))
         if int(a.flow_number) < 1:
             raise ValueError("flow_number must be >= 1")
+
+    # The loss curves of the update's fits (reference attribute: FactorGraphSolver._temp_training_loss, clique name ->
+    # list of per-iteration losses) are fetched from the device when somebody LOOKS at them: one copy for all fits recorded
+    # since the last look instead of one blocking copy per fit (a fit's curve is ready on the device long before that).
+    @property
+    def _temp_training_loss(self) -> dict:
+        pending = self.__dict__.get("_loss_pending")
+        if pending:
+            self.__dict__["_loss_pending"] = []
+            host = torch.cat([t for _, t in pending]).cpu().numpy().astype(np.float64)
+            off = 0
+            for name, t in pending:
+                self.__dict__["_loss_record"][name] = host[off:off + t.numel()].tolist()
+                off += t.numel()
+        return self.__dict__["_loss_record"]
+
+    @_temp_training_loss.setter
+    def _temp_training_loss(self, value: dict):
+        self.__dict__["_loss_record"] = value
+        self.__dict__["_loss_pending"] = []
 
     def _simulation_backend(self):
         if not getattr(self._args, "device_simulation", False) or not torch.cuda.is_available():
@@ -458,7 +478,7 @@ class NFiSAM(FactorGraphSolver):
         model = NormalizingFlowModelWithSeparator(flows, normal_clique, normal_separator, prep["circular"],
                                                   prep["means"], prep["stds"])
         clique_name = ''.join([str(var.name) for var in prep["clique"].vars])
-        self._temp_training_loss[clique_name] = prep["iter_loss"].cpu().numpy().astype(np.float64).tolist()
+        self.__dict__["_loss_pending"].append((clique_name, prep["iter_loss"]))
         self.last_fit_iterations = prep["iters"]
         self.last_fit_retried = bool(prep.get("retried", False))
         return model

@@ -13,3 +13,9 @@ pr.disable()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(70)
 print(s.getvalue()[:16000])
+if os.environ.get("CALLERS"):
+    s = io.StringIO()
+    st = pstats.Stats(pr, stream=s).sort_stats("tottime")
+    for pat in os.environ["CALLERS"].split(","):
+        st.print_callers(pat)
+    print(s.getvalue()[:30000])

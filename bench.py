@@ -408,17 +408,32 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the process-group branches at world size 1 too (the only way to execute the RCCL calls --
+    # init with device_id, barrier, device all-reduce, teardown -- on a 1-GPU box; needs RANK/WORLD_SIZE/MASTER_* like torchrun sets)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there,
+        # so file descriptor 1 points at stderr until the group has done its first collective
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # ---- headline: C3, resident in HBM before the timed region ---------------------------------
@@ -426,7 +441,7 @@ def main():
     wl = Workload(problem, 1, dev)
 
     def reduce_max(v):                # every replay: the slowest rank's time
-        if world == 1:
+        if not use_dist:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -514,7 +529,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -32,7 +32,10 @@ from factors.Factors import (SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaus
 mode, out = sys.argv[1], sys.argv[2]
 rank = int(os.environ.get("RANK", "0"))
 if mode != "single":
-    dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+    if os.environ.get("PAR_BACKEND") == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ["WORLD_SIZE"]), device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
 random.seed(3); np.random.seed(3 + rank); torch.manual_seed(3 + rank)
 
 # Two robots (arms) that meet: arm a = B_a (prior) -odom-> A_a -odom-> X_a, a landmark M_a ranged from B_a and A_a, and
@@ -95,7 +98,7 @@ def _mmd(a, b, sigma):
     return float(np.sqrt(max(k(a, a).mean() + k(b, b).mean() - 2 * k(a, b).mean(), 0.0)))
 
 
-def _run(tmp_path, mode, world):
+def _run(tmp_path, mode, world, backend="gloo"):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(root=ROOT))
     port = _free_port()
@@ -103,7 +106,8 @@ def _run(tmp_path, mode, world):
     for r in range(world):
         out = str(tmp_path / ("%s_rank%d.npz" % (mode, r)))
         outs.append(out)
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PAR_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -155,3 +159,42 @@ def test_bench_two_ranks_prints_the_contract_line():
     assert abs(d["value"] - 2 * d["per_gpu_value"]) < 1e-6 * d["value"]
     assert d["value"] > 1e7 and 0 < d["ms_per_step"] < 5.0
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("posterior", ["replicated", "sharded"])
+def test_one_rank_over_rccl_matches_single_process(tmp_path, posterior):
+    """The "nccl" (= RCCL) branches of `ParallelNFiSAM` -- device tensors in every collective, no host staging -- executed
+    for real: the box has one GPU, so the group has ONE rank (RCCL refuses two ranks on a device); every broadcast /
+    gather of the solver still goes through RCCL.  Same comparison as the two-rank gloo test."""
+    single = _run(tmp_path, "single", 1)[0]
+    one = _run(tmp_path, posterior, 1, backend="nccl")[0]
+    info = json.loads(str(one["info"]))
+    assert info["n_cliques"] == 5 and set(info["owners"].values()) == {0}, info
+    for v in (k for k in single if k != "info"):
+        a, b = one[v][:, :2], single[v][:, :2]
+        assert one[v].shape == single[v].shape and np.all(np.isfinite(one[v]))
+        scale = max(1.0, float(b.std(0).max()))
+        assert _mmd(a / scale, b / scale, np.sqrt(2.0)) < 0.16, v
+        assert np.linalg.norm(a.mean(0) - b.mean(0)) < 0.5 + 0.25 * scale, (v, a.mean(0), b.mean(0))
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_the_launcher_over_rccl_prints_only_the_contract_line():
+    """The driver's launch for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with the one rank a 1-GPU box
+    allows: `BENCH_FORCE_DIST=1` makes bench.py take its process-group branches at world size 1, so `init_process_group("nccl",
+    device_id=...)`, the barriers, the device all-reduce of the timings and the teardown run over RCCL.  RCCL's version banner
+    must not reach stdout: the ONLY stdout line is the JSON record."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--steps", "20", "--warmup", "5", "--no-regimes", "--no-update-bench", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=550)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 1e7
+    assert "RCCL version" in p.stderr          # the communicator really came up (its banner went to stderr)

@@ -174,6 +174,8 @@ def upload(*arrays, device):
     """Small numpy arrays -> device tensors of the same dtype and shape, ONE asynchronous copy for all of them on the
     current stream (each array starts 64-byte aligned in the transfer)."""
     arrays = [np.ascontiguousarray(a) for a in arrays]
+    if not arrays:
+        return []
     offs, total = [], 0
     for a in arrays:
         offs.append(total)

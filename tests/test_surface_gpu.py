@@ -151,6 +151,12 @@ def test_fit_clique_density_model_and_conditional_sampling():
     model = solver.fit_clique_density_model(clique, samples, [L0, X0], timer)
     np.testing.assert_array_equal(samples, keep)
     iters = solver.last_fit_iterations
+    # the loss curve stays on the device until somebody reads the reference's `_temp_training_loss` (one copy for all fits
+    # recorded since the last look); what the attribute hands out is the reference's plain {clique name: list of floats}
+    assert len(solver.__dict__["_loss_pending"]) == 1 and solver.__dict__["_loss_record"] == {}
+    record = solver._temp_training_loss
+    assert type(record) is dict and solver.__dict__["_loss_pending"] == [] and record is solver._temp_training_loss
+    assert all(isinstance(v, list) and isinstance(v[0], float) for v in record.values())
     loss = np.array(solver._temp_training_loss["".join(str(v.name) for v in clique.vars)])
     assert len(loss) == 600 and iters % 50 == 0 and 100 <= iters <= 600
     assert np.all(loss[iters:] == 0) and loss[iters - 1] < loss[0] - 0.3
@@ -591,3 +597,38 @@ def test_non_finite_batch_is_retried_once_then_raises():
     model = solver.finish_fit(p_good)
     xs = model.conditional_sample_given_observation(conditional_dim=6, sample_number=32)
     assert xs.shape == (32, 6) and np.all(np.isfinite(xs)) and 50 <= p_good["iters"] <= 100
+
+
+def test_small_uploads_through_the_pinned_ring_survive_its_reuse():
+    """`nfisam_hip.upload`: small host arrays go to the device as ONE asynchronous copy from a pinned staging ring (one ring
+    per thread and stream, 8 chunks of 64 KB).  Thousands of uploads on two streams with kernels queued in front of them --
+    so the copies really are pending when the ring comes round -- must all arrive intact: a chunk may only be overwritten
+    after the event behind its last copy has fired.  Also: several arrays per call (dtype and shape kept), an array larger
+    than a chunk (pageable fallback), an empty call."""
+    import nfisam_hip as nh
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(0)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    kept = []
+    busy = torch.randn(2048, 2048, device=dev)
+    for i in range(3000):
+        s = streams[i % 2]
+        with torch.cuda.stream(s):
+            if i % 50 == 0:
+                for _ in range(4):
+                    busy = (busy @ busy).clamp_(-1, 1)            # work in front of the copies of this stream
+            a = rng.randn(rng.randint(1, 3000)).astype(np.float32)
+            b = rng.randint(0, 255, size=(rng.randint(1, 40), 3)).astype(np.uint8)
+            c = rng.randint(-5, 5, size=rng.randint(0, 9)).astype(np.int32)
+            ta, tb, tc = nh.upload(a, b, c, device=dev)
+            assert ta.dtype == torch.float32 and tb.dtype == torch.uint8 and tc.dtype == torch.int32
+            assert tuple(tb.shape) == b.shape and tuple(tc.shape) == c.shape
+            kept.append((s, (a, b, c), (ta, tb, tc)))
+    big = rng.randn(40000).astype(np.float32)                       # > one chunk
+    tbig, = nh.upload(big, device=dev)
+    torch.cuda.synchronize()
+    for s, host, devs in kept:
+        for h, d in zip(host, devs):
+            np.testing.assert_array_equal(d.cpu().numpy(), h)
+    np.testing.assert_array_equal(tbig.cpu().numpy(), big)
+    assert nh.upload(device=dev) == []

@@ -229,9 +229,10 @@ class ReplicaNFiSAM:
         def train_odd():
             """Cliques of another shape than the plan's, collected since the last idle moment: ONE batched (ragged) training
             of all of them -- runs whose cliques keep changing shape (Manhattan) end up in lock-step batches this way, runs
-            with one dominant shape (Plaza) train the odd clique every few dozen updates on its own.  The call sits in a
-            worker thread (it releases the interpreter lock while it waits for the device; its plan has its own stream), so
-            the slots keep being served; `finish_odd` picks the results up."""
+            with one dominant shape (Plaza) train the odd clique every few dozen updates on its own.  A batch that holds a
+            minority of the replicas is trained by a worker thread (the call releases the interpreter lock while it waits
+            for the device; its plan has its own stream), so the slots keep being served and `finish_odd` picks the results
+            up; a batch that holds most of them blocks (NFISAM_ODD_THREAD=0 / 1: always block / always the thread)."""
             batch, odd[:] = list(odd), []
             err: List[BaseException] = []
             mode = os.environ.get("NFISAM_ODD_THREAD", "auto")
@@ -239,7 +240,7 @@ class ReplicaNFiSAM:
             if mode == "0" or (mode != "1" and (2 * len(batch) >= sum(1 for f in finished if not f) or busy < len(batch))):
                 # most replicas wait in this batch (runs whose cliques keep changing shape): blocking, so that the others
                 # pile up behind it and the next batch holds all of them again -- small staggered batches each pay the full
-                # latency-bound training time (measured: Manhattan 3.25 s like this, 4.16 s with every batch in the thread)
+                # latency-bound training time (Manhattan-136, eight replicas: 4.0-4.2 s either way, nothing to win there)
                 odd_job.append((None, batch, err, time.time()))
                 self.solvers[0].train_prepared([p for _, p in batch])
                 prof["train"] += time.time() - odd_job[0][3]

@@ -82,9 +82,17 @@ struct FusedAdam {
 };
 
 // sum of parameter j's gradient copies, in nsf_adam_kernel's one-thread-per-parameter order (at most 8 copies: the host checks)
+// COH: the word was written by ANOTHER block of this launch (chunk-persistent kernel: the blocks of a (clique, dim) group
+// sit on one XCD and meet at a group barrier): read it from the XCD's L2, not from this CU's vector cache.
+template <bool COH>
+__device__ __forceinline__ float group_load(const __attribute__((address_space(1))) float* p) {
+    if constexpr (COH) return __hip_atomic_load((const float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH = false>
 __device__ __forceinline__ void fused_load_grads(const FusedAdam& fa, int j, float (&gv)[8]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) gv[c] = fa.grads[(size_t)(c < fa.copies ? c : 0) * fa.gstride + j];
+    for (int c = 0; c < 8; ++c) gv[c] = group_load<COH>(&fa.grads[(size_t)(c < fa.copies ? c : 0) * fa.gstride + j]);
 }
 __device__ __forceinline__ float fused_sum_grads(const FusedAdam& fa, const float (&gv)[8]) {
     float gs = gv[0];
@@ -148,9 +156,9 @@ static inline void build_panel_map(uint32_t* map, int max_D) {
 // `st_step`, `st_stop` are the clique's state words, requested at kernel entry: they are first LOOKED AT after this
 // function's own loads have arrived (the empty asm is a use of the loaded values in front of the branch, so the loads are
 // not sunk behind it), i.e. the two round trips overlap.  -> false: the clique is finished, the block returns.
-template <int K, int H>
+template <int K, int H, bool COH = false>
 __device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta_generic, FusedAdam& fa, const uint32_t* map_generic,
-                                                 int i, int tid, int NT, int st_step, int st_stop, const TrainArgs& a, int n) {
+                                                 int i, int tid, int NT, int st_step, int st_stop, const TrainArgs& a, int n, int iter) {
     using CP = CondPanel<K, H>;
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
@@ -163,20 +171,21 @@ __device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta
         const int ja = base + tid, jb = base + NT + tid;
         const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
         const int ia = j0 + ca, ib = j0 + cb;
-        float ta = t_src[ia], tb = t_src[ib];
+        float ta = group_load<COH>(&t_src[ia]), tb = group_load<COH>(&t_src[ib]);
         uint32_t da = map[ca], db = map[cb];
         float ga[8], gb[8], ma = 0.f, va = 0.f, mb = 0.f, vb = 0.f;
         if (fa.grads != nullptr) {                             // launch-uniform: an update is pending
-            fused_load_grads(fa, ia, ga);
-            fused_load_grads(fa, ib, gb);
-            ma = fa.m_src[ia]; va = fa.v_src[ia]; mb = fa.m_src[ib]; vb = fa.v_src[ib];
+            fused_load_grads<COH>(fa, ia, ga);
+            fused_load_grads<COH>(fa, ib, gb);
+            ma = group_load<COH>(&fa.m_src[ia]); va = group_load<COH>(&fa.v_src[ia]);
+            mb = group_load<COH>(&fa.m_src[ib]); vb = group_load<COH>(&fa.v_src[ib]);
             asm volatile("" : "+v"(ga[0]), "+v"(ga[7]), "+v"(gb[0]), "+v"(gb[7]), "+v"(ma), "+v"(vb));
         }
         asm volatile("" : "+v"(ta), "+v"(tb), "+v"(da), "+v"(db));
         if (base == 0) {
-            if (st_stop != 0 || st_step + a.iter_idx >= a.max_iters) return false;     // block-uniform
+            if (st_stop != 0 || st_step + iter >= a.max_iters) return false;     // block-uniform
             if (fa.grads != nullptr)
-                fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + a.iter_idx, n);
+                fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + iter, n);
         }
         if (fa.grads != nullptr) {
             adam_update(fa.kc, fused_sum_grads(fa, ga), ma, va, ta);

@@ -75,6 +75,7 @@ struct TrainArgs {
     int pair_stash;                 // launcher-side: park it (the launch is in the workspace's size bound)
     int pair_image;                 // nsf_train3_kernel: the clique's panel image is current (written by the previous iteration's Adam kernel)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
+    int persist_iters;              // nsf_train1_kernel, chunk-persistent form: iterations 0 .. persist_iters - 1 of the chunk in ONE launch (0: one iteration per launch)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
 };

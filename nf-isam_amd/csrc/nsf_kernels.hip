@@ -191,6 +191,8 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     float part[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane];     // ring row w + 4k
+    // the group-barrier counters of the chunk-persistent training kernel (one per dim): zero at the start of every chunk
+    if (threadIdx.x < FUSED_COUNTERS) ((unsigned*)(ring + (size_t)LOSS_RING * LOSS_SLOTS))[threadIdx.x] = 0u;
     const int s0 = st->step, stop0 = st->stop, have_avg = st->have_avg;
     const float loss_avg = st->loss_avg;
     int new_step = s0, new_stop = stop0, new_have = have_avg, new_err = st->domain_err;
@@ -597,7 +599,7 @@ static bool pair_image_shape(int max_D, int K, int H, int L, const TrainShape& s
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
                         const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr,
-                        int chain = 0, int n_chains = 1, bool pair_image = false) {
+                        int chain = 0, int n_chains = 1, bool pair_image = false, int persist_iters = 0) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
@@ -613,6 +615,7 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
     a.chain = chain; a.n_chains = n_chains;
     if (single != nullptr) a.single = *single;
     a.B = B; a.L = L; a.max_iters = max_iters; a.nll_mode = 1; a.iter_idx = iter_idx;
+    a.persist_iters = persist_iters;                           // > 0: iterations 0 .. persist_iters - 1 of the chunk in this one launch
     a.pair_image = (pair_image && iter_idx > 0) ? 1 : 0;
     a.pair_ws = 1;                                             // clique descriptors: kgrad is a workspace by contract
     const NsfUnitOps* ops = find_ops(K, H);
@@ -632,16 +635,32 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
     ad.L = L; ad.K = K; ad.H = H; ad.max_n = max_n;
 }
 
+// The chunk-persistent form of the dim-major kernel (nsf_unit.hip: nsf_train1_kernel<K, H, true>) needs every block of the
+// launch resident at once: blocks spin at their group's barrier, a member that waits for a CU held by spinning blocks
+// would never arrive.  One 4-wave block per (clique, dim, 256 particles); the persistent instantiation is compiled for two
+// waves per SIMD (213 VGPRs: the loop keeps more alive; at three it spills), so two blocks fit a CU: 512 places, of which
+// a launch may take 420 (the dispatcher is not asked to pack perfectly).  NFISAM_PERSIST=0: never.
+static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L) {
+    static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
+    if (!on || host == nullptr || L != 1 || (H != 8 && H != 4) || max_D > 16) return false;
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
+    long blocks = 0;
+    for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
+    return blocks <= 420;
+}
+
 // iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel
 static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
-                        hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1) {
+                        hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1,
+                        int persist_iters = 0) {
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
     const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, sh);
-    if (!fused && n_chains > 1) return NFISAM_ERR_ARG;
+    if (!fused && (n_chains > 1 || persist_iters > 0)) return NFISAM_ERR_ARG;
     const bool image = !fused && pair_image_shape(max_D, K, H, L, sh);
     int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
-                          fused ? cfg : nullptr, host_cliques, chain, n_chains, image);
+                          fused ? cfg : nullptr, host_cliques, chain, n_chains, image, persist_iters);
     if (rc || fused) return rc;
     AdamArgs ad;
     fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
@@ -778,6 +797,8 @@ extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques
 }
 
 // ---- training plan: descriptors + (optionally) a hipGraph of `chunk` iterations, built once ----
+static std::atomic<bool> g_persist_busy{false};      // a run of a chunk-persistent graph is in flight in this process (nfisam_nsf_train_plan_run)
+
 struct nfisam_train_plan {
     std::vector<nfisam_clique> host;
     const nfisam_clique* dev = nullptr;
@@ -790,6 +811,8 @@ struct nfisam_train_plan {
     std::vector<hipEvent_t> side_ev;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_p = nullptr;          // the same chunk as ONE chunk-persistent launch per chain (persist_shape), or null
+    hipGraphExec_t exec_p = nullptr;
     nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
                                            // writes it (last word written: reserved[0] = chunks closed in this run)
     nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
@@ -822,6 +845,8 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p->cap) (void)hipStreamSynchronize(p->cap);       // a chunk enqueued ahead of an early stop may still be draining
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->exec_p) (void)hipGraphExecDestroy(p->exec_p);
+    if (p->graph_p) (void)hipGraphDestroy(p->graph_p);
     if (p->ev) (void)hipEventDestroy(p->ev);
     for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -885,6 +910,10 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
             if (e == hipSuccess) { p->side.push_back(st); e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming); }
             if (e == hipSuccess) p->side_ev.push_back(ev2);
         }
+        const bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L) && p->chunk > 1;
+        for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
+        const bool persist = pass == 1;
+        hipGraph_t* graph_out = persist ? &p->graph_p : &p->graph;
         if (e == hipSuccess) e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
@@ -892,10 +921,10 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
                 e = hipEventRecord(p->ev, p->cap);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->side[g - 1], p->ev, 0);
             }
-            for (int it = 0; it < p->chunk && status == NFISAM_OK && e == hipSuccess; ++it)
+            for (int it = 0; it < (persist ? 1 : p->chunk) && status == NFISAM_OK && e == hipSuccess; ++it)
                 for (int g = 0; g < chains && status == NFISAM_OK; ++g)
                     status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it,
-                                          g == 0 ? p->cap : p->side[g - 1], p->host.data(), g, chains);
+                                          g == 0 ? p->cap : p->side[g - 1], p->host.data(), g, chains, persist ? p->chunk : 0);
             for (int g = 1; g < chains && e == hipSuccess; ++g) {      // join
                 e = hipEventRecord(p->side_ev[g - 1], p->side[g - 1]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->cap, p->side_ev[g - 1], 0);
@@ -903,9 +932,11 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
             if (status == NFISAM_OK && e == hipSuccess)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
                                            p->cap, p->hst_dev);
-            e = hipStreamEndCapture(p->cap, &p->graph);
+            e = hipStreamEndCapture(p->cap, graph_out);
         }
-        if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+        if (e == hipSuccess && status == NFISAM_OK)
+            e = hipGraphInstantiate(persist ? &p->exec_p : &p->exec, *graph_out, nullptr, nullptr, 0);
+        }
         if (e != hipSuccess || status != NFISAM_OK) {
             if (e != hipSuccess) nfisam_g_last_hip_error = (int)e;
             nfisam_nsf_train_plan_destroy(p);
@@ -952,6 +983,19 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     }
     // An error return must not leave graph work running on buffers the caller is about to reset or free: every
     // failure path drains the work stream first.
+    // The chunk-persistent graph needs its blocks resident at once (persist_shape): ONE run per process uses it at a time
+    // (two of them could each hold the places the other's late blocks wait for); the others, and hand-stepped runs, take
+    // the plain graph -- same results bit for bit.
+    const bool persist = p->exec_p != nullptr && !g_persist_busy.exchange(true);
+    hipGraphExec_t const exec = persist ? p->exec_p : p->exec;
+    struct Release {
+        bool on; nfisam_train_plan* p; hipStream_t* w;
+        ~Release() {
+            if (!on) return;
+            if (p->ahead) { (void)hipStreamSynchronize(*w); p->ahead = false; }   // (behind a stop: one launch that returns at once)
+            g_persist_busy.store(false);
+        }
+    } release{persist, p, &work};
     auto fail = [&](int rc) { (void)hipStreamSynchronize(work); return rc; };
     // Nothing of an earlier run writes the mirror any more: its last closed chunk was waited for, and a chunk enqueued
     // ahead of an early stop only republishes the final state, so restarting the sequence needs that chunk drained.
@@ -963,8 +1007,8 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     auto launch_chunk = [&]() -> int {
         const int left = p->cfg.max_iters - launched * p->chunk;
         const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
-        if (p->exec && todo == p->chunk) {
-            const hipError_t e = hipGraphLaunch(p->exec, work);
+        if (exec && todo == p->chunk) {
+            const hipError_t e = hipGraphLaunch(exec, work);
             if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
         } else {
             for (int it = 0; it < todo; ++it) {

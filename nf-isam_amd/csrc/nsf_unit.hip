@@ -672,8 +672,15 @@ constexpr int TRAIN1_KERNARG_CLIQUES = 8;
 struct Train1Few { nfisam_clique c[TRAIN1_KERNARG_CLIQUES]; };
 constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);   // kernel-argument offset of `few` (asserted on the host)
 
-template <int K, int H>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(H == 16 ? 2 : 3, 8)))
+// PERSIST (chunk-persistent form, launches that are resident at once): the block stays for a.persist_iters iterations.  With
+// one layer a (clique, dim) group is an optimisation problem of its own, so only the group's blocks (one XCD by the grid's
+// construction: blockIdx.x = XCD) have to meet per iteration: every block writes its gradient copy as in the plain form,
+// the group passes ONE barrier (a counter in the clique's workspace; the copies and the Adam state alternate between two
+// buffers, so nobody overwrites what a slower block still reads), and the fused Adam update of the next iteration reads
+// the copies back from the XCD's L2 (device-scope loads: the CU's vector cache may hold the lines of two iterations ago).
+// The particle tile stays in LDS; no kernel boundary, no cold prologue.  Same arithmetic in the same order: bit-identical.
+template <int K, int H, bool PERSIST = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || PERSIST) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
@@ -732,11 +739,13 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
     // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
     // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
-    const int par = (a.fused_adam != 0) ? (a.iter_idx & 1) : 0;
-    const bool pending = a.fused_adam != 0 && a.iter_idx > 0;
+    gfloat* const G0 = G;
     gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
     gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
-    const gfloat* Gprev = par ? G : Gset1;                    // copy 0 of the previous iteration
+    int it = PERSIST ? 0 : a.iter_idx;                        // iteration inside the chunk
+    int par = (a.fused_adam != 0) ? (it & 1) : 0;
+    bool pending = a.fused_adam != 0 && it > 0;
+    const gfloat* Gprev = par ? G0 : Gset1;                   // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
     const int xrows = h_xrows;                                // rows of a particle tile in LDS (largest D of the launch)
@@ -758,6 +767,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
+    const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
+    if (PERSIST && bx >= members) return;
+    const bool has_tile = p0 < n;
 
     STAMP_DECL
     STAMP(0);
@@ -809,15 +821,17 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             store(c0, xr);
         }
     };
+  for (;;) {                                                  // (PERSIST: the iterations of the chunk; else one pass)
     {
         // the one workgroup barrier in front of the tile loop: the block's waves share the (clique, dim) and so the panel
         float xr[16];
-        if (p0 < n) fetch(p0, 0, xr);
+        const bool first = !PERSIST || it == 0;               // the particle tile stays in LDS between the iterations of a chunk
+        if (first && p0 < n) fetch(p0, 0, xr);
         {
             FusedAdam fa;
             fa.grads = pending ? Gprev : nullptr;
             fa.gstride = gstride;
-            fa.copies = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;
+            fa.copies = members;
             // state before the pending update: the buffer of the previous iteration's parity (even: the clique's own)
             const gfloat* own_t = (const gfloat*)kparams;
             const bool src_alt = pending && par == 0;
@@ -828,18 +842,20 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (!stage_cond_panel<K, H>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n)) return;
+            if (!stage_cond_panel<K, H, PERSIST>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it)) return;
             __syncthreads();
         }
-        if (p0 >= n) return;
+        if (!PERSIST && p0 >= n) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
         STAMP(11);
 #endif
-        store(0, xr);
-        load_tile(p0, 16);
+        if (first && has_tile) {
+            store(0, xr);
+            load_tile(p0, 16);
+        }
     }
 
-    for (int tt = 0; tt < T; ++tt) {
+    for (int tt = 0; tt < T && has_tile; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
         PSTAMP(1, lossv, r0);
@@ -999,7 +1015,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
         // and write the copy with consecutive 16-byte stores.
         float* frag = stg;                                     // 24 rows: room for every dim's block
-        if (i == 0) {
+        if (!has_tile) {
+            // (PERSIST: a wave without particles stays for the staging of the following iterations)
+        } else if (i == 0) {
             if (lane < PoP) frag[lane] = r0;
         } else {
             float* fw = frag + LY::oW2(i);
@@ -1025,18 +1043,33 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             }
             for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
         }
+        // the block's loss: the waves' sums added in wave order by ONE thread (below), then one atomic per block into a ring
+        // slot shared by at most two blocks of the clique while D x blocks <= 128 -- a sum of two floats does not depend on
+        // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
+        {
+            const float wtot = wave_sum(lossv);
+            if (lane == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
+        }
         __syncthreads();                                      // waves without a tile left before the panel barrier
         const int waves_c = (n + (TILE << ts) - 1) >> (6 + ts);
         const int alive = (waves_c - (bx << ws) < W) ? waves_c - (bx << ws) : W;
         const int nj4 = ((i == 0) ? PoP : LY::block(i)) >> 2;
         gvf4_t* Gc = (gvf4_t*)(G + ((i == 0) ? 0 : LY::off(i)));
-        for (int e = threadIdx.x; e < nj4; e += 64 * alive) {
+        for (int e = threadIdx.x; e < nj4 && w < alive; e += 64 * alive) {
             f32x4 sum = *(const f32x4*)&tiles0[4 * e];
             for (int ww = 1; ww < alive; ++ww) {
                 const f32x4 o = *(const f32x4*)&tiles0[(size_t)ww * wave_floats + 4 * e];
                 sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
             }
             Gc[e] = sum;
+        }
+        if (threadIdx.x == 0) {
+            float bl = 0.0f;
+            for (int ww = 0; ww < alive; ++ww) bl += tiles0[(size_t)ww * wave_floats + (16 + H) * XS + 64];
+            gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                    (((i * members + bx) >> 1) & (LOSS_SLOTS - 1))]
+                                          : (gfloat*)a.loss_sum;
+            if (dst != nullptr) gsink(dst, bl, false);
         }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
         STAMP(12);
@@ -1081,13 +1114,45 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         }
     }
     PSTAMP(9, lossv, r0);
-    const float tot = wave_sum(lossv);
-    if (lane == 0) {
-        gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
+    const float tot = slab ? 0.0f : wave_sum(lossv);
+    if (lane == 0 && has_tile && !slab) {
+        gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
                                                 ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
                                       : (gfloat*)a.loss_sum;
         if (dst != nullptr) gsink(dst, tot, false);
     }
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (++it >= a.persist_iters) break;
+        // ---- the group's blocks meet: this block's copy is in L2 (vmcnt: its stores are acknowledged), then everybody's is ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;       // zero at the start of every chunk (nsf_bookkeep_kernel)
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(it * members);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {                   // a member that never became resident: give up loudly (non-finite loss -> domain error)
+                    if (st != nullptr) ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS] = __builtin_nanf("");
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        par = it & 1;
+        pending = a.fused_adam != 0;
+        Gprev = par ? G0 : Gset1;
+        G = (par ? Gset1 : G0) + (slab ? (size_t)bx * gstride : (size_t)0);
+        Gb = G + LY::off(i > 0 ? i : 1);
+        lossv = 0.0f; r0 = 0.0f;
+        c1 = f32x4{0.f, 0.f, 0.f, 0.f}; c0 = c1; cb1 = c1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
+    }
+  }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
     if (STAMP_SEL && lane < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane];
 #endif
@@ -2583,7 +2648,9 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const size_t lds = ((size_t)PANEL_BASE + CondPanel<KK, HH>::floats(max_D) + ONES_ROW + (size_t)W * train1_wave_floats(max_D, HH)) * sizeof(float);
         size_t lds_launch = lds;
         if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
-        rc = set_lds(nsf_train1_kernel<KK, HH>, lds_launch);
+        const bool persist = a.persist_iters > 0;
+        if (persist && (T != 1 || !a.slab || !a.fused_adam || a.L != 1 || max_D > FUSED_COUNTERS)) return NFISAM_ERR_ARG;
+        rc = persist ? set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch) : set_lds(nsf_train1_kernel<KK, HH>, lds_launch);
         if (rc) return rc;
         // few cliques: their descriptors travel in the kernel arguments (host copy: the plan's, or the single one)
         static_assert(offsetof(Train1Head, shifts) == 32 && sizeof(Train1Head) == 40, "scalar head of the kernel arguments");
@@ -2601,7 +2668,11 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int octets = (a.groups + 7) / 8;
         const int gz = (octets - ch + nch - 1) / nch;          // octets ch, ch + nch, ...
         if (nch > 255 || ch < 0 || ch >= nch) return NFISAM_ERR_ARG;
-        if (gz > 0)
+        if (gz > 0 && persist)
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+                               a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
+                               a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
+        else if (gz > 0)
             hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
                                a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
                                a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);

@@ -44,6 +44,29 @@ __global__ void __launch_bounds__(256) k(Ctl* c, float* data, int iters, int pay
     if (acc == -1.f) *sink = acc;
 }
 
+// One barrier per iteration: the blocks ADD their partials into an L2-resident accumulator (three rotating buffers: after the
+// barrier of iteration i every read of buffer i - 1 is over, so member 0 zeroes it for iteration i + 2), meet once, read the sums.
+__global__ void __launch_bounds__(256) k1(Ctl* c, float* data, int iters, int payload, int members, int work, float* sink) {
+    const unsigned g = blockIdx.x + 8 * blockIdx.z;
+    const unsigned me = blockIdx.y;
+    float* accum = data + (size_t)g * 3 * payload;
+    float acc = 0.f;
+    unsigned phase = 0;
+    for (int it = 0; it < iters; ++it) {
+        float v = (float)it;
+        for (int q = 0; q < work; ++q) v = __builtin_fmaf(v, 1.0001f, 0.5f);
+        float* buf = accum + (size_t)(it % 3) * payload;
+        for (int e = threadIdx.x; e < payload; e += 256) __hip_atomic_fetch_add(&buf[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        group_barrier(&c->ctr[g * 32], ++phase * members, &c->err);
+        for (int e = threadIdx.x; e < payload; e += 256) acc += __hip_atomic_load(&buf[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (me == 0) {
+            float* old = accum + (size_t)((it + 2) % 3) * payload;
+            for (int e = threadIdx.x; e < payload; e += 256) __hip_atomic_store(&old[e], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (acc == -1.f) *sink = acc;
+}
+
 int main() {
     Ctl* c; CK(hipMalloc(&c, sizeof(Ctl)));
     float* data; CK(hipMalloc(&data, sizeof(float) * 256 * 16 * 1024));
@@ -68,6 +91,24 @@ int main() {
         Ctl h; CK(hipMemcpy(&h, c, sizeof(Ctl), hipMemcpyDeviceToHost));
         printf("%d blocks x %2d groups (%s), payload %3d floats, work %4d: %.2f us per iteration (two barriers + copies)%s\n", members, groups,
                same ? "one XCD per group " : "group across XCDs", payload, work, ms * 1e3 / iters, h.err ? "  [SPIN TIMEOUT]" : "");
+    }
+    const int cfg1[][4] = {{8, 16, 640, 0}, {8, 16, 640, 2000}, {8, 96, 640, 0}, {4, 16, 640, 0}, {2, 16, 640, 0}};     // members, groups, payload, work
+    for (auto& cf : cfg1) {
+        int members = cf[0], groups = cf[1], payload = cf[2], work = cf[3], iters = 500;
+        void* args[] = {&c, &data, &iters, &payload, &members, &work, &sink};
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipMemset(c, 0, sizeof(Ctl)));
+            CK(hipMemset(data, 0, sizeof(float) * 256 * 16 * 1024));
+            CK(hipEventRecord(e0));
+            CK(hipLaunchCooperativeKernel((const void*)k1, dim3(8, members, groups / 8), dim3(256), args, 0, 0));
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        Ctl h; CK(hipMemcpy(&h, c, sizeof(Ctl), hipMemcpyDeviceToHost));
+        printf("ONE barrier + atomic accumulation: %d blocks x %2d groups (one XCD per group), payload %3d floats, work %4d: %.2f us per iteration%s\n",
+               members, groups, payload, work, ms * 1e3 / iters, h.err ? "  [SPIN TIMEOUT]" : "");
     }
     return 0;
 }

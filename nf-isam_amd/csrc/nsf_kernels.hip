@@ -797,6 +797,7 @@ extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques
 }
 
 // ---- training plan: descriptors + (optionally) a hipGraph of `chunk` iterations, built once ----
+static std::atomic<int> g_hand_stepped{0};            // hand-stepped runs between `begin` and `end` (conveyors of chunks: they fill the machine)
 static std::atomic<bool> g_persist_busy{false};      // a run of a chunk-persistent graph is in flight in this process (nfisam_nsf_train_plan_run)
 
 struct nfisam_train_plan {
@@ -831,6 +832,7 @@ struct nfisam_train_plan {
     hipEvent_t ev_end = nullptr;           // `end` records this one: the caller's stream may still hold the wait on it when the next
                                            // `begin` records p->ev -- re-recording an event a stream still waits for ties that wait to
                                            // the NEW record on this runtime (the stream then waits for itself)
+    bool stepping = false;                 // between `begin` and `end` (counted in g_hand_stepped)
     std::mutex enqueue_mu;                 // a chunk's graph launch and a slot's refill must not interleave on the stream: a graph
                                            // launch is not one atomic enqueue for a second thread (a state reset landed mid-chunk)
 };
@@ -842,6 +844,7 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
         p->feed_quit.store(1);
         p->feeder.join();
     }
+    if (p->stepping) { p->stepping = false; g_hand_stepped.fetch_sub(1); }
     if (p->cap) (void)hipStreamSynchronize(p->cap);       // a chunk enqueued ahead of an early stop may still be draining
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
@@ -986,7 +989,9 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     // The chunk-persistent graph needs its blocks resident at once (persist_shape): ONE run per process uses it at a time
     // (two of them could each hold the places the other's late blocks wait for); the others, and hand-stepped runs, take
     // the plain graph -- same results bit for bit.
-    const bool persist = p->exec_p != nullptr && !g_persist_busy.exchange(true);
+    // (not next to a conveyor either: its launches take every place as soon as one is free, the persistent blocks would
+    //  spin at their barriers for members that queue behind them)
+    const bool persist = p->exec_p != nullptr && g_hand_stepped.load() == 0 && !g_persist_busy.exchange(true);
     hipGraphExec_t const exec = persist ? p->exec_p : p->exec;
     struct Release {
         bool on; nfisam_train_plan* p; hipStream_t* w;
@@ -1085,6 +1090,7 @@ extern "C" int nfisam_nsf_train_plan_begin(nfisam_train_plan* p, nfisam_stream_t
     p->enqueued.store(0);
     p->refills.store(0);
     p->feed_error.store(0);
+    if (!p->stepping) { p->stepping = true; g_hand_stepped.fetch_add(1); }
     return NFISAM_OK;
 }
 extern "C" int nfisam_nsf_train_plan_enqueue(nfisam_train_plan* p) {
@@ -1188,6 +1194,7 @@ extern "C" int nfisam_nsf_train_plan_end(nfisam_train_plan* p, nfisam_stream_t s
     if (p->ev_end == nullptr) HIP_TRY(hipEventCreateWithFlags(&p->ev_end, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(p->ev_end, p->cap));        // the caller's stream continues behind everything enqueued here
     HIP_TRY(hipStreamWaitEvent(user, p->ev_end, 0));
+    if (p->stepping) { p->stepping = false; g_hand_stepped.fetch_sub(1); }
     return NFISAM_OK;
 }
 

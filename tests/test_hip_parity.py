@@ -961,3 +961,52 @@ def test_plan_as_a_conveyor_of_chunks_trains_every_slot_like_a_plan_of_its_own()
         torch.cuda.synchronize()
         assert tb.enqueued() < 200                               # no chunks launched for an idle conveyor
     tb.close()
+
+
+PERSIST_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "nf-isam_amd")); sys.path.insert(0, %(root)r)
+import nfisam_hip as nh
+dev = torch.device("cuda", 0)
+K, H, B = 9, 8, 5.0
+out = {}
+for name, shapes, iters, window, tol in (("plaza", [(2000, 15)], 230, 50, 0.0), ("two_ragged", [(1500, 11), (777, 16)], 200, 50, 0.0),
+                                         ("early_stop", [(2000, 7)], 600, 50, 0.05), ("tiny", [(64, 3)], 120, 40, 0.0)):
+    gen = torch.Generator().manual_seed(len(name))
+    xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
+    kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(dev), D, K, H, 1) for n, D in shapes]
+    tb = nh.TrainBatch(xs, kp, K, H, B, 1, lr=0.01, max_iters=iters, average_window=window, loss_delta_tol=tol, early_stop=True)
+    done = tb.run()
+    for c in range(len(shapes)):
+        out["%%s_%%d_params" %% (name, c)] = tb.kparams[c].cpu().numpy()
+        out["%%s_%%d_loss" %% (name, c)] = tb.iter_loss[c].cpu().numpy()
+        out["%%s_%%d_iters" %% (name, c)] = np.array(done[c])
+    tb.close()
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.timeout(300)
+def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tmp_path):
+    """The chunk-persistent form of the dim-major kernel (a chunk's iterations in ONE launch per chain, the blocks of a
+    (clique, dim) group meeting at a barrier in L2; default for launches that are resident at once) against
+    NFISAM_PERSIST=0 (one launch per iteration): the same parameters, loss records and early-stop iterations, bit for bit --
+    a Plaza-shaped clique (230 iterations: full chunks of 50 through the persistent graph, the last 30 eagerly), two ragged
+    cliques in one plan, a run that stops early, a clique of one tile.  (The knob is read once per process.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(PERSIST_WORKER % dict(root=root))
+    res = {}
+    for knob in ("1", "0"):
+        out = str(tmp_path / ("persist_%s.npz" % knob))
+        p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, NFISAM_PERSIST=knob), capture_output=True,
+                           text=True, timeout=200)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[knob] = dict(np.load(out))
+    assert res["1"].keys() == res["0"].keys()
+    for k in res["1"]:
+        np.testing.assert_array_equal(res["1"][k], res["0"][k], err_msg=k)
+    assert int(res["1"]["early_stop_0_iters"]) < 600 and int(res["1"]["plaza_0_iters"]) == 230
+    assert np.all(np.isfinite(res["1"]["plaza_0_loss"][:230])) and res["1"]["plaza_0_loss"][229] < res["1"]["plaza_0_loss"][0]

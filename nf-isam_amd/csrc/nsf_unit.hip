@@ -1055,6 +1055,14 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         const int alive = (waves_c - (bx << ws) < W) ? waves_c - (bx << ws) : W;
         const int nj4 = ((i == 0) ? PoP : LY::block(i)) >> 2;
         gvf4_t* Gc = (gvf4_t*)(G + ((i == 0) ? 0 : LY::off(i)));
+        if (threadIdx.x == 64 * (alive - 1)) {                 // (the block's LAST wave with a tile: it has the fewest fragments to add below)
+            float bl = 0.0f;
+            for (int ww = 0; ww < alive; ++ww) bl += tiles0[(size_t)ww * wave_floats + (16 + H) * XS + 64];
+            gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                    (((i * members + bx) >> 1) & (LOSS_SLOTS - 1))]
+                                          : (gfloat*)a.loss_sum;
+            if (dst != nullptr) gsink(dst, bl, false);
+        }
         for (int e = threadIdx.x; e < nj4 && w < alive; e += 64 * alive) {
             f32x4 sum = *(const f32x4*)&tiles0[4 * e];
             for (int ww = 1; ww < alive; ++ww) {
@@ -1062,14 +1070,6 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
             }
             Gc[e] = sum;
-        }
-        if (threadIdx.x == 0) {
-            float bl = 0.0f;
-            for (int ww = 0; ww < alive; ++ww) bl += tiles0[(size_t)ww * wave_floats + (16 + H) * XS + 64];
-            gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
-                                                    (((i * members + bx) >> 1) & (LOSS_SLOTS - 1))]
-                                          : (gfloat*)a.loss_sum;
-            if (dst != nullptr) gsink(dst, bl, false);
         }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
         STAMP(12);

@@ -11,5 +11,5 @@ for r in $(seq 0 $((R-1))); do
 done
 for p in "${pids[@]}"; do wait $p; done
 t1=$(date +%s.%N)
-echo "processes: $R runs in $(echo "$t1 - $t0" | bc) s wall (includes python start-up + import of every process)"
+echo "processes: $R runs from $t0 to $t1 (includes python start-up + import of every process)"
 for r in $(seq 0 $((R-1))); do tail -1 /tmp/proc_rep_$r.log | cut -c1-200; done

@@ -639,10 +639,11 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 // launch resident at once: blocks spin at their group's barrier, a member that waits for a CU held by spinning blocks
 // would never arrive.  One 4-wave block per (clique, dim, 256 particles); the persistent instantiation is compiled for two
 // waves per SIMD (213 VGPRs: the loop keeps more alive; at three it spills), so two blocks fit a CU: 512 places, of which
-// a launch may take 420 (the dispatcher is not asked to pack perfectly).  NFISAM_PERSIST=0: never.
+// a launch may take 420 (the dispatcher is not asked to pack perfectly; H = 16: 256 VGPRs, ~61 KB of LDS per block, the same two
+// blocks per CU).  NFISAM_PERSIST=0: never.
 static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L) {
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
-    if (!on || host == nullptr || L != 1 || (H != 8 && H != 4) || max_D > 16) return false;
+    if (!on || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > 16) return false;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
     long blocks = 0;

@@ -648,7 +648,8 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
     long blocks = 0;
     for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
-    return blocks <= 420;
+    static const long limit = getenv("NFISAM_PERSIST_BLOCKS") != nullptr ? atol(getenv("NFISAM_PERSIST_BLOCKS")) : 420;   // (measurement aid)
+    return blocks <= limit;
 }
 
 // iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel

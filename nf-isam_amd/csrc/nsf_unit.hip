@@ -679,8 +679,11 @@ constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);  
 // buffers, so nobody overwrites what a slower block still reads), and the fused Adam update of the next iteration reads
 // the copies back from the XCD's L2 (device-scope loads: the CU's vector cache may hold the lines of two iterations ago).
 // The particle tile stays in LDS; no kernel boundary, no cold prologue.  Same arithmetic in the same order: bit-identical.
+#ifndef NSF_PERSIST_WAVES
+#define NSF_PERSIST_WAVES 2      // resident waves per SIMD the chunk-persistent instantiation is compiled for (3: it spills)
+#endif
 template <int K, int H, bool PERSIST = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || PERSIST) ? 2 : 3, 8)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
@@ -826,7 +829,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         // the one workgroup barrier in front of the tile loop: the block's waves share the (clique, dim) and so the panel
         float xr[16];
         const bool first = !PERSIST || it == 0;               // the particle tile stays in LDS between the iterations of a chunk
-        if (first && p0 < n) fetch(p0, 0, xr);
+        if (!PERSIST && p0 < n) fetch(p0, 0, xr);               // (PERSIST: once per chunk, after the staging: fewer live registers)
         {
             FusedAdam fa;
             fa.grads = pending ? Gprev : nullptr;
@@ -850,11 +853,18 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         STAMP(11);
 #endif
         if (first && has_tile) {
+            if (PERSIST) fetch(p0, 0, xr);
             store(0, xr);
             load_tile(p0, 16);
         }
     }
 
+    if constexpr (PERSIST) {                                  // (zeroed HERE, not at the loop's end: nothing of them is live across the staging)
+        lossv = 0.0f; r0 = 0.0f;
+        c1 = f32x4{0.f, 0.f, 0.f, 0.f}; c0 = c1; cb1 = c1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
+    }
     for (int tt = 0; tt < T && has_tile; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
@@ -1147,10 +1157,6 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         Gprev = par ? G0 : Gset1;
         G = (par ? Gset1 : G0) + (slab ? (size_t)bx * gstride : (size_t)0);
         Gb = G + LY::off(i > 0 ? i : 1);
-        lossv = 0.0f; r0 = 0.0f;
-        c1 = f32x4{0.f, 0.f, 0.f, 0.f}; c0 = c1; cb1 = c1;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
     }
   }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0

@@ -973,7 +973,8 @@ K, B = 9, 5.0
 out = {}
 for name, shapes, iters, window, tol, H in (("plaza", [(2000, 15)], 230, 50, 0.0, 8), ("two_ragged", [(1500, 11), (777, 16)], 200, 50, 0.0, 8),
                                             ("early_stop", [(2000, 7)], 600, 50, 0.05, 8), ("tiny", [(64, 3)], 120, 40, 0.0, 8),
-                                            ("plaza_h16", [(2000, 15)], 130, 50, 0.0, 16), ("h4", [(900, 9)], 100, 50, 0.0, 4)):
+                                            ("plaza_h16", [(2000, 15)], 130, 50, 0.0, 16), ("h4", [(900, 9)], 100, 50, 0.0, 4),
+                                            ("three_wide", [(2000, 16)] * 3, 100, 50, 0.0, 8)):
     gen = torch.Generator().manual_seed(len(name))
     xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
     kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(dev), D, K, H, 1) for n, D in shapes]
@@ -994,7 +995,8 @@ def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tm
     (clique, dim) group meeting at a barrier in L2; default for launches that are resident at once) against
     NFISAM_PERSIST=0 (one launch per iteration): the same parameters, loss records and early-stop iterations, bit for bit --
     a Plaza-shaped clique (230 iterations: full chunks of 50 through the persistent graph, the last 30 eagerly), two ragged
-    cliques in one plan, a run that stops early, a clique of one tile, hidden_dim 16 and 4.  (The knob is read once per process.)"""
+    cliques in one plan, a run that stops early, a clique of one tile, hidden_dim 16 and 4, three cliques of D = 16 (384 blocks in two
+    parallel persistent launches).  (The knob is read once per process.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"

@@ -1013,3 +1013,42 @@ def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tm
         np.testing.assert_array_equal(res["1"][k], res["0"][k], err_msg=k)
     assert int(res["1"]["early_stop_0_iters"]) < 600 and int(res["1"]["plaza_0_iters"]) == 230
     assert np.all(np.isfinite(res["1"]["plaza_0_loss"][:230])) and res["1"]["plaza_0_loss"][229] < res["1"]["plaza_0_loss"][0]
+
+
+@pytest.mark.timeout(120)
+def test_concurrent_plan_runs_share_the_persistent_form_safely():
+    """Two threads run Plaza-shaped plans at the same time: only ONE run of the process may use the chunk-persistent graph
+    (two persistent launches could starve each other's late blocks), the other takes the plain graph -- and both end with
+    exactly what each of them gives alone."""
+    import threading
+    K, H, B = 9, 8, 5.0
+    dev = torch.device("cuda", 0)
+
+    def problem(seed):
+        gen = torch.Generator().manual_seed(seed)
+        x = (1.2 * torch.randn(2000, 15, generator=gen)).clamp_(-4, 4).to(dev)
+        kp = nh.pack((0.2 * torch.randn(nh.param_count(15, K, H), generator=gen)).to(dev), 15, K, H, 1)
+        return x, kp
+
+    def run(seed, out):
+        x, kp = problem(seed)
+        tb = nh.TrainBatch([x], [kp], K, H, B, 1, lr=0.01, max_iters=400, average_window=50, loss_delta_tol=0.0, early_stop=True)
+        done = tb.run()
+        torch.cuda.synchronize()
+        out[seed] = (tb.kparams[0].cpu().numpy().copy(), tb.iter_loss[0].cpu().numpy().copy(), done[0])
+        tb.close()
+
+    alone = {}
+    for seed in (1, 2, 3):
+        run(seed, alone)
+    for rep in range(3):
+        together = {}
+        threads = [threading.Thread(target=run, args=(seed, together)) for seed in (1, 2, 3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for seed in (1, 2, 3):
+            assert together[seed][2] == alone[seed][2] == 400
+            np.testing.assert_array_equal(together[seed][0], alone[seed][0])
+            np.testing.assert_array_equal(together[seed][1], alone[seed][1])

@@ -97,16 +97,15 @@ for i, (vs, fs) in enumerate(steps[:max_updates]):
     fit = sum(timer[2:-1:2]) if len(timer) > 2 else 0.0      # [graph, (sample, fit)*, posterior]
     samp = sum(timer[1:-1:2])
     poses_ = [v for v in solver.physical_vars if str(v.name).startswith("X")]
-    err_ = np.array([samples[v][:, :2].mean(0) - truth[v][:2] for v in poses_])
+    # (one mean over the stacked xy columns: a numpy call per variable costs 0.7 s over the run)
+    err_ = np.hstack([samples[v][:, :2] for v in poses_]).mean(0).reshape(-1, 2) - np.array([truth[v][:2] for v in poses_])
     rmse_ = float(np.sqrt((err_ ** 2).sum(1).mean()))
     rows.append(dict(update=i, rmse=rmse_, wall=dt, graph=timer[0], sampling=samp, fitting=fit, posterior=timer[-1],
                      cliques_trained=len(iters), iterations=sum(iters), n_vars=len(solver.physical_vars)))
     if i % int(os.environ.get('EVERY', '10')) == 0 or i == min(len(steps), max_updates) - 1:
-        poses = [v for v in solver.physical_vars if str(v.name).startswith("X")]
-        err = np.array([samples[v][:, :2].mean(0) - truth[v][:2] for v in poses])
         print("update %3d: %.3f s (graph %.3f, sampling %.3f, fit %.3f [%d cliques, %d it], posterior %.3f) vars %d "
               "traj RMSE %.2f m" % (i, dt, timer[0], samp, fit, len(iters), sum(iters), timer[-1],
-                                    len(solver.physical_vars), np.sqrt((err ** 2).sum(1).mean())), flush=True)
+                                    len(solver.physical_vars), rmse_), flush=True)
 total = time.time() - t_all
 w = np.array([r["wall"] for r in rows]); f = np.array([r["fitting"] for r in rows]); it = np.array([r["iterations"] for r in rows])
 summary = dict(updates=len(rows), total_s=total, wall_per_update_mean=float(w.mean()), wall_per_update_median=float(np.median(w)),

@@ -637,13 +637,15 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 
 // The chunk-persistent form of the dim-major kernel (nsf_unit.hip: nsf_train1_kernel<K, H, true>) needs every block of the
 // launch resident at once: blocks spin at their group's barrier, a member that waits for a CU held by spinning blocks
-// would never arrive.  One 4-wave block per (clique, dim, 256 particles); the persistent instantiation is compiled for two
+// would never arrive.  One 4-wave block per (clique, dim, 256 particles; one barrier counter per dim: D <= 64); the persistent instantiation is compiled for two
 // waves per SIMD (213 VGPRs: the loop keeps more alive; at three it spills), so two blocks fit a CU: 512 places, of which
 // a launch may take 420 (the dispatcher is not asked to pack perfectly; H = 16: 256 VGPRs, ~61 KB of LDS per block, the same two
 // blocks per CU).  NFISAM_PERSIST=0: never.
 static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L) {
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
-    if (!on || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > 16) return false;
+    if (!on || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
+    // two blocks per CU: 4 waves' tiles within 64 KB, the panel and the row of ones in the rest of the block's 80 KB
+    if ((size_t)4 * train1_wave_floats(max_D, H) * sizeof(float) > (size_t)64 * 1024) return false;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
     long blocks = 0;

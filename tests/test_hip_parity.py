@@ -974,7 +974,8 @@ out = {}
 for name, shapes, iters, window, tol, H in (("plaza", [(2000, 15)], 230, 50, 0.0, 8), ("two_ragged", [(1500, 11), (777, 16)], 200, 50, 0.0, 8),
                                             ("early_stop", [(2000, 7)], 600, 50, 0.05, 8), ("tiny", [(64, 3)], 120, 40, 0.0, 8),
                                             ("plaza_h16", [(2000, 15)], 130, 50, 0.0, 16), ("h4", [(900, 9)], 100, 50, 0.0, 4),
-                                            ("three_wide", [(2000, 16)] * 3, 100, 50, 0.0, 8)):
+                                            ("three_wide", [(2000, 16)] * 3, 100, 50, 0.0, 8), ("d24", [(1000, 24), (600, 19)], 100, 50, 0.0, 8),
+                                            ("d33", [(700, 33)], 100, 50, 0.0, 8)):
     gen = torch.Generator().manual_seed(len(name))
     xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
     kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(dev), D, K, H, 1) for n, D in shapes]

@@ -1941,12 +1941,20 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     }
     STAMP(9);
     if (a.nll_mode) {
+        // the block's loss: the waves' sums added in wave order by one thread, ONE atomic per block into a ring slot that two
+        // blocks share while the launch has <= 128 tiles (a sum of two floats does not depend on their order: the loss
+        // record is the same however the blocks happen to be timed; a third of the atomics to drain at the kernel's end)
+        __shared__ float s_wave_loss[8];
         const float tot = wave_sum(lossv);
-        if (lane == 0) {
+        if (lane == 0) s_wave_loss[w] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bl = s_wave_loss[0];
+            for (int ww = 1; ww < (int)(blockDim.x >> 6); ++ww) bl += s_wave_loss[ww];
             gfloat* dst = (st != nullptr) ? &ring[((st_step + a.iter_idx) & (LOSS_RING - 1)) * LOSS_SLOTS +
-                                                    ((blockIdx.x * 7 + w) & (LOSS_SLOTS - 1))]
+                                                    ((blockIdx.x >> 1) & (LOSS_SLOTS - 1))]
                                           : (gfloat*)a.loss_sum;
-            if (dst != nullptr) gsink(dst, tot, false);
+            if (dst != nullptr) gsink(dst, bl, false);
         }
     }
 }

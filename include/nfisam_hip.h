@@ -227,7 +227,8 @@ typedef struct nfisam_clique {
 } nfisam_clique;
 
 /* Floats the `kgrad` workspace of a clique must hold (gradient copies + a ring of 128 x 64 per-iteration
- * loss words behind them) when the largest clique of its batch has n
+ * loss words behind them + 64 counter words: the per-dim group barriers of the chunk-persistent training
+ * kernel, which the library keeps zero between chunks -- the caller provides the workspace ZEROED) when the largest clique of its batch has n
  * particles: launches of <= 128 particle tiles write per-tile partial gradients with plain stores and
  * the Adam kernel sums them in tile order (no atomics); larger ones accumulate with float atomics
  * into a single copy.  A tile is 32 particles (two-lanes-per-particle kernel) or 64 (one lane per

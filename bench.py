@@ -27,7 +27,7 @@ Prints ONE JSON line on rank 0 (driver contract), including
                  hidden_dim 16 (the reference's parameter grids sweep it, src/slam/NFiSAM.py:589-609).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
                  the reference) timed on the host cores on a bounded sample of the same workload, next to the
-                 TRUE reference's figures measured in the build container (profiles/r02_cpu_reference_vs_port.json).
+                 TRUE reference's figures measured in the build container (profiles/history/r02_cpu_reference_vs_port.json).
 """
 import argparse
 import json
@@ -195,8 +195,10 @@ class Workload:
 
     def time_iterations(self, iters, warmup, barrier, reduce_max=None):
         """`iters` training iterations of the prepared plan, timed R times (R from `iters` alone, so every rank agrees):
-        each replay restarts from the initial parameters (re-initialised in place, untimed), is bracketed by
-        barrier + synchronize on both sides and reduced with MAX over ranks; the MEDIAN replay is reported, so that one
+        each replay restarts from the initial parameters (re-initialised in place, untimed), starts behind a
+        barrier + synchronize, ends at the rank's own synchronize (the closing barrier follows, outside the clock: with
+        RCCL it is a collective of tens of microseconds that would be charged to a 0.3 ms region of an exchange-free job)
+        and is reduced with MAX over ranks; the MEDIAN replay is reported, so that one
         slow graph launch does not decide a 0.4 ms measurement.  -> (median seconds, median GPU ms, first loss, final loss)"""
         torch = self.torch
         tbw = self.batch(max(warmup, 1))
@@ -215,8 +217,9 @@ class Workload:
             ev0.record()
             done = tb.run(use_graph=True)
             ev1.record()
-            barrier()
+            torch.cuda.synchronize()             # LOCAL: this rank's K steps are done
             dt = time.perf_counter() - t0
+            barrier()                            # the closing barrier is an RCCL collective: outside dt, MAX over ranks below
             assert all(i == iters for i in done), done
             dts.append(reduce_max(dt) if reduce_max is not None else dt)
             gms.append(ev0.elapsed_time(ev1))
@@ -295,7 +298,7 @@ def cpu_baseline(problem, budget_s=12.0):
            "sample": "%s full-batch Adam iterations of the 8 C3 cliques (n=2000, D=6..12, L=1, K=9), one clique after the "
                      "other, with the PyTorch-eager CPU restatement of the reference path (oracle/nsf_torch.py), %d threads"
                      % ("/".join(str(i) for i in iters_used), cores)}
-    ref = os.path.join(ROOT, "profiles", "r02_cpu_reference_vs_port.json")
+    ref = os.path.join(ROOT, "profiles", "history", "r02_cpu_reference_vs_port.json")
     if os.path.exists(ref):   # the TRUE reference cannot travel to the GPU box: its figures were taken in the build container
         try:
             r = json.load(open(ref))
@@ -487,7 +490,7 @@ def main():
                                  "tile) unit a wave issues ~560 VALU instructions (~450 of them the spline, 64 transcendentals), "
                                  "164 v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane), 48-64 v_mfma_f32_16x16x4 "
                                  "(the weight-gradient GEMMs) and ~220 LDS instructions; on gfx950 f32 MFMA and VALU issue of a "
-                                 "SIMD do not overlap (profiles/r02_mfma_valu_issue_microbench.txt), so their times add, and under "
+                                 "SIMD do not overlap (profiles/history/r02_mfma_valu_issue_microbench.txt), so their times add, and under "
                                  "load a VALU instruction costs ~2.9 cycles of the port (profiles/r03_phase_cycles_stamps3.txt): "
                                  "the 64-clique batch (`regimes.batch64_n2000_D15`, the throughput regime) runs at ~95 % of what "
                                  "this instruction mix allows (DESIGN.md §3.1c).  333 MFLOP per launch = 2.1 us at peak: the C3 "

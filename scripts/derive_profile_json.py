@@ -20,7 +20,7 @@ out = {"_formulas": {
                        "DESIGN.md 3.1b), so this fraction understates how busy the port is",
     "instruction_counts": "SQ_INSTS_VALU includes the MFMA instructions (static count of the tile loop: ~560 VALU + 212 MFMA per unit)",
     "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024)",
-    "issue_frac": "valu_issue_frac + mfma_busy_frac (MFMA and VALU issue of a SIMD do not overlap: profiles/r02_mfma_valu_issue_microbench.txt)",
+    "issue_frac": "valu_issue_frac + mfma_busy_frac (MFMA and VALU issue of a SIMD do not overlap: profiles/history/r02_mfma_valu_issue_microbench.txt)",
     "scalar_cache_hit_rate": "SQC_DCACHE_HITS / (SQC_DCACHE_HITS + SQC_DCACHE_MISSES)"}}
 for name, key in (("C3", "c3"), ("batch64", "b64")):
     k = kernel_of(pm[key])

@@ -4,7 +4,10 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
 import nfisam_hip as nh
-nh.LIB_PATH = os.path.join(os.path.dirname(nh.LIB_PATH), "libnfisam_hip_stamps.so")
+nh.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nf-isam_amd", "csrc", "_diag", "libnfisam_hip_stamps.so")
+if not os.path.exists(nh.LIB_PATH):      # built on demand, on this box (not shipped)
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nf-isam_amd", "csrc"), "stamps"])
 import bench as BM
 dev = torch.device("cuda:0")
 n, D, L, K, H, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 9, 8, 5.0

@@ -7,7 +7,12 @@ src/slam/NFiSAM.py:317-586) on the first updates of
     small_range   example/slam/small_range_gaussian_problem/journal_paper/case1   (run_nfisam.py arguments, incremental_step 1)
     plaza1        example/slam/plaza_dataset/RangeOnlyDataset/Plaza1EFG            (run_nfisam.py:5-21, incremental_step 5)
     manhattan136  example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3 (incremental_step 1)
-with a REDUCED iteration budget (CPU: ~15-25 ms per training iteration of one clique), for several seeds, and stores
+    plaza1ada     example/slam/plaza_dataset/RangeOnlyDataset/Plaza1ADA0.4EFG      (same arguments; the first
+                  AmbiguousDataAssociationFactor enters at X4, i.e. in the first update)
+    icra          example/slam/small_range_gaussian_problem/icra_paper/case1       (file `factor_graph`; arguments = the
+                  reference-held run1/parameters: K = 5, n = 600, 80 iterations, lr .02, icra_paper/run_nfisam.py:27-95)
+with the REFERENCE'S OWN ARGUMENTS AND ITERATION BUDGET (round 4; round 3 had cut the budget to 300-400 iterations), for
+several seeds, and stores
   (i)  what the reference fed to `fit_clique_density_model` (FactorGraphSolver.py:479-495): per trained clique the
        variable ordering, the true observations and a row subsample of the training batch;
   (ii) the posterior samples of every step (the `step{i}` files run_incrementally writes) with their orderings.
@@ -18,7 +23,11 @@ The reference imports TransportMaps / dynesty / seaborn ... at module level (abs
 path): permissive stand-in modules are written to a TEMPORARY directory at run time and never committed.  The reference
 tree is read-only: the case directory is copied to a temp dir and `run_incrementally` writes its run folder there.
 
-    python tests/golden/make_pipeline_fixture.py [small_range plaza1 manhattan136] [--seeds 5] [--jobs 4]
+For `icra` the reference-held results of that case travel with the fixture as data: run1/batch1..6 (+ orderings: the
+reference's NF-iSAM posteriors of its own run), reference/step_0..2 (nested sampling; steps 3-5 hold no samples), run1/mmd
+and run1/marginal_mmd (the bars the reference published for this case).
+
+    python tests/golden/make_pipeline_fixture.py [small_range plaza1 plaza1ada manhattan136 icra] [--seeds 5] [--jobs 4]
 Workers are separate processes started with PYTHONHASHSEED=0 (set iteration order = reproducible orderings).
 """
 import argparse
@@ -35,20 +44,33 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 CASES = {
-    # name: (case dir in the reference, incremental_step, updates, NFiSAM kwargs of the reference's run script with the
-    #        iteration budget reduced, posterior samples kept per step, batch rows kept per clique)
-    "small_range": ("example/slam/small_range_gaussian_problem/journal_paper/case1", 1, 6,
-                    dict(num_knots=9, flow_iterations=400, local_sample_num=2000, learning_rate=.025, hidden_dim=8,
+    # name: (case dir in the reference, graph file, incremental_step, updates, NFiSAM kwargs of the reference's run script,
+    #        posterior samples kept per step, batch rows kept per clique, default number of seeds)
+    # run_nfisam.py:12-27 (2000 iterations, window early stop)
+    "small_range": ("example/slam/small_range_gaussian_problem/journal_paper/case1", "factor_graph.fg", 1, 6,
+                    dict(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.025, hidden_dim=8,
                          cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
-                         posterior_sample_num=500), 500, 400),
-    "plaza1": ("example/slam/plaza_dataset/RangeOnlyDataset/Plaza1EFG", 5, 4,
-               dict(num_knots=9, flow_iterations=300, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                         posterior_sample_num=1000), 500, 400, 8),
+    # plaza_dataset/run_nfisam.py:5-21
+    "plaza1": ("example/slam/plaza_dataset/RangeOnlyDataset/Plaza1EFG", "factor_graph.fg", 5, 4,
+               dict(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
                     cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
-                    average_window=50, posterior_sample_num=300), 300, 300),
-    "manhattan136": ("example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3", 1, 6,
-                     dict(num_knots=9, flow_iterations=300, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                    average_window=50, posterior_sample_num=500), 300, 300, 5),
+    "plaza1ada": ("example/slam/plaza_dataset/RangeOnlyDataset/Plaza1ADA0.4EFG", "factor_graph.fg", 5, 4,
+                  dict(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                       cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
+                       average_window=50, posterior_sample_num=500), 300, 300, 5),
+    # manhattan_plaza/run_nfisam.py:5-52 (iters = [500], loss_delta_tol 1e-9: a fixed budget)
+    "manhattan136": ("example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3",
+                     "factor_graph.fg", 1, 6,
+                     dict(num_knots=9, flow_iterations=500, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
                           cuda_training=False, elimination_method="pose_first", training_set_frac=1.0,
-                          loss_delta_tol=1e-9, average_window=50, posterior_sample_num=300), 300, 300),
+                          loss_delta_tol=1e-9, average_window=50, posterior_sample_num=500), 300, 300, 5),
+    # icra_paper/case1/run1/parameters + icra_paper/run_nfisam.py:64-75 (everything else NFiSAMArgs' defaults)
+    "icra": ("example/slam/small_range_gaussian_problem/icra_paper/case1", "factor_graph", 1, 6,
+             dict(num_knots=5, flow_iterations=80, local_sample_num=600, learning_rate=.02, flow_number=1, flow_type="NSF_AR",
+                  cuda_training=False, elimination_method="pose_first", posterior_sample_num=500,
+                  store_clique_samples=False), 500, 400, 8),
 }
 
 STUB = '''
@@ -116,7 +138,7 @@ def write_stubs(root):
 def worker(case, seed, out_path):
     """One reference run (own process, PYTHONHASHSEED=0)."""
     import random
-    ref_dir, step, updates, kwargs, n_post, n_batch = CASES[case]
+    ref_dir, graph_file, step, updates, kwargs, n_post, n_batch, _ = CASES[case]
     tmp = tempfile.mkdtemp(prefix="nfisam_ref_")
     try:
         write_stubs(os.path.join(tmp, "stubs"))
@@ -134,9 +156,9 @@ def worker(case, seed, out_path):
         RN.NFiSAM.plot2d_mean_rbt_only = lambda *a, **k: None
         case_dir = os.path.join(tmp, "case")
         os.makedirs(case_dir)
-        shutil.copy(os.path.join(REF, ref_dir, "factor_graph.fg"), case_dir)
+        shutil.copy(os.path.join(REF, ref_dir, graph_file), case_dir)
         random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
-        nodes, truth, factors = graph_file_parser(data_file=os.path.join(case_dir, "factor_graph.fg"), data_format="fg",
+        nodes, truth, factors = graph_file_parser(data_file=os.path.join(case_dir, graph_file), data_format="fg",
                                                   prior_cov_scale=0.1)
         steps = group_nodes_factors_incrementally(nodes=nodes, factors=factors, incremental_step=step)[:updates]
         solver = RN.NFiSAM(RN.NFiSAMArgs(**kwargs))
@@ -150,7 +172,12 @@ def worker(case, seed, out_path):
             fits.append(dict(update=update_no[0] - 1, vars=[v.name for v in var_ordering],
                              frontal=sorted(v.name for v in clique.frontal), dims=[int(v.dim) for v in var_ordering],
                              true_obs=np.asarray(true_obs, dtype=np.float64), batch=np.asarray(samples)[rows].astype(np.float32)))
-            return orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
+            res = orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
+            name = "".join(v.name for v in clique.vars)                       # NFiSAM.py:496-497: zero-padded loss record
+            loss = np.asarray(self._temp_training_loss.get(name, []), dtype=np.float64)
+            fits[-1]["iterations"] = int(np.count_nonzero(loss))
+            fits[-1]["final_loss"] = float(loss[np.nonzero(loss)[0][-1]]) if np.count_nonzero(loss) else float("nan")
+            return res
 
         def update(self, *a, **k):
             update_no[0] += 1
@@ -167,7 +194,8 @@ def worker(case, seed, out_path):
             out["step%d_samples" % i] = X[rows].astype(np.float32)
             out["step%d_ordering" % i] = np.array(names)
         for j, f in enumerate(fits):
-            out["fit%d_meta" % j] = np.array(json.dumps(dict(update=f["update"], vars=f["vars"], frontal=f["frontal"], dims=f["dims"])))
+            out["fit%d_meta" % j] = np.array(json.dumps(dict(update=f["update"], vars=f["vars"], frontal=f["frontal"], dims=f["dims"],
+                                                                iterations=f.get("iterations", -1), final_loss=f.get("final_loss"))))
             out["fit%d_true_obs" % j] = f["true_obs"]
             out["fit%d_batch" % j] = f["batch"]
         out["timing"] = np.array([float(t) for t in open(os.path.join(run_dir, "step_timing")).read().split()])
@@ -176,10 +204,31 @@ def worker(case, seed, out_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def reference_held(case):
+    """Result files the reference ships for the case (data, no source): stored as they are."""
+    out = {}
+    if case != "icra":
+        return out
+    d = os.path.join(REF, CASES[case][0])
+    for b in range(1, 7):
+        out["held_run1_batch%d" % b] = np.loadtxt(os.path.join(d, "run1", "batch%d" % b)).astype(np.float32)
+        out["held_run1_batch%d_ordering" % b] = np.array(open(os.path.join(d, "run1", "batch_%d_ordering" % b)).read().split())
+    for st in range(3):
+        X = np.loadtxt(os.path.join(d, "reference", "step_%d" % st))
+        rows = np.sort(np.random.RandomState(st).permutation(X.shape[0])[:2000])
+        out["held_reference_step%d" % st] = X[rows].astype(np.float32)
+        out["held_reference_step%d_ordering" % st] = np.array(open(os.path.join(d, "reference", "step_%d_ordering" % st)).read().split())
+    out["held_run1_mmd"] = np.loadtxt(os.path.join(d, "run1", "mmd"))
+    out["held_run1_marginal_mmd"] = np.loadtxt(os.path.join(d, "run1", "marginal_mmd"))
+    out["held_run1_parameters"] = np.array(open(os.path.join(d, "run1", "parameters")).read())
+    out["held_factor_graph"] = np.array(open(os.path.join(d, "factor_graph")).read())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", default=list(CASES))
-    ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--seeds", type=int, default=0, help="0 = the case's default")
     ap.add_argument("--jobs", type=int, default=4)
     ap.add_argument("--worker", nargs=3, metavar=("CASE", "SEED", "OUT"))
     args = ap.parse_args()
@@ -189,7 +238,8 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs the reference at %s (build container only)" % REF)
     work = tempfile.mkdtemp(prefix="nfisam_fixture_")
-    jobs = [(c, s, os.path.join(work, "%s_seed%d.npz" % (c, s))) for c in args.cases for s in range(args.seeds)]
+    n_seeds = {c: (args.seeds or CASES[c][7]) for c in args.cases}
+    jobs = [(c, s, os.path.join(work, "%s_seed%d.npz" % (c, s))) for c in args.cases for s in range(n_seeds[c])]
     running = []
     env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1", REF_THREADS=str(max(1, 8 // args.jobs)))
     while jobs or running:
@@ -203,9 +253,10 @@ def main():
             raise SystemExit("reference run %s seed %d failed: see %s.log" % (c, s, o))
         print("done", c, s, flush=True)
     for c in args.cases:
-        merged = {"seeds": np.arange(args.seeds), "arguments": np.array(json.dumps(CASES[c][3])),
-                  "incremental_step": np.array(CASES[c][1])}
-        for s in range(args.seeds):
+        merged = {"seeds": np.arange(n_seeds[c]), "arguments": np.array(json.dumps(CASES[c][4])),
+                  "incremental_step": np.array(CASES[c][2])}
+        merged.update(reference_held(c))
+        for s in range(n_seeds[c]):
             d = np.load(os.path.join(work, "%s_seed%d.npz" % (c, s)))
             for k in d.files:
                 merged["seed%d_%s" % (s, k)] = d[k]

@@ -52,6 +52,11 @@ extern "C" {
 #define NFISAM_ERR_LAUNCH 2       /* HIP launch or runtime failure                              */
 #define NFISAM_ERR_DOMAIN 3       /* numerical domain error flagged by a kernel (utils.py:74-76,133) */
 #define NFISAM_ERR_NO_DEVICE 4    /* no usable gfx950 device                                    */
+#define NFISAM_ERR_STALL 5        /* a chunk-persistent training launch gave up waiting for a block of its own that never
+                                   * became resident (another process or launch held its place): the plan's parameters,
+                                   * moments and loss record are those of an INCOMPLETE chunk -- not a numerical failure.
+                                   * The library takes the one-launch-per-iteration graph for every later run of the
+                                   * process; the caller re-runs the fit from its initial state (ABI 1400)          */
 
 typedef void* nfisam_stream_t;
 
@@ -202,9 +207,14 @@ typedef struct nfisam_train_state {      /* 32 bytes since ABI 1200 (the unused 
     int32_t stop;        /* set by the device when the early-stop rule fired                 */
     int32_t have_avg;    /* a previous window mean exists                                    */
     float   loss_avg;    /* previous window mean (NFiSAM.py:481-491)                         */
-    int32_t domain_err;  /* non-zero if a kernel saw a non-finite loss                       */
-    int32_t reserved[3];
+    int32_t domain_err;  /* bit 0: a kernel saw a non-finite loss; bit 1 (NFISAM_STATE_STALLED, ABI 1400): a group
+                          * barrier of a chunk-persistent launch timed out (-> NFISAM_ERR_STALL)            */
+    int32_t reserved[3]; /* [0]: a plan's host mirror counts the chunks closed in the current run; [1] (ABI 1400): the
+                          * most XCDs one (clique, dim) group of a chunk-persistent launch ran on (1 = the placement the
+                          * grid asks for; diagnostic, correctness does not depend on it)                   */
 } nfisam_train_state;
+
+#define NFISAM_STATE_STALLED 2
 
 typedef struct nfisam_adam_cfg {
     float lr, beta1, beta2, eps;      /* torch.optim.Adam defaults: betas .9/.999, eps 1e-8 (NFiSAM.py:425) */
@@ -315,6 +325,9 @@ int nfisam_nsf_train_plan_destroy(nfisam_train_plan* plan);
  *   end      pauses the feeder and orders `stream` behind everything enqueued on the plan.                */
 int nfisam_nsf_train_plan_begin(nfisam_train_plan* plan, nfisam_stream_t stream);
 int nfisam_nsf_train_plan_enqueue(nfisam_train_plan* plan);
+/* ABI 1400.  Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on (0: none has run; 1: what
+ * the grid asks for; > 1: slower, equally correct -- the group's exchange uses agent-scope write-through stores).  */
+int nfisam_nsf_train_plan_xcd_span(const nfisam_train_plan* plan);
 int nfisam_nsf_train_plan_feed(nfisam_train_plan* plan, int depth);
 long nfisam_nsf_train_plan_enqueued(const nfisam_train_plan* plan);
 int nfisam_nsf_train_plan_peek(const nfisam_train_plan* plan, nfisam_train_state* out);

@@ -83,11 +83,21 @@ struct FusedAdam {
 
 // sum of parameter j's gradient copies, in nsf_adam_kernel's one-thread-per-parameter order (at most 8 copies: the host checks)
 // COH: the word was written by ANOTHER block of this launch (chunk-persistent kernel: the blocks of a (clique, dim) group
-// sit on one XCD and meet at a group barrier): read it from the XCD's L2, not from this CU's vector cache.
+// meet at a group barrier): an agent-scope (sc1) load -- served by L2, not by this CU's vector cache, and coherent with the
+// agent-scope write-through stores of a block on ANOTHER XCD (group_store / the gradient copy's sc1 store); the grid puts a
+// group on one XCD, where both stay L2 hits, but nothing depends on that placement.
 template <bool COH>
 __device__ __forceinline__ float group_load(const __attribute__((address_space(1))) float* p) {
     if constexpr (COH) return __hip_atomic_load((const float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void group_store(__attribute__((address_space(1))) float* p, float v) {
+#ifndef NSF_PERSIST_PLAIN_STORES       // (A/B build: round 3's plain stores, coherent through ONE XCD's L2 only)
+    if constexpr (COH) __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+#endif
+    *p = v;
 }
 template <bool COH = false>
 __device__ __forceinline__ void fused_load_grads(const FusedAdam& fa, int j, float (&gv)[8]) {
@@ -191,8 +201,9 @@ __device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta
             adam_update(fa.kc, fused_sum_grads(fa, ga), ma, va, ta);
             adam_update(fa.kc, fused_sum_grads(fa, gb), mb, vb, tb);
             if (fa.t_dst != nullptr) {                         // the dim's first block records the new state
-                if (ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
-                if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
+                // (COH: read by the group's other blocks in the next iteration of the same launch: agent-scope stores)
+                if (ja < nj) { group_store<COH>(&fa.t_dst[ia], ta); group_store<COH>(&fa.m_dst[ia], ma); group_store<COH>(&fa.v_dst[ia], va); }
+                if (jb < nj) { group_store<COH>(&fa.t_dst[ib], tb); group_store<COH>(&fa.m_dst[ib], mb); group_store<COH>(&fa.v_dst[ib], vb); }
             }
         }
         if (ja < nj) { lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta; }
@@ -207,6 +218,130 @@ __device__ __forceinline__ bool stage_cond_panel(float* lds0, const float* theta
         }
     }
     return true;
+}
+
+// ---- the chunk-persistent form's staging (round 4): flag-in-data exchange instead of a barrier ------------------------------
+// Between two iterations of ONE launch the blocks of a (clique, dim) group have to see each other's gradient copies.  Round
+// 3 did that with store -> wait for the acknowledgement -> arrive at a counter -> poll the counter -> load the copies: four
+// dependent memory round trips, 8.5 k of a lone Plaza wave's 20.7 k cycles per iteration (13.2 k of 28.2 k on C3).  Now every
+// gradient word travels WITH its flag: a copy is written as 8-byte pairs (value, tag), tag = the iteration's number in the
+// run (state->step + it + 1, never 0 and never repeated for a buffer while the workspace lives: a re-used plan zeroes it), by
+// agent-scope write-through stores that nobody waits for, and the reader simply loads the pairs of all copies (8-byte
+// agent-scope loads: a pair is written and read in one piece) until every tag is the expected one.  On the critical path
+// that is the writer's store reaching L2 and the reader's load: no counter, no acknowledgement, no workgroup barrier beyond
+// the one the staging needs anyway.  The copies still alternate between two buffers with the iteration's parity: a block
+// can produce copy k + 2 only after it has seen everybody's copy k + 1, i.e. after everybody has finished reading copy k.
+// theta, m and v of the dim never leave the block between iterations: every block of the group computes the same update from
+// the same sums (bit for bit: one function, one order), so each keeps its own set in LDS; the dim's first block still
+// records them in the clique's buffers (plain stores: their readers are the NEXT kernels).
+struct PersistAdam {
+    const __attribute__((address_space(1))) float* tagged;   // previous iteration's tagged copies (copy 0), or nullptr: nothing pending (first iteration of the chunk)
+    size_t cstride;                                          // floats between tagged copies (2 per parameter)
+    int copies;
+    uint32_t tag;                                            // the tag the previous iteration's copies carry
+    const __attribute__((address_space(1))) float *m_src, *v_src;     // first iteration of the chunk: the clique's moments
+    __attribute__((address_space(1))) float *t_dst, *m_dst, *v_dst;   // written by the dim's first block only (else nullptr)
+    unsigned looks;                                          // (diagnostic builds: unsuccessful looks of this thread, summed over the call)
+    float* keep;                                             // LDS: theta | m | v of this dim, `kstride` floats each
+    int kstride;
+    unsigned* ctr;                                           // the dim's control word: bit 31 = the group's abort flag
+    int spin_log2;
+    AdamCoef kc;
+};
+
+// -> 0: staged; 1: the clique is finished (the block returns); 2: gave up waiting for a copy (the group's abort flag is up)
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                        int i, int tid, int NT, int st_step, int st_stop, const TrainArgs& a, int n, int iter) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    typedef const __attribute__((address_space(1))) unsigned long long* gq;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    int gave_up = 0;
+    // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
+    if (st_stop != 0 || st_step + iter >= a.max_iters) return 1;     // block-uniform
+    if (pending) fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + iter, n);
+    for (int base = 0; base < nj; base += 2 * NT) {
+        const int ja = base + tid, jb = base + NT + tid;
+        const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
+        const int ia = j0 + ca, ib = j0 + cb;
+        uint32_t da = map[ca], db = map[cb];
+        float ta, tb, ma, va, mb, vb;
+        float ga[8], gb[8];
+        if (!pending) {                                        // launch-uniform per iteration: the chunk's first iteration
+            ta = t_src[ia]; tb = t_src[ib];
+            ma = fa.m_src[ia]; va = fa.v_src[ia];
+            mb = fa.m_src[ib]; vb = fa.v_src[ib];
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(ma), "+v"(va), "+v"(mb), "+v"(vb), "+v"(da), "+v"(db));
+        } else {
+            ta = fa.keep[ca]; ma = fa.keep[fa.kstride + ca]; va = fa.keep[2 * fa.kstride + ca];
+            tb = fa.keep[cb]; mb = fa.keep[fa.kstride + cb]; vb = fa.keep[2 * fa.kstride + cb];
+            // the copies' (value, tag) pairs of this thread's two parameters: all sixteen loads in flight, again until every
+            // tag is this iteration's (a copy whose block is still computing shows the tag of two iterations ago, or 0)
+            unsigned spins = 0;
+            for (;;) {
+                unsigned long long qa[8], qb[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const size_t o = (size_t)(c < fa.copies ? c : 0) * fa.cstride;
+                    qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qb[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag && (uint32_t)(qb[c] >> 32) == fa.tag;
+                    ga[c] = __uint_as_float((uint32_t)qa[c]);
+                    gb[c] = __uint_as_float((uint32_t)qb[c]);
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+#if defined(NSF_STAMPS)
+                ++fa.looks;
+#endif
+                // every 64 looks: has a member of the group given up?  after 2^spin_log2 looks: give up (and say so)
+                if ((spins & 63u) == 0u) {
+                    const bool timeout = spins > (1u << fa.spin_log2);
+                    if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) { gave_up = 1; break; }
+                }
+            }
+        }
+        if (pending) {
+            FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
+            sum_order.copies = fa.copies;
+            adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+            adam_update(fa.kc, fused_sum_grads(sum_order, gb), mb, vb, tb);
+            if (fa.t_dst != nullptr) {                         // the dim's first block records the new state (read by later KERNELS)
+                if (ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
+                if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
+            }
+        }
+        if (ja < nj) {
+            fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
+            lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
+        }
+        if (jb < nj) {
+            fa.keep[cb] = tb; fa.keep[fa.kstride + cb] = mb; fa.keep[2 * fa.kstride + cb] = vb;
+            lds0[db & 0x7fffu] = (db & PANEL_SCALED) ? tb * kTanhScale : tb; lds0[db >> 16] = tb;
+        }
+    }
+    if (i > 0 && !pending) {                                   // (the zero weights behind W0's rows stay: the panel is the block's for the whole chunk)
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    return gave_up ? 2 : 0;
 }
 
 // acc[g * SPLIT + (q % SPLIT)][u] += sum over the quads q < NK/4 of  A[4g + u][4q + v] * b[4q + v]

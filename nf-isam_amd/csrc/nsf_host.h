@@ -76,6 +76,7 @@ struct TrainArgs {
     int pair_image;                 // nsf_train3_kernel: the clique's panel image is current (written by the previous iteration's Adam kernel)
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     int persist_iters;              // nsf_train1_kernel, chunk-persistent form: iterations 0 .. persist_iters - 1 of the chunk in ONE launch (0: one iteration per launch)
+    int persist_spins;              // ... log2 of the polls a block waits at its group barrier before it raises the group's abort flag (22; NFISAM_PERSIST_SPINS: tests)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
 };
@@ -97,6 +98,9 @@ struct NsfUnitOps {
     // device-resident panel map + the offsets of each clique width's map in it (nsf_cond_mfma.h: build_pair_map)
     size_t (*pair_lds)(int L, int max_D);
     int (*pair_map)(const uint32_t** map, uint32_t* offsets /* [PAIR_MAP_OFFSETS] */);
+    // blocks of the chunk-persistent dim-major kernel (4 waves, tiles of max_D rows) the CURRENT DEVICE holds at once:
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units (0: no such kernel / the query failed)
+    long (*persist_places)(int max_D);
 };
 constexpr int PAIR_MAP_OFFSETS = 17;
 // the clique workspace reserves room for the parked forward state of multi-layer launches up to this size (the

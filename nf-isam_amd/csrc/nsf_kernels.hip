@@ -191,8 +191,19 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     float part[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane];     // ring row w + 4k
-    // the group-barrier counters of the chunk-persistent training kernel (one per dim): zero at the start of every chunk
-    if (threadIdx.x < FUSED_COUNTERS) ((unsigned*)(ring + (size_t)LOSS_RING * LOSS_SLOTS))[threadIdx.x] = 0u;
+    // the group-barrier counters of the chunk-persistent training kernel (one per dim; nsf_unit.hip: bits 0-22 arrivals,
+    // 23-30 the XCC ids the group's blocks ran on, 31 the group's abort flag): looked at, then zeroed for the next chunk
+    int stalled = 0, xcd_span = 0;
+    if (threadIdx.x < FUSED_COUNTERS) {                              // (= the block's first wave)
+        unsigned* ctr = (unsigned*)(ring + (size_t)LOSS_RING * LOSS_SLOTS) + threadIdx.x;
+        const unsigned cv = *ctr;
+        *ctr = 0u;
+        stalled = __any((int)(cv >> 31));
+        int span = __popc((cv >> 23) & 0xffu);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(span, off, 64); span = o > span ? o : span; }
+        xcd_span = span;
+    }
     const int s0 = st->step, stop0 = st->stop, have_avg = st->have_avg;
     const float loss_avg = st->loss_avg;
     int new_step = s0, new_stop = stop0, new_have = have_avg, new_err = st->domain_err;
@@ -232,7 +243,7 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
         __syncthreads();
         bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
         if (bad_at < cnt) {
-            new_err = 1; new_stop = 1; new_step = s0 + bad_at + 1;
+            new_err |= 1; new_stop = 1; new_step = s0 + bad_at + 1;
         } else {
             const int t_end = s0 + cnt;
             if (wnd > 0 && (t_end % wnd) == 0) {   // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
@@ -254,6 +265,11 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
         }
     }
     if (threadIdx.x == 0) {
+        if (stalled) {                                               // a group barrier of the chunk timed out: the run is over, loudly
+            new_err |= NFISAM_STATE_STALLED; new_stop = 1;
+            st->domain_err = new_err; st->stop = new_stop;
+        }
+        if (xcd_span > st->reserved[1]) st->reserved[1] = xcd_span;   // most XCDs a (clique, dim) group of a persistent chunk spanned
         if (active) {
             st->loss_avg = new_avg; st->have_avg = new_have; st->domain_err = new_err; st->stop = new_stop; st->step = new_step;
         }
@@ -261,6 +277,7 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
             nfisam_train_state* m = a.mirror + blockIdx.x;
             const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
             m->step = new_step; m->stop = new_stop; m->have_avg = new_have; m->loss_avg = new_avg; m->domain_err = new_err;
+            m->reserved[1] = st->reserved[1];
             __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -386,7 +403,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-extern "C" int nfisam_abi_version(void) { return 1320; }
+extern "C" int nfisam_abi_version(void) { return 1400; }
 extern "C" int nfisam_last_hip_error(void) { return nfisam_g_last_hip_error; }
 
 // (K, H) -> launchers of the kernel unit that instantiates the pair (nsf_units.h), nullptr if none does
@@ -549,7 +566,8 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
                                              : (use_slabs(n, TILE) ? (size_t)((n + TILE - 1) / TILE) : 1);
     // + the fused-Adam launches' second set of gradient copies (64-particle tiles) and second state buffer (theta | m | v)
     const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
-    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3) * kcount(D, K, H) : 0;
+    // + the chunk-persistent form's two sets of TAGGED copies (8 blocks of 4 waves at most, 2 floats per parameter)
+    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 32) * kcount(D, K, H) : 0;
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && H == 8 && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
     // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)
@@ -637,20 +655,25 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 
 // The chunk-persistent form of the dim-major kernel (nsf_unit.hip: nsf_train1_kernel<K, H, true>) needs every block of the
 // launch resident at once: blocks spin at their group's barrier, a member that waits for a CU held by spinning blocks
-// would never arrive.  One 4-wave block per (clique, dim, 256 particles; one barrier counter per dim: D <= 64); the persistent instantiation is compiled for two
-// waves per SIMD (213 VGPRs: the loop keeps more alive; at three it spills), so two blocks fit a CU: 512 places, of which
-// a launch may take 420 (the dispatcher is not asked to pack perfectly; H = 16: 256 VGPRs, ~61 KB of LDS per block, the same two
-// blocks per CU).  NFISAM_PERSIST=0: never.
+// would never arrive (the kernel gives up after 2^22 polls and the run ends with NFISAM_ERR_STALL -- loud, but a lost fit).
+// One 4-wave block per (clique, dim, 256 particles); one barrier counter per dim: D <= 64.  How many blocks the device holds
+// is ASKED, not assumed: hipOccupancyMaxActiveBlocksPerMultiprocessor for the launch's LDS size x the device's compute units
+// (MI355X: H <= 8 compiles to three waves per SIMD = three blocks per CU while the four wave tiles + panel stay within
+// 53 KB, i.e. D <= ~20, two beyond; H = 16: 256 VGPRs, two), of which a launch may take 7/8 -- the dispatcher is not asked to
+// pack perfectly, and a block of another kernel may sit on a CU for a while.  Other PROCESSES on the device are not seen by
+// this count; what protects against them is the barrier's timeout.  NFISAM_PERSIST=0: never.
+static std::atomic<bool> g_persist_broken{false};     // a persistent launch of this process stalled once: never again (nfisam_nsf_train_plan_run)
 static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L) {
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
-    if (!on || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
-    // two blocks per CU: 4 waves' tiles within 64 KB, the panel and the row of ones in the rest of the block's 80 KB
-    if ((size_t)4 * train1_wave_floats(max_D, H) * sizeof(float) > (size_t)64 * 1024) return false;
+    if (!on || g_persist_broken.load() || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
     long blocks = 0;
     for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
-    static const long limit = getenv("NFISAM_PERSIST_BLOCKS") != nullptr ? atol(getenv("NFISAM_PERSIST_BLOCKS")) : 420;   // (measurement aid)
+    const NsfUnitOps* ops = find_ops(K, H);
+    const long places = ops != nullptr ? ops->persist_places(max_D) : 0;
+    long limit = places - places / 8;
+    if (const char* e = getenv("NFISAM_PERSIST_BLOCKS")) limit = atol(e);    // (measurement aid)
     return blocks <= limit;
 }
 
@@ -955,20 +978,23 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
 }
 
 // Waits until the bookkeeping kernel of chunk number `k` (1-based, this run) has written every clique's mirror.  The
-// device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms, so the host yields between
-// looks and gives up after ~20 s (a wedged GPU must not hang the caller for ever).
-static int wait_chunk(const nfisam_train_plan* p, int k) {
+// device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms: the host spins for the first
+// ~50 us (the common case at the end of a short chunk), then sleeps 20 us between looks so that a worker thread or a rank
+// of a parallel run does not hold a core at 100 % for the whole fit; every ~65 k looks the WORK stream -- the one the
+// chunk was enqueued on, which for plans without a graph is the caller's -- is queried for a launch failure, and after
+// ~60 s without progress the wait gives up (-> `poisoned`: the caller must not synchronise a wedged stream either).
+static int wait_chunk(const nfisam_train_plan* p, int k, hipStream_t work, bool* poisoned) {
     const volatile nfisam_train_state* m = p->hst;
-    for (long spins = 0;; ++spins) {
+    const struct timespec nap = {0, 20000};
+    for (long looks = 0;; ++looks) {
         bool all = true;
         for (int c = 0; c < p->n_cliques; ++c)
             if (m[c].reserved[0] < k) { all = false; break; }
         if (all) break;
-        if (spins > 2000000000L) return NFISAM_ERR_LAUNCH;
-        if ((spins & 0xffff) == 0xffff) {
-            if (hipStreamQuery(p->exec ? p->cap : nullptr) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
-        }
-        __builtin_ia32_pause();
+        if (looks > 3000000L) { *poisoned = true; return NFISAM_ERR_LAUNCH; }
+        if ((looks & 0xffff) == 0xffff && hipStreamQuery(work) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
+        if (looks < 2000) __builtin_ia32_pause();
+        else nanosleep(&nap, nullptr);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return NFISAM_OK;
@@ -995,7 +1021,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     // the plain graph -- same results bit for bit.
     // (not next to a conveyor either: its launches take every place as soon as one is free, the persistent blocks would
     //  spin at their barriers for members that queue behind them)
-    const bool persist = p->exec_p != nullptr && g_hand_stepped.load() == 0 && !g_persist_busy.exchange(true);
+    const bool persist = p->exec_p != nullptr && !g_persist_broken.load() && g_hand_stepped.load() == 0 && !g_persist_busy.exchange(true);
     hipGraphExec_t const exec = persist ? p->exec_p : p->exec;
     struct Release {
         bool on; nfisam_train_plan* p; hipStream_t* w;
@@ -1005,7 +1031,8 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
             g_persist_busy.store(false);
         }
     } release{persist, p, &work};
-    auto fail = [&](int rc) { (void)hipStreamSynchronize(work); return rc; };
+    bool poisoned = false;            // the wait gave up on a wedged stream: return without draining it (the plan is unusable)
+    auto fail = [&](int rc) { if (!poisoned) (void)hipStreamSynchronize(work); else p->ahead = false; return rc; };
     // Nothing of an earlier run writes the mirror any more: its last closed chunk was waited for, and a chunk enqueued
     // ahead of an early stop only republishes the final state, so restarting the sequence needs that chunk drained.
     if (p->ahead) { HIP_TRY(hipStreamSynchronize(work)); p->ahead = false; }
@@ -1045,12 +1072,19 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
             int rc = launch_chunk();
             if (rc) return fail(rc);
         }
-        int rc = wait_chunk(p, closed + 1);
+        int rc = wait_chunk(p, closed + 1, work, &poisoned);
         if (rc) return fail(rc);
         ++closed;
         bool all_stopped = true;
         for (int c = 0; c < p->n_cliques; ++c) {
-            if (p->hst[c].domain_err) status = NFISAM_ERR_DOMAIN;
+            if ((p->hst[c].domain_err & NFISAM_STATE_STALLED) != 0) {          // a group barrier of a persistent chunk timed out
+                status = NFISAM_ERR_STALL;
+                if (!g_persist_broken.exchange(true))
+                    fprintf(stderr, "nfisam: a chunk-persistent training launch stalled (a block of it never became resident); "
+                                    "this process keeps to one launch per iteration from now on\n");
+            } else if (p->hst[c].domain_err != 0 && status != NFISAM_ERR_STALL) {
+                status = NFISAM_ERR_DOMAIN;
+            }
             if (!p->hst[c].stop && p->hst[c].step < p->cfg.max_iters) all_stopped = false;
         }
         if (all_stopped) break;        // (a clique with a domain error has stop set: the others run to their own end)
@@ -1072,6 +1106,18 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     }
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;
+}
+
+// Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on, as of the last closed chunk (0: no
+// persistent chunk has run; 1: the placement the grid asks for).  Diagnostic: the exchange inside a group is agent-scope
+// coherent, so a larger value costs time (L2 misses), not correctness -- tests use it to prove that a scattered launch
+// really straddled XCDs.
+extern "C" int nfisam_nsf_train_plan_xcd_span(const nfisam_train_plan* p) {
+    if (p == nullptr || p->hst == nullptr) return -1;
+    int span = 0;
+    const volatile nfisam_train_state* m = p->hst;
+    for (int c = 0; c < p->n_cliques; ++c) span = m[c].reserved[1] > span ? m[c].reserved[1] : span;
+    return span;
 }
 
 // ---- stepping a plan by hand (slam.ReplicaNFiSAM's slot scheduler) ---------------------------------------------------------

@@ -680,8 +680,15 @@ constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);  
 // the copies back from the XCD's L2 (device-scope loads: the CU's vector cache may hold the lines of two iterations ago).
 // The particle tile stays in LDS; no kernel boundary, no cold prologue.  Same arithmetic in the same order: bit-identical.
 #ifndef NSF_PERSIST_WAVES
-#define NSF_PERSIST_WAVES 2      // resident waves per SIMD the chunk-persistent instantiation is compiled for (3: it spills)
+#define NSF_PERSIST_WAVES 3      // resident waves per SIMD the chunk-persistent instantiation is compiled for (round 3: 2 -- it spilled at 3)
 #endif
+// chunk-persistent form: floats of each of the three arrays (theta | m | v of the block's dim) kept in LDS behind the waves' tiles
+template <int K, int H>
+__host__ __device__ constexpr int persist_keep_stride(int max_D) {
+    using LY = Layout<K, H>;
+    const int b = max_D > 1 ? LY::block(max_D - 1) : 0;
+    return ((b > LY::PoP ? b : LY::PoP) + 3) & ~3;
+}
 template <int K, int H, bool PERSIST = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
@@ -696,20 +703,97 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int bx = blockIdx.y;                                // tile group inside the (clique, dim)
+    // Grid dim3(8, blocks per group, octets): workgroups are dealt round-robin over the 8 XCDs in linear order, so the
+    // blocks of a (clique, dim) group (8 apart) share one XCD's L2.  A SPEED matter only, also for the chunk-persistent form
+    // (its exchange goes through agent-scope write-through stores and loads, see below); h_shifts bit 7 (debug knob
+    // NFISAM_PERSIST_SCATTER=1, PERSIST only) transposes the two grid axes so that a group's blocks are 1 apart, i.e. on
+    // DIFFERENT XCDs: tests/test_hip_parity.py holds that launch to the same bits.
+    const bool scatter = PERSIST && (h_shifts & 0x80) != 0;
+    const int bx = scatter ? blockIdx.x : blockIdx.y;         // tile group inside the (clique, dim)
     // (chains: an iteration may be split into n launches on parallel graph branches, see nfisam_nsf_train_plan_create;
     //  launch c takes the octets of groups c, c + n, ...)
-    const int grp = blockIdx.x + 8 * (blockIdx.z * ((h_shifts >> 24) & 0xff) + ((h_shifts >> 16) & 0xff));
+    const int grp = (scatter ? blockIdx.y : blockIdx.x) + 8 * (blockIdx.z * ((h_shifts >> 24) & 0xff) + ((h_shifts >> 16) & 0xff));
     if (grp >= h_groups) return;                              // padding of the group count to a multiple of 8
     const int gq = h_magic != 0u ? (int)__umulhi((unsigned)grp, h_magic) : grp;    // grp / cliques
-    const int by = grp - gq * h_grid_cliques;                 // clique
+    // clique: rotated by the dim's row, so that the dims of ONE clique spread over the XCDs also when the number of cliques is
+    // a multiple of 8 (XCD = grp mod 8 would otherwise be the clique itself: the eight C3 cliques, D = 6 .. 12, put 48 .. 96
+    // blocks on an XCD -- the widest clique filled its XCD's 96 places while the narrowest left half of its own idle)
+    // (PERSIST only: the one-launch-per-iteration form re-reads the particle tile every launch, and a clique whose dims share
+    //  an XCD fetches it into ONE L2; its C3 time did not change with the rotation -- 14.5 us either way)
+    int by = grp - gq * h_grid_cliques;
+    if constexpr (PERSIST) {
+        by += gq;
+        by -= (h_magic != 0u ? (int)__umulhi((unsigned)by, h_magic) : by) * h_grid_cliques;
+    }
     const int i = h_xrows - 1 - gq;                           // this block's dim: the long ones first
     typedef const __attribute__((address_space(4))) nfisam_clique cclique;
     typedef const __attribute__((address_space(4))) char cchar;
-    cclique* cp = (h_cliques != nullptr)
+    cclique* cp0 = (h_cliques != nullptr)
                       ? (cclique*)(h_cliques + by)
                       : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + TRAIN1_FEW_OFFSET) + by;
     (void)few;
+    typedef __attribute__((address_space(1))) nfisam_train_state gstate;
+    if (i >= cp0->D) return;
+    const int lane0 = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ws = (h_shifts >> 8) & 0xff, ts = h_shifts & 0x3f;
+    const int W = 1 << ws, T = 1 << ts;
+#if defined(NSF_STAMPS)
+    const int lane = lane0;                                   // (the stamp macros name `lane`; the loop below declares its own)
+#endif
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+    STAMP(10);
+#endif
+    int st_stop = 0, st_step = 0;
+    {
+        gstate* st0 = (gstate*)cp0->state;
+        if (st0 != nullptr) {
+            st_stop = __hip_atomic_load(&st0->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st_step = __hip_atomic_load(&st0->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (PERSIST) {                                  // (uniform values that arrive in VGPRs: scalar registers around the loop)
+        st_stop = __builtin_amdgcn_readfirstlane(st_stop);
+        st_step = __builtin_amdgcn_readfirstlane(st_step);
+    }
+    {
+        // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
+        // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
+        // Every wave writes the same 68 words; its own LDS operations are in order, so it reads what it wrote.
+        float* ones0 = smem + PANEL_BASE + CP::floats(h_xrows);
+        ones0[lane0] = 1.0f;
+        if (lane0 < ONES_ROW - 64) ones0[64 + lane0] = 1.0f;
+    }
+    if (PERSIST && bx >= (((((int)cp0->n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws)) return;   // a block without a tile
+    if (PERSIST && threadIdx.x == 0) smem[1] = 0.0f;          // the block's abort word (words 1-3 in front of the panel are free)
+    // (test knob NFISAM_PERSIST_DROP=1, h_shifts bit 6: block 1 of group 0 leaves at once -- a member that "never became
+    //  resident"; its group must time out, raise the abort flag and end the run with NFISAM_ERR_STALL)
+    if (PERSIST && (h_shifts & 0x40) != 0 && grp == 0 && bx == 1) return;
+
+    STAMP_DECL
+#if !(defined(NSF_STAMPS) && NSF_STAMPS == 2)
+    STAMP(0);
+#endif
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+    if (lane0 < 16) smem[PANEL_BASE - 64 + w * 16 + lane0] = 0.0f;
+#endif
+    f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cb2[NT], cb1 = {0.f, 0.f, 0.f, 0.f};                 // WIDE_H only
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float r0 = 0.0f, lossv = 0.0f;
+    int it = PERSIST ? 0 : a.iter_idx;                        // iteration inside the chunk
+
+  for (;;) {                                                  // (PERSIST: the iterations of the chunk; else one pass)
+    // Everything the body needs is (re)derived INSIDE the loop from two laundered roots -- the thread index and the address
+    // of the clique's descriptor: values defined in front of a loop and used in its body stay alive around the back
+    // edge, ~35 VGPRs and ~150 SGPRs more than the one-pass kernel needs, which is what kept the chunk-persistent form
+    // from three waves per SIMD (round 3: 37 VGPRs spilled to scratch, reloads in the middle of the dependent chain).
+    // The descriptor comes back with one s_load_dwordx16 per iteration (scalar cache), under the staging's own loads.
+    int tl_ = threadIdx.x;
+    cclique* cp = cp0;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tl_), "+s"(cp));
+    const int lane = tl_ & 63;
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
     // atomics, which count against both memory counters)
     const gfloat* x = (const gfloat*)cp->x;
@@ -717,26 +801,13 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     gfloat* G = (gfloat*)cp->kgrad;
     const gfloat* own_m = (const gfloat*)cp->adam_m;
     const gfloat* own_v = (const gfloat*)cp->adam_v;
-    typedef __attribute__((address_space(1))) nfisam_train_state gstate;
     gstate* st = (gstate*)cp->state;
     const int n = cp->n;
     const int D = cp->D;
-    if (i >= D) return;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ws = (h_shifts >> 8) & 0xff, ts = h_shifts & 0xff;
-    const int W = 1 << ws, T = 1 << ts;
     const int slot = (bx << ws) + w;                          // this wave's tile group
     const int p0 = slot << (6 + ts);
-#if defined(NSF_STAMPS) && NSF_STAMPS == 2
-    STAMP(10);
-#endif
-    int st_stop = 0, st_step = 0;
-    if (st != nullptr) {
-        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const float B = a.B;
+    float B = a.B;
+    if constexpr (PERSIST) asm volatile("" : "+s"(B));         // (the spline's per-bin constants are functions of B: not to be hoisted into VGPRs)
     const bool slab = a.slab != 0;
     const size_t gstride = (size_t)LY::count(D);
     gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
@@ -745,47 +816,33 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     gfloat* const G0 = G;
     gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
     gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
-    int it = PERSIST ? 0 : a.iter_idx;                        // iteration inside the chunk
-    int par = (a.fused_adam != 0) ? (it & 1) : 0;
-    bool pending = a.fused_adam != 0 && it > 0;
+    // chunk-persistent form: two sets of TAGGED copies behind the second state buffer, 2 floats (value, tag) per parameter
+    gfloat* const tg0 = alt + 3 * gstride;
+    const size_t tg_set = (size_t)a.n_copies * 2 * gstride;
+    const int par = (a.fused_adam != 0) ? (it & 1) : 0;
+    const bool pending = a.fused_adam != 0 && it > 0;
     const gfloat* Gprev = par ? G0 : Gset1;                   // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
     const int xrows = h_xrows;                                // rows of a particle tile in LDS (largest D of the launch)
     const float* pan = smem + PANEL_BASE;                     // the block's conditioner panel (nsf_cond_mfma.h)
-    // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
-    // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
-    // Every wave writes the same 68 words; its own LDS operations are in order, so it reads what it wrote.
-    float* ones = smem + PANEL_BASE + CP::floats(xrows);
+    float* ones = smem + PANEL_BASE + CP::floats(xrows);      // (the row of ones, written above)
     float* tiles0 = ones + ONES_ROW;
     const int wave_floats = train1_wave_floats(xrows, H);
     // fixed-size rows first: their offsets from the wave's base are immediates of the LDS instructions (fewer address registers)
     float* stg = tiles0 + (size_t)w * wave_floats;            // [16][XS] staging rows
     float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
-    const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
     float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
     float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
-    const int r16 = lane & 15, kq = lane >> 4;
-    ones[lane] = 1.0f;
-    if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
     const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
-    if (PERSIST && bx >= members) return;
     const bool has_tile = p0 < n;
-
-    STAMP_DECL
-    STAMP(0);
+    const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
+    const int r16 = lane & 15, kq = lane >> 4;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
-    if (lane < 16) smem[PANEL_BASE - 64 + w * 16 + lane] = 0.0f;
-    { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
+    if (it == (PERSIST ? 0 : a.iter_idx)) { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
 #endif
-    f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cb2[NT], cb1 = {0.f, 0.f, 0.f, 0.f};                 // WIDE_H only
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float r0 = 0.0f, lossv = 0.0f;
-
     // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
     // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
     // arithmetic, no column the dim does not need.  Rows beyond n re-read row n-1 (masked out of loss and gradient).
@@ -824,7 +881,6 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             store(c0, xr);
         }
     };
-  for (;;) {                                                  // (PERSIST: the iterations of the chunk; else one pass)
     {
         // the one workgroup barrier in front of the tile loop: the block's waves share the (clique, dim) and so the panel
         float xr[16];
@@ -845,8 +901,46 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
             fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
             fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
-            if (!stage_cond_panel<K, H, PERSIST>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it)) return;
-            __syncthreads();
+            if constexpr (PERSIST) {
+                // flag-in-data exchange (nsf_cond_mfma.h: stage_cond_panel_persist): the previous iteration's copies arrive as
+                // (value, tag) pairs, theta | m | v of the dim stay in this block's LDS between the iterations
+                PersistAdam pa_;
+                pa_.tagged = pending ? tg0 + (size_t)(par ^ 1) * tg_set : nullptr;
+                pa_.cstride = 2 * gstride;
+                pa_.copies = members;
+                pa_.tag = (uint32_t)(st_step + it);            // = the writer's st_step + (it - 1) + 1
+                pa_.m_src = own_m; pa_.v_src = own_v;          // (first iteration of a chunk: the state is in the clique's own arrays)
+                pa_.t_dst = fa.t_dst; pa_.m_dst = fa.m_dst; pa_.v_dst = fa.v_dst;
+                pa_.keep = tiles0 + (size_t)W * wave_floats;
+                pa_.kstride = persist_keep_stride<K, H>(xrows);
+                pa_.ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;
+                pa_.spin_log2 = a.persist_spins;
+                if (it == 1 && threadIdx.x == 0) {             // (diagnostic: the XCCs a group's blocks run on, bits 23-30 of the dim's control word)
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+                    __hip_atomic_fetch_or(pa_.ctr, 1u << (23 + (xcc & 7u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                pa_.looks = 0u;
+                { float d0_ = lossv, d1_ = r0; PSTAMP(10, d0_, d1_); }       // (loop top -> here: descriptor, pointers)
+                const int rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it);
+                if (rc_ == 1) return;
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+                { float d0_ = smem[PANEL_BASE], d1_ = (float)rc_; PSTAMP(11, d0_, d1_); }   // the staging: loads, looks, Adam, LDS stores
+                if (lane == 0) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + 13], pa_.looks);
+#endif
+                // A thread that gave up (2^persist_spins looks at copies that never came: a member of the group is not on the
+                // machine, somebody else holds its place) has raised the group's abort flag; the block leaves as one, the
+                // other members see the flag at their next look and leave too, nsf_bookkeep_kernel turns it into the STALL status.
+                if (rc_ == 2) *(volatile int*)&smem[1] = 1;
+                __syncthreads();
+                if (*(volatile int*)&smem[1] != 0) return;
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+                { float d0_ = smem[PANEL_BASE], d1_ = smem[PANEL_BASE + 1]; PSTAMP(12, d0_, d1_); }   // the block's barrier behind the staging
+#endif
+            } else {
+                if (!stage_cond_panel<K, H, false>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it)) return;
+                __syncthreads();
+            }
         }
         if (!PERSIST && p0 >= n) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
@@ -860,8 +954,10 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     }
 
     if constexpr (PERSIST) {                                  // (zeroed HERE, not at the loop's end: nothing of them is live across the staging)
-        lossv = 0.0f; r0 = 0.0f;
-        c1 = f32x4{0.f, 0.f, 0.f, 0.f}; c0 = c1; cb1 = c1;
+        float z_ = 0.0f;
+        asm volatile("" : "+v"(z_));                          // (a zero made in the loop: the compiler keeps hoisted zero vectors in registers otherwise)
+        lossv = z_; r0 = z_;
+        c1 = f32x4{z_, z_, z_, z_}; c0 = c1; cb1 = c1;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
     }
@@ -871,6 +967,13 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         PSTAMP(1, lossv, r0);
         if (tt > 0) load_tile(pt, 0);
         wave_lds_sync();
+        // (PERSIST: a fresh derivation per phase -- a value derived once at the loop's top would have to stay in a register,
+        //  or in scratch, from there to its last use in the epilogue)
+        int tl2_ = threadIdx.x;
+        if constexpr (PERSIST) asm volatile("" : "+v"(tl2_));
+        const int lane = tl2_ & 63;
+        const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);
+        const int r16 = lane & 15, kq = lane >> 4;
         PSTAMP(2, lossv, r0);
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
@@ -1020,6 +1123,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     }
 
     // ---- the gradient of this dim's parameter block ----
+    int tl3_ = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tl3_));
+    const int lane_e = tl3_ & 63, r16_e = lane_e & 15, kq_e = lane_e >> 4;
     if (slab) {
         // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
         // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
@@ -1028,37 +1134,37 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         if (!has_tile) {
             // (PERSIST: a wave without particles stays for the staging of the following iterations)
         } else if (i == 0) {
-            if (lane < PoP) frag[lane] = r0;
+            if (lane_e < PoP) frag[lane_e] = r0;
         } else {
             float* fw = frag + LY::oW2(i);
-            if (r16 <= H) {
+            if (r16_e <= H) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[r16 * PoP + 16 * t + 4 * kq] = cacc[t];
+                    if (16 * t + 4 * kq_e + 3 < PoP) *(f32x4*)&fw[r16_e * PoP + 16 * t + 4 * kq_e] = cacc[t];
             }
-            if (kq < QH && r16 <= H) *(f32x4*)&(frag + LY::oW1(i))[r16 * H + 4 * kq] = c1;
+            if (kq_e < QH && r16_e <= H) *(f32x4*)&(frag + LY::oW1(i))[r16_e * H + 4 * kq_e] = c1;
             if constexpr (WIDE_H) {                           // the bias rows (every column of a bias chain holds the same sums) + dW0t | db0
-                if (r16 == 0) {
+                if (r16_e == 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[H * PoP + 16 * t + 4 * kq] = cb2[t];
-                    *(f32x4*)&(frag + LY::oW1(i))[H * H + 4 * kq] = cb1;
+                        if (16 * t + 4 * kq_e + 3 < PoP) *(f32x4*)&fw[H * PoP + 16 * t + 4 * kq_e] = cb2[t];
+                    *(f32x4*)&(frag + LY::oW1(i))[H * H + 4 * kq_e] = cb1;
                 }
-                if (r16 <= i) *(f32x4*)&frag[r16 * H + 4 * kq] = c0;
+                if (r16_e <= i) *(f32x4*)&frag[r16_e * H + 4 * kq_e] = c0;
             } else if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
-                const int k0 = (r16 == H) ? i : r16 - (H + 1);
-                if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) *(f32x4*)&frag[k0 * H + 4 * (kq - QH)] = c1;
-            } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
-                *(f32x4*)&frag[r16 * H + 4 * (kq - QH)] = c0;
+                const int k0 = (r16_e == H) ? i : r16_e - (H + 1);
+                if (kq_e >= QH && kq_e < 2 * QH && (r16_e == H || (r16_e > H && k0 < i))) *(f32x4*)&frag[k0 * H + 4 * (kq_e - QH)] = c1;
+            } else if (kq_e >= QH && kq_e < 2 * QH && r16_e <= i) {
+                *(f32x4*)&frag[r16_e * H + 4 * (kq_e - QH)] = c0;
             }
-            for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
+            for (int e = lane_e; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
         }
         // the block's loss: the waves' sums added in wave order by ONE thread (below), then one atomic per block into a ring
         // slot shared by at most two blocks of the clique while D x blocks <= 128 -- a sum of two floats does not depend on
         // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
         {
             const float wtot = wave_sum(lossv);
-            if (lane == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
+            if (lane_e == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
         }
         __syncthreads();                                      // waves without a tile left before the panel barrier
         const int waves_c = (n + (TILE << ts) - 1) >> (6 + ts);
@@ -1079,53 +1185,64 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 const f32x4 o = *(const f32x4*)&tiles0[(size_t)ww * wave_floats + 4 * e];
                 sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
             }
-            Gc[e] = sum;
+            // PERSIST, not the chunk's last iteration: the group's other blocks read this copy in the next iteration of the
+            // SAME launch -- every word goes out with its tag (the iteration's number in the run) as an 8-byte pair, by
+            // agent-scope (sc1) write-through stores that nobody waits for: the readers poll the tags themselves.
+            // The chunk's LAST copy is read by the next kernel (nsf_adam_kernel, close_chunk): the plain layout.
+            if (PERSIST && it + 1 < a.persist_iters) {
+                const float tagf = __uint_as_float((uint32_t)(st_step + it + 1));
+                gfloat* dst = tg0 + (size_t)par * tg_set + (size_t)bx * 2 * gstride + 2 * (size_t)(((i == 0) ? 0 : LY::off(i)) + 4 * e);
+                const f32x4 lo = {sum.x, tagf, sum.y, tagf}, hi = {sum.z, tagf, sum.w, tagf};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(dst), "v"(lo), "v"(hi) : "memory");
+            } else {
+                Gc[e] = sum;
+            }
         }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
         STAMP(12);
 #endif
     } else if (i == 0) {
-        if (lane < PoP) gsink(&G[lane], r0, false);
+        if (lane_e < PoP) gsink(&G[lane_e], r0, false);
     } else {
         gfloat* Gw = Gb + LY::oW2(i);
         {
             // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
             constexpr int TOT = (WIDE_H ? H : H + 1) * PoP;     // (H = 16: the bias row comes from its own chain, below)
             static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
-            if (r16 <= H) {
+            if (r16_e <= H) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + 4 * kq + 3 < PoP) {
-                        float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                    if (16 * t + 4 * kq_e + 3 < PoP) {
+                        float* d = &stg[r16_e * PoP + 16 * t + 4 * kq_e];
                         d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
                     }
             }
             wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < (TOT + 63) / 64; ++c) {
-                const int f = c * 64 + lane;
+                const int f = c * 64 + lane_e;
                 if (f < TOT) gsink(&Gw[f], stg[f], false);
             }
         }
-        if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
+        if (kq_e < QH && r16_e <= H) gsink4(&(Gb + LY::oW1(i))[r16_e * H + 4 * kq_e], c1, false);
         if constexpr (WIDE_H) {
-            if (r16 == 0) {
+            if (r16_e == 0) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[H * PoP + 16 * t + 4 * kq], cb2[t], false);
-                gsink4(&(Gb + LY::oW1(i))[H * H + 4 * kq], cb1, false);
+                    if (16 * t + 4 * kq_e + 3 < PoP) gsink4(&Gw[H * PoP + 16 * t + 4 * kq_e], cb2[t], false);
+                gsink4(&(Gb + LY::oW1(i))[H * H + 4 * kq_e], cb1, false);
             }
-            if (r16 <= i) gsink4(&Gb[r16 * H + 4 * kq], c0, false);
+            if (r16_e <= i) gsink4(&Gb[r16_e * H + 4 * kq_e], c0, false);
         } else if (merged) {
-            const int k0 = (r16 == H) ? i : r16 - (H + 1);
-            if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1, false);
-        } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
-            gsink4(&Gb[r16 * H + 4 * (kq - QH)], c0, false);
+            const int k0 = (r16_e == H) ? i : r16_e - (H + 1);
+            if (kq_e >= QH && kq_e < 2 * QH && (r16_e == H || (r16_e > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq_e - QH)], c1, false);
+        } else if (kq_e >= QH && kq_e < 2 * QH && r16_e <= i) {
+            gsink4(&Gb[r16_e * H + 4 * (kq_e - QH)], c0, false);
         }
     }
     PSTAMP(9, lossv, r0);
     const float tot = slab ? 0.0f : wave_sum(lossv);
-    if (lane == 0 && has_tile && !slab) {
+    if (lane_e == 0 && has_tile && !slab) {
         gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
                                                 ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
                                       : (gfloat*)a.loss_sum;
@@ -1134,33 +1251,11 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     if constexpr (!PERSIST) {
         break;
     } else {
-        if (++it >= a.persist_iters) break;
-        // ---- the group's blocks meet: this block's copy is in L2 (vmcnt: its stores are acknowledged), then everybody's is ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned* ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;       // zero at the start of every chunk (nsf_bookkeep_kernel)
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (unsigned)(it * members);
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) {                   // a member that never became resident: give up loudly (non-finite loss -> domain error)
-                    if (st != nullptr) ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS] = __builtin_nanf("");
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        par = it & 1;
-        pending = a.fused_adam != 0;
-        Gprev = par ? G0 : Gset1;
-        G = (par ? Gset1 : G0) + (slab ? (size_t)bx * gstride : (size_t)0);
-        Gb = G + LY::off(i > 0 ? i : 1);
+        if (++it >= a.persist_iters) break;                 // (no barrier: the next staging waits for the copies' tags)
     }
   }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
-    if (STAMP_SEL && lane < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane];
+    if (STAMP_SEL && lane0 < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane0] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane0];
 #endif
 }
 
@@ -2638,6 +2733,27 @@ static int unit_prepare(int max_D) {
 }
 
 template <int KK, int HH>
+static size_t train1_lds_bytes(int max_D, int W, bool persist = false) {
+    return ((size_t)PANEL_BASE + CondPanel<KK, HH>::floats(max_D) + ONES_ROW + (size_t)W * train1_wave_floats(max_D, HH) +
+            (persist ? (size_t)3 * persist_keep_stride<KK, HH>(max_D) : 0)) * sizeof(float);
+}
+// co-resident blocks of nsf_train1_kernel<K, H, true> on this device (what its registers and LDS allow per CU x CUs)
+template <int KK, int HH>
+static long unit_persist_places(int max_D) {
+    if constexpr (HH != 8 && HH != 4 && HH != 16) {
+        return 0;
+    } else {
+        const size_t lds = train1_lds_bytes<KK, HH>(max_D, 4, true);
+        if (set_lds(nsf_train1_kernel<KK, HH, true>, lds) != NFISAM_OK) return 0;
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsf_train1_kernel<KK, HH, true>, 256, lds) != hipSuccess) return 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return (long)per_cu * (long)prop.multiProcessorCount;
+    }
+}
+
+template <int KK, int HH>
 static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
     if constexpr (HH != 8 && HH != 4 && HH != 16) {
         return NFISAM_ERR_ARG;
@@ -2659,7 +2775,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         a.magic_cliques = n_cliques > 1 ? (unsigned)(((1ull << 32) + (unsigned)n_cliques - 1) / (unsigned)n_cliques) : 0u;
         int rc = PanelMap<KK, HH>::get(max_D, &a.panel_map);
         if (rc) return rc;
-        const size_t lds = ((size_t)PANEL_BASE + CondPanel<KK, HH>::floats(max_D) + ONES_ROW + (size_t)W * train1_wave_floats(max_D, HH)) * sizeof(float);
+        const size_t lds = train1_lds_bytes<KK, HH>(max_D, W, a.persist_iters > 0);
         size_t lds_launch = lds;
         if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
         const bool persist = a.persist_iters > 0;
@@ -2682,10 +2798,14 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int octets = (a.groups + 7) / 8;
         const int gz = (octets - ch + nch - 1) / nch;          // octets ch, ch + nch, ...
         if (nch > 255 || ch < 0 || ch >= nch) return NFISAM_ERR_ARG;
+        static const int spin_log2 = getenv("NFISAM_PERSIST_SPINS") != nullptr ? atoi(getenv("NFISAM_PERSIST_SPINS")) : 22;           // (test knob)
+        a.persist_spins = spin_log2 < 1 ? 1 : (spin_log2 > 30 ? 30 : spin_log2);
+        static const bool drop = getenv("NFISAM_PERSIST_DROP") != nullptr && getenv("NFISAM_PERSIST_DROP")[0] == '1';                  // (test knob)
+        static const bool scatter = getenv("NFISAM_PERSIST_SCATTER") != nullptr && getenv("NFISAM_PERSIST_SCATTER")[0] == '1';   // (test knob)
         if (gz > 0 && persist)
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
-                               a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
-                               a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                               dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
+                               a.t_shift | (scatter ? 0x80 : 0) | (drop ? 0x40 : 0) | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
         else if (gz > 0)
             hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
                                a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
@@ -2753,7 +2873,7 @@ static int unit_train(const TrainArgs& a_in, int n_cliques, int max_n, int max_D
 
 // ---- the unit's table -------------------------------------------------------------------------------------------
 #define NSF_OPS_ENTRY(k, h) \
-    {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>, unit_prepare<k, h>, pair_kernel_lds<k, h>, unit_pair_map<k, h>},
+    {k, h, unit_forward<k, h>, unit_inverse<k, h>, unit_walk<k, h>, unit_train<k, h>, unit_prepare<k, h>, pair_kernel_lds<k, h>, unit_pair_map<k, h>, unit_persist_places<k, h>},
 static const NsfUnitOps g_unit_ops[] = {NSF_FOR_EACH_KH(NSF_OPS_ENTRY)};
 
 #define NSF_UNIT_FN_(u) nsf_unit_ops_u##u

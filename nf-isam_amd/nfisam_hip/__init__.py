@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnfisam_hip.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
-OK, ERR_ARG, ERR_LAUNCH, ERR_DOMAIN, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+OK, ERR_ARG, ERR_LAUNCH, ERR_DOMAIN, ERR_NO_DEVICE, ERR_STALL = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
     "nfisam_abi_version", "nfisam_last_hip_error", "nfisam_nsf_supported", "nfisam_nsf_param_count",
@@ -25,7 +25,7 @@ EXPORTS = [
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
     "nfisam_nsf_train_plan_begin", "nfisam_nsf_train_plan_enqueue", "nfisam_nsf_train_plan_peek", "nfisam_nsf_train_plan_stream",
-    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
+    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
     "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
@@ -89,13 +89,28 @@ def lib():
     return _lib
 
 
+class DomainError(RuntimeError):
+    """NFISAM_ERR_DOMAIN: a kernel saw a non-finite loss (the reference raises / asserts at src/flows/utils.py:74-76,133)."""
+
+
+class PersistentStall(RuntimeError):
+    """NFISAM_ERR_STALL: a chunk-persistent training launch gave up waiting for one of its own blocks (somebody else held
+    its place on the device).  NOT a numerical failure: the fit is incomplete; re-run it from its initial state -- the
+    library keeps to one launch per iteration for the rest of the process."""
+
+
 def _check(rc, what):
     if rc == OK:
         return
     msg = {ERR_ARG: "invalid argument / unsupported (K,H)", ERR_LAUNCH: "HIP launch failure (hip error %d)" %
-           lib().nfisam_last_hip_error(), ERR_DOMAIN: "numerical domain error", ERR_NO_DEVICE: "no gfx950 device"}
+           lib().nfisam_last_hip_error(), ERR_DOMAIN: "numerical domain error", ERR_NO_DEVICE: "no gfx950 device",
+           ERR_STALL: "a chunk-persistent training launch stalled (a block never became resident)"}
     if rc == ERR_ARG:
         raise ValueError("%s: %s" % (what, msg[rc]))
+    if rc == ERR_DOMAIN:
+        raise DomainError("%s: %s" % (what, msg[rc]))
+    if rc == ERR_STALL:
+        raise PersistentStall("%s: %s" % (what, msg[rc]))
     raise RuntimeError("%s: %s" % (what, msg.get(rc, "error %d" % rc)))
 
 
@@ -428,6 +443,10 @@ class TrainBatch:
         self.last_iters = [int(v) for v in iters]          # valid also when a clique hit a domain error
         _check(rc, "nfisam_nsf_train_plan_run")
         return self.last_iters
+
+    def xcd_span(self):
+        """Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on (0: none ran; diagnostic)."""
+        return int(lib().nfisam_nsf_train_plan_xcd_span(self._plan)) if getattr(self, "_plan", None) is not None else 0
 
     # ---- stepping the plan by hand (nfisam_nsf_train_plan_begin / enqueue / peek / stream / end) ----------------------
     def begin(self):

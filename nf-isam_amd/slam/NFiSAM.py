@@ -429,13 +429,19 @@ class NFiSAM(FactorGraphSolver):
         tb.reset(kparams=[p["kp0"] for p in preps])
         logger = logging.getLogger("flows on clique")
         try:
-            iters = tb.run(use_graph=True)
-        except RuntimeError as err:
+            try:
+                iters = tb.run(use_graph=True)
+            except _nh.PersistentStall:
+                # Not a numerical event: a chunk-persistent launch gave up waiting for a block of its own (another process
+                # held its place on the device).  The SAME fit -- same batch, same initial parameters -- runs again; the
+                # library has switched this process to one launch per iteration, whose results are the same bit for bit.
+                logger.warning("a chunk-persistent training launch stalled: re-running the fit with one launch per iteration")
+                tb.reset(kparams=[p["kp0"] for p in preps])
+                iters = tb.run(use_graph=True)
+        except _nh.DomainError:
             # A non-finite loss (the reference raises "Input outside domain" / fails its discriminant assert there,
             # src/flows/utils.py:74-76,133, and the whole update dies).  The other cliques of the batch have run to their
             # own end; a failed clique is retried ONCE from a fresh initialisation, on its own.
-            if "domain" not in str(err):
-                raise
             iters = tb.last_iters
             failed = [c for c in range(len(preps)) if tb.state(c)["domain_err"]]
             if retry and failed:

@@ -30,4 +30,17 @@ def MMDu2(x: np.ndarray, y: np.ndarray, sigma: float = None) -> float:
                  2.0 * _rbf_gram(x, y, sigma).mean())
 
 
-mmd = MMDb
+def mmd(samples1: np.ndarray, samples2: np.ndarray, k_sigma2: float = 1.0) -> np.ndarray:
+    """The reference's `mmd` (src/utils/Statistics.py:13-45; what icra_paper/compute_mmd.py writes to `run1/mmd`):
+    sqrt(E1 + E2 - 2 E3) with the Gaussian kernel k(d) = N(d; 0, k_sigma2 I) / N(0; 0, k_sigma2 I) = exp(-|d|^2 / (2 k_sigma2)),
+    E1 / E2 without the diagonal (means over i != j), E3 over all pairs.  Returns a one-element array like the
+    reference (callers index `[0]`); NaN when the unbiased combination is negative, as there.  Vectorised."""
+    x, y = np.atleast_2d(samples1).astype(np.float64), np.atleast_2d(samples2).astype(np.float64)
+    m, n = x.shape[0], y.shape[0]
+    s = np.sqrt(k_sigma2)
+    kxx, kyy = _rbf_gram(x, x, s), _rbf_gram(y, y, s)
+    e1 = (kxx.sum() - np.trace(kxx)) / (m * (m - 1))
+    e2 = (kyy.sum() - np.trace(kyy)) / (n * (n - 1))
+    e3 = _rbf_gram(x, y, s).mean()
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(np.array([e1 + e2 - 2.0 * e3]))

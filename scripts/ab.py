@@ -1,6 +1,7 @@
 """Diagnostic (GPU): A/B of library builds on ONE device, interleaved rounds (devices differ by several per cent, so
 timings of different gpurun calls do not compare).
-    python scripts/ab.py [rounds] libA.so libB.so ...      (file names inside nf-isam_amd/nfisam_hip/)
+    python scripts/ab.py [rounds] variant ...      variant = lib.so[,ENV=value,...]  (file names inside nf-isam_amd/nfisam_hip/;
+                                                   e.g. libnfisam_hip.so,NFISAM_PERSIST=0)
 Each round runs every library once in its own process: C3, one Plaza clique, the 64-clique batch (bench.Workload)."""
 import json, os, subprocess, sys
 import numpy as np
@@ -33,7 +34,8 @@ libs = args
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        env = dict(os.environ, AB_LIB=l)
+        parts = l.split(",")
+        env = dict(os.environ, AB_LIB=parts[0], **dict(kv.split("=", 1) for kv in parts[1:]))
         o = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [x for x in o.stdout.split("\n") if x.startswith("AB_RESULT ")]
         if not line:
@@ -42,7 +44,7 @@ for r in range(rounds):
 for l in libs:
     if not res[l]:
         continue
-    s = "%-34s" % l
+    s = "%-60s" % l
     for name in res[l][0]:
         k = np.median([x[name][0] for x in res[l]]); st = np.median([x[name][1] for x in res[l]])
         s += "  %s kernel %7.2f step %7.2f |" % (name, k, st)

@@ -18,7 +18,20 @@ rng = np.random.RandomState(0)
 xs = [torch.from_numpy(rng.randn(n, D).astype(np.float32)).to(dev) for _ in range(nc)]
 kps = [nh.pack(torch.from_numpy(BM.init_blob_np(D, K, H, L, c)).to(dev), D, K, H, L) for c in range(nc)]
 lib = nh.lib()
-if len(sys.argv) > 4:
+per = 1
+if len(sys.argv) > 4 and sys.argv[4] == "persist":
+    # the chunk-persistent form (when the plan takes it): 2 chunks of 50 iterations through the graph; the sums are those of
+    # the LAST launch = 50 iterations ("prologue" = group barrier + staging of the next iteration)
+    if nc == 0:                                             # argv: 0 n D persist -> the C3 cliques, widest first
+        prob = BM.c3_problem(0)[::-1]
+        xs = [torch.from_numpy(x).to(dev) for x, _ in prob]
+        kps = [nh.pack(torch.from_numpy(b).to(dev), x.shape[1], K, H, L) for x, b in prob]
+        nc, D = len(xs), int(xs[0].shape[1])
+    tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
+    tb.run(use_graph=True)
+    print("XCDs per group:", tb.xcd_span(), "(0: the plan did not take the persistent form)")
+    per = 50 if tb.xcd_span() > 0 else 1
+elif len(sys.argv) > 4:
     tb = nh.TrainBatch(xs, kps, K, H, B, L, lr=0.01, max_iters=8, average_window=4, loss_delta_tol=0.0, early_stop=True)
     tb.run(use_graph=False)
 else:
@@ -32,13 +45,15 @@ torch.cuda.synchronize()
 buf = (C.c_ulonglong * (64 * 32))()
 assert lib.nfisam_debug_read_stamps(buf) == 0
 st = np.array(buf[:]).reshape(64, 32)[:, 16:32].astype(np.int64)
-names = ["", "prologue", "load tile", "cond fwd", "spline fwd", "spline bwd", "cond bwd", "h2 operand", "grad GEMMs", "epilogue"]
+names = ["", "prologue", "load tile", "cond fwd", "spline fwd", "spline bwd", "cond bwd", "h2 operand", "grad GEMMs", "epilogue",
+         "P:loop top", "P:staging", "P:barrier", "P:looks(count)"]
 rows = [w for w in range(min(64, 4 * D)) if st[w].sum() > 0 and w >= 4]
 print("%d x (n=%d, D=%d): cycles per phase, summed over the wave's tiles (mean over %d stamped waves of dims >= 1)" % (nc, n, D, len(rows)))
-m = st[rows].mean(0)
-for i in range(1, 10):
-    print("  %-12s %8.0f" % (names[i], m[i]))
-print("  %-12s %8.0f" % ("total", m[1:10].sum()))
+m = st[rows].mean(0) / per
+st = st // per
+for i in range(1, 14 if per > 1 else 10):
+    print("  %-14s %8.0f" % (names[i], m[i]))
+print("  %-14s %8.0f" % ("total", m[1:10].sum() + (m[10:13].sum() if per > 1 else 0)))
 for w in (4, 5, 4 * (D // 2), 4 * (D - 1)):
     if w < 64:
         print("  slot %2d (dim %2d wave %d): " % (w, w // 4, w % 4) + " ".join("%s=%d" % (names[i], st[w][i]) for i in range(1, 10)))

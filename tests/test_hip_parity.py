@@ -975,7 +975,8 @@ for name, shapes, iters, window, tol, H in (("plaza", [(2000, 15)], 230, 50, 0.0
                                             ("early_stop", [(2000, 7)], 600, 50, 0.05, 8), ("tiny", [(64, 3)], 120, 40, 0.0, 8),
                                             ("plaza_h16", [(2000, 15)], 130, 50, 0.0, 16), ("h4", [(900, 9)], 100, 50, 0.0, 4),
                                             ("three_wide", [(2000, 16)] * 3, 100, 50, 0.0, 8), ("d24", [(1000, 24), (600, 19)], 100, 50, 0.0, 8),
-                                            ("d33", [(700, 33)], 100, 50, 0.0, 8)):
+                                            ("d33", [(700, 33)], 100, 50, 0.0, 8),
+                                            ("c3", [(2000, D) for D in (6, 8, 8, 10, 10, 12, 12, 12)], 100, 50, 0.0, 8)):
     gen = torch.Generator().manual_seed(len(name))
     xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
     kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(dev), D, K, H, 1) for n, D in shapes]
@@ -985,35 +986,103 @@ for name, shapes, iters, window, tol, H in (("plaza", [(2000, 15)], 230, 50, 0.0
         out["%%s_%%d_params" %% (name, c)] = tb.kparams[c].cpu().numpy()
         out["%%s_%%d_loss" %% (name, c)] = tb.iter_loss[c].cpu().numpy()
         out["%%s_%%d_iters" %% (name, c)] = np.array(done[c])
+    out["span_%%s" %% name] = np.array(tb.xcd_span())
     tb.close()
 np.savez(sys.argv[1], **out)
 '''
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(400)
 def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tmp_path):
     """The chunk-persistent form of the dim-major kernel (a chunk's iterations in ONE launch per chain, the blocks of a
-    (clique, dim) group meeting at a barrier in L2; default for launches that are resident at once) against
+    (clique, dim) group meeting at a barrier per iteration; default for launches that are resident at once) against
     NFISAM_PERSIST=0 (one launch per iteration): the same parameters, loss records and early-stop iterations, bit for bit --
     a Plaza-shaped clique (230 iterations: full chunks of 50 through the persistent graph, the last 30 eagerly), two ragged
     cliques in one plan, a run that stops early, a clique of one tile, hidden_dim 16 and 4, three cliques of D = 16 (384 blocks in two
-    parallel persistent launches).  (The knob is read once per process.)"""
+    parallel persistent launches), D = 19 / 24 / 33, the eight C3 cliques (624 blocks: three per CU).
+    Third run, NFISAM_PERSIST_SCATTER=1 (round 4): the launch's grid is transposed so that the blocks of a group are
+    neighbours in dispatch order, i.e. on DIFFERENT XCDs (checked: every plan reports a span > 1 where a group has several
+    blocks; the normal launch reports exactly 1) -- still the same bits: the group's exchange goes through agent-scope
+    write-through stores and agent-scope loads, the one-XCD placement is for speed only.  (The knobs are read once per process.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(PERSIST_WORKER % dict(root=root))
     res = {}
-    for knob in ("1", "0"):
+    for knob, env in (("1", dict(NFISAM_PERSIST="1")), ("0", dict(NFISAM_PERSIST="0")),
+                      ("scatter", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_SCATTER="1"))):
         out = str(tmp_path / ("persist_%s.npz" % knob))
-        p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, NFISAM_PERSIST=knob), capture_output=True,
-                           text=True, timeout=200)
+        p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         res[knob] = dict(np.load(out))
-    assert res["1"].keys() == res["0"].keys()
+    assert res["1"].keys() == res["0"].keys() == res["scatter"].keys()
     for k in res["1"]:
+        if k.startswith("span_"):
+            continue
         np.testing.assert_array_equal(res["1"][k], res["0"][k], err_msg=k)
+        np.testing.assert_array_equal(res["scatter"][k], res["0"][k], err_msg="scattered: " + k)
+    spans = {k[5:]: (int(res["1"][k]), int(res["0"][k]), int(res["scatter"][k])) for k in res["1"] if k.startswith("span_")}
+    print("XCDs per (clique, dim) group: persistent / one launch per iteration / scattered", spans)
+    for name, (normal, plain, scattered) in spans.items():
+        assert plain == 0, (name, plain)                            # no persistent chunk ran
+        assert normal == 1, (name, normal)                          # the grid puts a group behind ONE L2
+        assert scattered > 1 or name == "tiny", (name, scattered)   # ("tiny": one block per group)
     assert int(res["1"]["early_stop_0_iters"]) < 600 and int(res["1"]["plaza_0_iters"]) == 230
     assert np.all(np.isfinite(res["1"]["plaza_0_loss"][:230])) and res["1"]["plaza_0_loss"][229] < res["1"]["plaza_0_loss"][0]
+
+
+STALL_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "nf-isam_amd")); sys.path.insert(0, %(root)r)
+import nfisam_hip as nh
+dev = torch.device("cuda", 0)
+K, H, B, R = 9, 8, 5.0, 3
+gen = torch.Generator().manual_seed(5)
+xs = [(1.3 * torch.randn(2000, 15, generator=gen)).clamp_(-4, 4).to(dev) for _ in range(R)]
+kp0 = [nh.pack((0.2 * torch.randn(nh.param_count(15, K, H), generator=gen)).to(dev), 15, K, H, 1) for _ in range(R)]
+tb = nh.TrainBatch(xs, [k.clone() for k in kp0], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
+outcome = "ran"
+try:
+    done = tb.run()
+    sys.stderr.write("no stall; XCDs per group of the persistent launches: %%d (0: the plan did not take that form)\\n" %% tb.xcd_span())
+except nh.PersistentStall:
+    outcome = "stalled"
+    tb.reset(kp0)                    # the same fit again: the library keeps to one launch per iteration now
+    done = tb.run()
+torch.cuda.synchronize()
+np.savez(sys.argv[1], outcome=np.array(outcome), iters=np.array(done), params=torch.stack([k for k in tb.kparams]).cpu().numpy(),
+         loss=torch.stack([l for l in tb.iter_loss]).cpu().numpy())
+tb.close()
+'''
+
+
+@pytest.mark.timeout(400)
+def test_oversubscribed_persistent_launch_stalls_loudly_and_the_rerun_is_exact(tmp_path):
+    """A chunk-persistent launch whose blocks do not all arrive must not hang and must not pass for a numerical failure.
+    Provoked with a test knob (oversubscribing the machine does not do it: blocks are dispatched in order, 1440 blocks on 768
+    places merely ran one behind the other -- measured): NFISAM_PERSIST_DROP=1 makes one block of one (clique, dim) group
+    leave at once, like a member whose place is held by a foreign process that never yields; NFISAM_PERSIST_SPINS=12 shortens
+    the wait from 2^22 looks (seconds) to 4096.  The starved group's blocks give up, raise the group's abort flag and leave,
+    the run ends with NFISAM_ERR_STALL (nfisam_hip.PersistentStall), the process switches to one launch per iteration, and
+    the same fit run again gives exactly what NFISAM_PERSIST=0 gives."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "stall_worker.py"
+    script.write_text(STALL_WORKER % dict(root=root))
+    res = {}
+    for name, env in (("forced", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_DROP="1", NFISAM_PERSIST_SPINS="12")), ("plain", dict(NFISAM_PERSIST="0"))):
+        out = str(tmp_path / (name + ".npz"))
+        p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = dict(np.load(out))
+        if name == "forced":
+            assert "stalled" in p.stderr, p.stderr[-500:]            # the library says so once
+    assert str(res["forced"]["outcome"]) == "stalled" and str(res["plain"]["outcome"]) == "ran"
+    assert list(res["forced"]["iters"]) == list(res["plain"]["iters"]) == [100] * 3
+    np.testing.assert_array_equal(res["forced"]["params"], res["plain"]["params"])
+    np.testing.assert_array_equal(res["forced"]["loss"], res["plain"]["loss"])
 
 
 @pytest.mark.timeout(120)

@@ -1,21 +1,33 @@
-"""End-to-end pipeline parity against runs of the REFERENCE ITSELF (BASELINE configs 0 / 3 / 4).
+"""End-to-end pipeline parity against runs of the REFERENCE ITSELF (BASELINE configs 0 / 3 / 4, + the ICRA case).
 
-Fixtures: tests/golden/pipeline_{small_range,plaza1,manhattan136}.npz, written by tests/golden/make_pipeline_fixture.py in
-the build container: the reference's `run_incrementally` (src/slam/FactorGraphSolver.py:760-933) over the first updates of
-each dataset with a reduced iteration budget, 5 seeds, storing (i) what it fed to `fit_clique_density_model`
-(FactorGraphSolver.py:479-495: variable ordering, true observations, a row subsample of the training batch) and (ii) the
-posterior samples + ordering of every step.
+Fixtures: tests/golden/pipeline_{small_range,plaza1,plaza1ada,manhattan136,icra}.npz, written by
+tests/golden/make_pipeline_fixture.py in the build container: the reference's `run_incrementally`
+(src/slam/FactorGraphSolver.py:760-933) over the first updates of each dataset WITH THE ARGUMENTS AND THE ITERATION BUDGET OF
+THE REFERENCE'S OWN RUN SCRIPTS (2000 iterations + window early stop; Manhattan: 500 fixed; ICRA: run1/parameters), 5-8
+seeds, storing (i) what it fed to `fit_clique_density_model` (FactorGraphSolver.py:479-495: variable ordering, true
+observations, a row subsample of the training batch, iterations run) and (ii) the posterior samples + ordering of every step.
+The reference imports TransportMaps at module level (absent here); the generator supplies a restatement of its
+`GaussianDistribution` (the one class the NF-iSAM path calls), so the fixtures pin the pipeline IN DISTRIBUTION ONLY --
+by construction, and unavoidably: the reference never seeds torch.
 
 Here this repository's solver runs the same updates with the SAME arguments (3 seeds) and is compared
   (i)  per trained clique: same variable ordering and true observations as the reference; MMD of the simulated training
        batch (device simulator: csrc/clique_sim.hip) against the reference's batches of that clique;
-  (ii) per step: same elimination ordering; MMDb (the reference's metric: RBF, sigma = sqrt(dim), xy columns,
-       src/utils/Statistics.py:68-84) of the posterior against the reference's seed band.
+  (ii) per step: same elimination ordering; then
+       * joint MMDb (the reference's estimator: RBF, sigma = sqrt(dim), xy columns, src/utils/Statistics.py:68-84) on columns
+         STANDARDISED by the reference's pooled spread, and ONLY while it has dynamic range (<= 20 columns).  In raw metres --
+         the reference's own usage -- an RBF of width sqrt(dim) m sees no two samples of a 100 m world as neighbours and the
+         statistic sits at its floor sqrt(2 / n) whatever the samples are (measured: small-range step 0, six columns: ours
+         0.0632, reference spread 0.0636, floor 0.0632); the same happens beyond ~20 standardised columns;
+       * BLOCK-WISE MMDb at every size: every (pose_k xy, landmark_j xy) block and every consecutive-pose block
+         (pose_k xy, pose_k+1 xy), 4 columns each, standardised by the reference's pooled spread of those columns; statistic =
+         the LARGEST block value (and the mean over blocks), which keeps the cross-variable structure the joint metric
+         was meant to see (a landmark mode that does not move with its pose shows up in that block);
+       * every variable's standardised xy marginal (mean over variables).
 Tolerance: statistic = median over the reference's seeds of MMD(ours, reference seed); bound =
 max(0.08, 1.5 x the reference's own spread), spread = the same statistic of the reference's own runs (each seed against the
-other four; the largest of the five) at that step / clique.
-The reference is badly under-trained at this budget on the multi-modal steps (its own spread reaches 0.3-0.7 there), so
-the bound is wide exactly where the reference does not agree with itself.
+other ones; the largest leave-one-out value) at that step / clique / block set.
+`compare_case` returns every row it evaluated; scripts/pipeline_report.py dumps them (profiles/r04_pipeline_parity_vs_reference.json).
 """
 import json
 import os
@@ -31,7 +43,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 DATA = os.path.join(HERE, "data")
 
-CASES = {"small_range": None, "plaza1": "Plaza1EFG", "manhattan136": "ManhattanPlaza136"}
+# case -> graph under tests/data (None: the graph text travels inside a fixture)
+CASES = {"small_range": None, "icra": None, "plaza1": "Plaza1EFG", "plaza1ada": "Plaza1ADA0.4EFG",
+         "manhattan136": "ManhattanPlaza136"}
+JOINT_MAX_COLUMNS = 20
 
 
 def _xy_block(names, dims, arr, keep_obs=True):
@@ -63,6 +78,29 @@ def _band(ours, refs):
     return float(np.median(to_ref)), float(max(loo))
 
 
+def _pose_key(v):
+    return int(v[1:]) if v[1:].isdigit() else v
+
+
+def _blocks(order):
+    """4-column blocks of a step: (pose, landmark) for every pair, (pose_k, pose_k+1) along the trajectory."""
+    poses = sorted([v for v in order if v.startswith("X")], key=_pose_key)
+    lms = sorted(v for v in order if not v.startswith("X"))
+    return [(p, l) for p in poses for l in lms] + list(zip(poses[:-1], poses[1:]))
+
+
+def _graph_path(tmp_path, case, fx):
+    if case == "small_range":
+        path = tmp_path / "factor_graph.fg"
+        path.write_text(str(np.load(os.path.join(GOLDEN, "small_range_case1.npz"))["factor_graph_fg"]))
+        return str(path)
+    if case == "icra":                              # the reference-held graph file of icra_paper/case1 (data)
+        path = tmp_path / "factor_graph"
+        path.write_text(str(fx["held_factor_graph"]))
+        return str(path)
+    return os.path.join(DATA, CASES[case], "factor_graph.fg")
+
+
 def _run(tmp_path, case, fx, seed):
     from slam.FactorGraphSolver import run_incrementally
     from slam.NFiSAM import NFiSAM, NFiSAMArgs
@@ -70,12 +108,7 @@ def _run(tmp_path, case, fx, seed):
     kwargs = json.loads(str(fx["arguments"]))
     kwargs["cuda_training"] = True
     n_steps = int(fx["seed0_n_steps"])
-    if CASES[case] is None:
-        path = tmp_path / "factor_graph.fg"
-        path.write_text(str(np.load(os.path.join(GOLDEN, "small_range_case1.npz"))["factor_graph_fg"]))
-        path = str(path)
-    else:
-        path = os.path.join(DATA, CASES[case], "factor_graph.fg")
+    path = _graph_path(tmp_path, case, fx)
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
     steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))[:n_steps]
@@ -86,7 +119,8 @@ def _run(tmp_path, case, fx, seed):
     def fit(self, clique, samples, var_ordering, timer, *a, **k):
         s = samples.detach().cpu().numpy() if torch.is_tensor(samples) else np.asarray(samples)
         fits.append(dict(update=update_no[0] - 1, vars=[str(v.name) for v in var_ordering], dims=[int(v.dim) for v in var_ordering],
-                         true_obs=np.asarray(self._clique_true_obs[clique], dtype=np.float64), batch=s.astype(np.float64)))
+                         true_obs=np.asarray(self._clique_true_obs[clique], dtype=np.float64), batch=s.astype(np.float64),
+                         name="".join(str(v.name) for v in clique.vars)))
         return orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
 
     def update(self, *a, **k):
@@ -97,19 +131,31 @@ def _run(tmp_path, case, fx, seed):
         run_dir = run_incrementally(str(tmp_path), solver, steps, truth)
     finally:
         NFiSAM.fit_clique_density_model, NFiSAM.update_physical_and_working_graphs = orig_fit, orig_update
+    # iterations run = non-zero entries of the zero-padded loss record (NFiSAM.py:496-497), written per update by run_incrementally
+    curves = [json.load(open(os.path.join(run_dir, "step%d_step_training_loss" % i))) for i in range(n_steps)]
+    for f in fits:
+        f["iterations"] = int(np.count_nonzero(np.asarray(curves[f["update"]].get(f["name"], []), dtype=np.float64)))
     return run_dir, fits, n_steps
 
 
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize("case", list(CASES))
-def test_pipeline_matches_reference_runs(tmp_path, case):
+def compare_case(tmp_path, case, seeds=(0, 1, 2)):
+    """-> (rows, failures, timing): every comparison as a dict(kind, seed, index, ours, spread, bound, ...)."""
     fx = np.load(os.path.join(GOLDEN, "pipeline_%s.npz" % case))
     ref_seeds = [int(s) for s in fx["seeds"]]
-    report = []
-    for seed in range(3):
+    rows, failures, timing = [], [], []
+
+    def check(kind, seed, idx, m, spread, **extra):
+        bound = max(0.08, 1.5 * spread)
+        row = dict(kind=kind, seed=seed, index=idx, ours=round(m, 4), spread=round(spread, 4), bound=round(bound, 4), **extra)
+        rows.append(row)
+        if not m <= bound:
+            failures.append(row)
+
+    for seed in seeds:
         sub = tmp_path / ("seed%d" % seed)
         sub.mkdir()
         run_dir, fits, n_steps = _run(sub, case, fx, seed)
+        timing.append([float(t) for t in open(os.path.join(run_dir, "step_timing")).read().split()])
         # ---- (i) what goes into fit_clique_density_model -----------------------------------------------------------
         n_fits = int(fx["seed0_n_fits"])
         assert len(fits) == n_fits, (len(fits), n_fits)
@@ -123,11 +169,11 @@ def test_pipeline_matches_reference_runs(tmp_path, case):
             assert f["batch"].shape[1] == sum(meta["dims"]) == sum(dims)
             refs = [_xy_block(meta["vars"], meta["dims"], fx["seed%d_fit%d_batch" % (s, j)]) for s in ref_seeds]
             scale = np.maximum(np.vstack(refs).std(0), 1e-3)
-            rows = np.random.RandomState(j).permutation(f["batch"].shape[0])[:refs[0].shape[0]]
-            ours = _xy_block(meta["vars"], dims, f["batch"][rows])
+            rr = np.random.RandomState(j).permutation(f["batch"].shape[0])[:refs[0].shape[0]]
+            ours = _xy_block(meta["vars"], dims, f["batch"][rr])
             m, spread = _band(ours / scale, [r / scale for r in refs])
-            report.append(("fit", seed, j, round(m, 3), round(spread, 3)))
-            assert m <= max(0.08, 1.5 * spread), (case, seed, "fit", j, meta["vars"], m, spread)
+            ref_it = [json.loads(str(fx["seed%d_fit%d_meta" % (s, j)])).get("iterations", -1) for s in ref_seeds]
+            check("fit", seed, j, m, spread, vars=meta["vars"], iterations=f["iterations"], reference_iterations=ref_it)
         # ---- (ii) per-step posteriors ------------------------------------------------------------------------------
         for i in range(n_steps):
             order = open(os.path.join(run_dir, "step%d_ordering" % i)).read().split()
@@ -135,23 +181,109 @@ def test_pipeline_matches_reference_runs(tmp_path, case):
             S = np.loadtxt(os.path.join(run_dir, "step%d" % i))
             dims = [3 if v.startswith("X") else 2 for v in order]
             assert S.shape[1] == sum(dims) and np.all(np.isfinite(S))
-            refs = [_xy_block(order, dims, fx["seed%d_step%d_samples" % (s, i)]) for s in ref_seeds]
-            rows = np.random.RandomState(100 + i).permutation(S.shape[0])[:refs[0].shape[0]]
-            m, spread = _band(_xy_block(order, dims, S[rows]), refs)
-            report.append(("step", seed, i, round(m, 3), round(spread, 3)))
-            assert m <= max(0.08, 1.5 * spread), (case, seed, "step", i, m, spread)
-            # The joint metric saturates at sqrt(2 / n) once the step has tens of variables (an RBF of width sqrt(dim) metres
-            # sees no two samples as neighbours), so every variable's xy marginal is also compared on its own, standardised
-            # by the reference's pooled spread of that variable: mean over the variables of the same two statistics.
-            ours_v, ref_v = [], []
-            off = 0
+            ref_raw = [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds]
+            rr = np.random.RandomState(100 + i).permutation(S.shape[0])[:ref_raw[0].shape[0]]
+            Sr = S[rr]
+            floor = round(float(np.sqrt(2.0 / Sr.shape[0])), 4)
+            if 2 * len(order) <= JOINT_MAX_COLUMNS:
+                refs_xy = [_xy_block(order, dims, r) for r in ref_raw]
+                sc = np.maximum(np.vstack(refs_xy).std(0), 1e-3)
+                m, spread = _band(_xy_block(order, dims, Sr) / sc, [r / sc for r in refs_xy])
+                check("step-joint", seed, i, m, spread, columns=2 * len(order), floor=floor)
+            # xy columns of every variable: ours, the reference's seeds, the pooled reference scale
+            off, col = 0, {}
             for v, d in zip(order, dims):
-                rv = [fx["seed%d_step%d_samples" % (s2, i)][:, off:off + 2].astype(np.float64) for s2 in ref_seeds]
-                sc = np.maximum(np.vstack(rv).std(0), 1e-3)
-                mv, sv = _band(S[rows][:, off:off + 2] / sc, [x / sc for x in rv])
-                ours_v.append(mv); ref_v.append(sv)
+                col[v] = (off, off + 2)
                 off += d
-            mv, sv = float(np.mean(ours_v)), float(np.mean(ref_v))
-            report.append(("step-marginals", seed, i, round(mv, 3), round(sv, 3)))
-            assert mv <= max(0.08, 1.5 * sv), (case, seed, "step marginals", i, mv, sv)
-    print(case, report)
+            pooled = np.vstack(ref_raw)
+            per_block = []
+            for a, b in _blocks(order):
+                idx = list(range(*col[a])) + list(range(*col[b]))
+                sc = np.maximum(pooled[:, idx].std(0), 1e-3)
+                mb, sb = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
+                per_block.append((mb, sb, a + "-" + b))
+            if per_block:
+                worst = max(per_block, key=lambda t: t[0])
+                check("step-blocks-max", seed, i, worst[0], max(t[1] for t in per_block), blocks=len(per_block), worst_block=worst[2], floor=floor)
+                check("step-blocks-mean", seed, i, float(np.mean([t[0] for t in per_block])), float(np.mean([t[1] for t in per_block])),
+                      blocks=len(per_block), floor=floor)
+            ours_v, ref_v = [], []
+            for v in order:
+                idx = list(range(*col[v]))
+                sc = np.maximum(pooled[:, idx].std(0), 1e-3)
+                mv, sv = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
+                ours_v.append(mv); ref_v.append(sv)
+            check("step-marginals", seed, i, float(np.mean(ours_v)), float(np.mean(ref_v)), variables=len(order), floor=floor)
+    return rows, failures, timing
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("case", list(CASES))
+def test_pipeline_matches_reference_runs(tmp_path, case):
+    rows, failures, _ = compare_case(tmp_path, case)
+    print(case, [(r["kind"], r["seed"], r["index"], r["ours"], r["spread"]) for r in rows])
+    # MMDb of two n-sample sets that share no neighbour under the kernel is exactly sqrt(2 / n): no statistic may sit there
+    sat = [r for r in rows if r["kind"] != "fit" and abs(r["ours"] - r["floor"]) < 0.01 * r["floor"] and abs(r["spread"] - r["floor"]) < 0.01 * r["floor"]]
+    assert not sat, ("a statistic sits at its saturation floor sqrt(2 / n)", sat)
+    assert not failures, failures
+
+
+# ---- the ICRA case against the results the REFERENCE HOLDS for it ---------------------------------------------------------
+def _xy_reorder(order, arr, ref_order):
+    """icra_paper/compute_mmd.py:72-95 (`reorder_samples`): the xy columns of every variable, in `ref_order`."""
+    off, col = 0, {}
+    for v in order:
+        col[v] = arr[:, off:off + 2]
+        off += 3 if v.startswith("X") else 2
+    return np.hstack([col[v] for v in ref_order]).astype(np.float64)
+
+
+@pytest.mark.timeout(900)
+def test_icra_case_against_the_reference_held_results(tmp_path):
+    """example/slam/small_range_gaussian_problem/icra_paper/case1 with the reference-held run1/parameters (K = 5, n = 600,
+    80 iterations, lr .02, 500 posterior samples): per step, with the reference's own statistic (`mmd`,
+    src/utils/Statistics.py:13-45, 500 x 500 samples, xy columns in the reference solution's ordering, compute_mmd.py:97-150)
+      * steps 0-2 against the reference-held nested-sampling solution (reference/step_0..2; steps 3-5 hold no samples):
+        bar = 1.5 x the value the reference published for its own NF-iSAM run at that step (run1/mmd: 0.0149 / 0.125 /
+        0.036 -- this file's `mmd` and column order reproduce them from the held files: 0.0149 / 0.13-0.14 depending on the
+        500-row subsample / 0.035), or 1.5 x the LARGEST value re-runs of the reference reach (8 seeds, same arguments:
+        0.039-0.096 / 0.08-0.13 / 0.032-0.037 -- the stored run's 0.0149 at step 0 is a favourable draw of an 80-iteration
+        fit, its own re-runs do not reach it), whichever is larger, floor 0.08;
+      * steps 0-5 against the reference-held NF-iSAM posteriors (run1/batch1..6): bar = 1.5 x the LARGEST distance of a
+        re-run of the reference (8 seeds, same arguments, fixture) to that stored run at that step, floor 0.08 -- a
+        single stored run of an 80-iteration fit is one draw, its distance to another draw is what re-runs say it is."""
+    from utils.Statistics import mmd
+    fx = np.load(os.path.join(GOLDEN, "pipeline_icra.npz"))
+    ref_seeds = [int(s) for s in fx["seeds"]]
+    held_mmd = np.asarray(fx["held_run1_mmd"], dtype=np.float64)
+    assert held_mmd.shape == (6,)
+    report = []
+    for seed in range(3):
+        sub = tmp_path / ("seed%d" % seed)
+        sub.mkdir()
+        run_dir, fits, n_steps = _run(sub, "icra", fx, seed)
+        assert n_steps == 6 and [f["iterations"] for f in fits] == [80] * len(fits)          # 80 < 2 windows: the budget runs out
+        for i in range(6):
+            order = open(os.path.join(run_dir, "step%d_ordering" % i)).read().split()
+            assert order == [str(v) for v in fx["held_run1_batch%d_ordering" % (i + 1)]], (i, order)
+            S = np.loadtxt(os.path.join(run_dir, "step%d" % i))[:500]
+            assert S.shape[0] == 500 and np.all(np.isfinite(S))
+            held = fx["held_run1_batch%d" % (i + 1)].astype(np.float64)
+            m_run = float(mmd(_xy_reorder(order, S, order), _xy_reorder(order, held, order))[0])
+            reruns = [float(mmd(_xy_reorder(order, fx["seed%d_step%d_samples" % (s, i)].astype(np.float64), order),
+                                _xy_reorder(order, held, order))[0]) for s in ref_seeds]
+            bar_run = max(0.08, 1.5 * np.nanmax(reruns))
+            report.append(("vs run1/batch%d" % (i + 1), seed, round(m_run, 4), round(float(np.nanmax(reruns)), 4)))
+            assert not m_run > bar_run, (seed, i, m_run, reruns)
+            if i <= 2:
+                ref_order = [str(v) for v in fx["held_reference_step%d_ordering" % i]]
+                R = fx["held_reference_step%d" % i].astype(np.float64)
+                R = R[np.random.RandomState(i).permutation(R.shape[0])[:500]]
+                Rxy = _xy_reorder(ref_order, R, ref_order)
+                m_ns = float(mmd(_xy_reorder(order, S, ref_order), Rxy)[0])
+                reruns_ns = [float(mmd(_xy_reorder(order, fx["seed%d_step%d_samples" % (s, i)].astype(np.float64), ref_order), Rxy)[0])
+                             for s in ref_seeds]
+                bar_ns = max(0.08, 1.5 * held_mmd[i], 1.5 * np.nanmax(reruns_ns))
+                report.append(("vs reference/step_%d" % i, seed, round(m_ns, 4), round(float(held_mmd[i]), 4), round(float(np.nanmax(reruns_ns)), 4)))
+                assert not m_ns > bar_ns, (seed, i, m_ns, held_mmd[i], reruns_ns)
+    print("icra", report)

@@ -325,6 +325,29 @@ int nfisam_nsf_train_plan_destroy(nfisam_train_plan* plan);
  *   end      pauses the feeder and orders `stream` behind everything enqueued on the plan.                */
 int nfisam_nsf_train_plan_begin(nfisam_train_plan* plan, nfisam_stream_t stream);
 int nfisam_nsf_train_plan_enqueue(nfisam_train_plan* plan);
+/* ABI 1400.  A training plan with the reference's HOLD-OUT stop rule (src/slam/NFiSAM.py:452-468, `training_set_frac < 1`):
+ * every `validation_interval` iterations -- in front of iteration i whenever (i + 1) % validation_interval == 0 -- the
+ * negative mean log-density of the held-out batch under the current parameters is evaluated on the device; the first time
+ * it exceeds the previous evaluation the run is scheduled to end at slower_stop_iter = int(slower_stop_rate * (i + 1))
+ * (the loop breaks in front of the iteration with i + 1 >= slower_stop_iter) and evaluation ceases.  The window rule is
+ * off in this mode (cfg->average_window is ignored), as in the reference (`if testing_data is None`, :481).
+ * One graph replay = one validation period; whole-number slower_stop_rate >= 1 only (the reference's default 2.0: the
+ * scheduled end then falls on a period boundary), 1 <= validation_interval <= 129; anything else: NFISAM_ERR_ARG (callers
+ * step such fits themselves).  state->have_avg / loss_avg hold the last validation loss, state->reserved[2] the scheduled
+ * end (0: none).  `val[c].logprob` is scratch of n_val floats; `val[c].val_loss` (nullable) receives evaluation number k
+ * at index k (max_iters / validation_interval entries).  All device pointers; `val` itself is a host array. */
+typedef struct nfisam_validation {
+    const float* x_val;       /* [n_val, D] held-out batch, normalised as the reference does (its OWN statistics, NFiSAM.py:381) */
+    float* logprob;           /* [n_val] scratch                                                              */
+    float* val_loss;          /* [max_iters / validation_interval] or NULL                                    */
+    int32_t n_val;
+    int32_t reserved;
+} nfisam_validation;
+int nfisam_nsf_train_plan_create_validated(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,
+                                           int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
+                                           const nfisam_validation* val, int validation_interval, float slower_stop_rate,
+                                           int use_graph, nfisam_train_plan** out);
+
 /* ABI 1400.  Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on (0: none has run; 1: what
  * the grid asks for; > 1: slower, equally correct -- the group's exchange uses agent-scope write-through stores).  */
 int nfisam_nsf_train_plan_xcd_span(const nfisam_train_plan* plan);

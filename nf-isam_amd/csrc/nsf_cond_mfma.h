@@ -266,7 +266,6 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     int gave_up = 0;
     // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
     if (st_stop != 0 || st_step + iter >= a.max_iters) return 1;     // block-uniform
-    if (pending) fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + iter, n);
     for (int base = 0; base < nj; base += 2 * NT) {
         const int ja = base + tid, jb = base + NT + tid;
         const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
@@ -293,6 +292,9 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
                     qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     qb[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                // (the iteration's bias corrections while the loads are under way: ~80 instructions that depend on nothing loaded)
+                if (base == 0 && spins == 0u)
+                    fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + iter, n);
                 bool ok = true;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {

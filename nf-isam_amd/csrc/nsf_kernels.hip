@@ -6,6 +6,7 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include <time.h>
 #include <vector>
 
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const int s0 = st->step, stop0 = st->stop, have_avg = st->have_avg;
     const float loss_avg = st->loss_avg;
     int new_step = s0, new_stop = stop0, new_have = have_avg, new_err = st->domain_err;
+    const int slower_stop = st->reserved[2];                         // hold-out validation: the scheduled end (nsf_validate_kernel), 0: none
     float new_avg = loss_avg;
     __shared__ float s_loss[LOSS_RING];
     __shared__ float s_wsum[4];
@@ -263,6 +265,8 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
             }
             new_step = t_end;
         }
+        // (reference NFiSAM.py:453-456: the loop breaks in front of iteration i when i + 1 >= slower_stop_iter)
+        if (slower_stop != 0 && new_step + 1 >= slower_stop) new_stop = 1;
     }
     if (threadIdx.x == 0) {
         if (stalled) {                                               // a group barrier of the chunk timed out: the run is over, loudly
@@ -278,8 +282,36 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
             const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
             m->step = new_step; m->stop = new_stop; m->have_avg = new_have; m->loss_avg = new_avg; m->domain_err = new_err;
             m->reserved[1] = st->reserved[1];
+            m->reserved[2] = st->reserved[2];
             __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+// Hold-out validation of a fit (reference: src/slam/NFiSAM.py:452-468, `training_set_frac < 1`): every
+// `validation_interval` iterations the NLL of the held-out batch is evaluated with the CURRENT parameters (before the
+// training step of that iteration); on the first increase the run is scheduled to end at slower_stop_rate x (i + 1), and no
+// further evaluation takes place.  `lp` = per-sample log-density of the held-out batch (nsf_forward_kernel, enqueued in front
+// of this kernel); one block, a fixed summation order.  State words: have_avg / loss_avg hold the last validation loss (the
+// window rule is off in this mode, as in the reference), reserved[2] the scheduled end (0: none).
+__global__ void __launch_bounds__(256) nsf_validate_kernel(const float* __restrict__ lp, int n_val, nfisam_train_state* st, float rate,
+                                                           int max_iters, int interval, float* __restrict__ record) {
+    __shared__ float s_w[4];
+    float sm = 0.0f;
+    for (int j = threadIdx.x; j < n_val; j += blockDim.x) sm += lp[j];
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (st->stop != 0 || st->step >= max_iters || st->reserved[2] != 0) return;
+    const float new_loss = -((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) / (float)n_val;
+    const int iter1 = st->step + 1;                                   // the reference's i + 1
+    if (record != nullptr && interval > 0) record[iter1 / interval - 1] = new_loss;
+    if (st->have_avg != 0 && new_loss > st->loss_avg) {
+        st->reserved[2] = (int)((double)rate * (double)iter1);         // slower_stop_iter = int(slower_stop_rate * (i + 1))
+    } else {
+        st->loss_avg = new_loss;
+        st->have_avg = 1;
     }
 }
 
@@ -859,6 +891,9 @@ struct nfisam_train_plan {
     hipEvent_t ev_end = nullptr;           // `end` records this one: the caller's stream may still hold the wait on it when the next
                                            // `begin` records p->ev -- re-recording an event a stream still waits for ties that wait to
                                            // the NEW record on this runtime (the stream then waits for itself)
+    // hold-out validation (nfisam_nsf_train_plan_create_validated): a chunk is one validation period
+    std::vector<nfisam_validation> val;    // per clique, or empty
+    float val_rate = 0.0f;
     bool stepping = false;                 // between `begin` and `end` (counted in g_hand_stepped)
     std::mutex enqueue_mu;                 // a chunk's graph launch and a slot's refill must not interleave on the stream: a graph
                                            // launch is not one atomic enqueue for a second thread (a state reset landed mid-chunk)
@@ -888,9 +923,38 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     return NFISAM_OK;
 }
 
+// One validation period of a validated plan on stream `s`: interval - 1 iterations (one chunk: its own closing Adam update
+// and bookkeeping, nothing published), the held-out NLL with the parameters as they stand and the reference's rule
+// (nsf_validate_kernel), then the period's last iteration as a chunk of one, whose bookkeeping publishes the state.
+// `persist`: the first part as ONE chunk-persistent launch.
+static int enqueue_validated_period(const nfisam_train_plan* p, hipStream_t s, bool persist);
+
+static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques, int K, int H, float B,
+                            int L, const nfisam_adam_cfg* cfg, const nfisam_validation* val, int validation_interval,
+                            float slower_stop_rate, int use_graph, nfisam_train_plan** out);
+
 extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
                                             int n_cliques, int K, int H, float B, int L,
                                             const nfisam_adam_cfg* cfg, int use_graph, nfisam_train_plan** out) {
+    return plan_create_impl(host_cliques, dev_cliques, n_cliques, K, H, B, L, cfg, nullptr, 0, 0.0f, use_graph, out);
+}
+
+extern "C" int nfisam_nsf_train_plan_create_validated(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
+                                                      int n_cliques, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
+                                                      const nfisam_validation* val, int validation_interval,
+                                                      float slower_stop_rate, int use_graph, nfisam_train_plan** out) {
+    // the scheduled end int(rate x (i + 1)) must fall on a period boundary: whole-number rates (the reference's default is 2.0)
+    if (val == nullptr || validation_interval < 1 || validation_interval > LOSS_RING + 1 || !(slower_stop_rate >= 1.0f) ||
+        slower_stop_rate != (float)(int)slower_stop_rate)
+        return NFISAM_ERR_ARG;
+    for (int c = 0; c < n_cliques; ++c)
+        if (val[c].x_val == nullptr || val[c].logprob == nullptr || val[c].n_val < 1) return NFISAM_ERR_ARG;
+    return plan_create_impl(host_cliques, dev_cliques, n_cliques, K, H, B, L, cfg, val, validation_interval, slower_stop_rate, use_graph, out);
+}
+
+static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques, int K, int H, float B,
+                            int L, const nfisam_adam_cfg* cfg, const nfisam_validation* val, int validation_interval,
+                            float slower_stop_rate, int use_graph, nfisam_train_plan** out) {
     int rc = check_cfg(cfg, K, H, L, B);
     if (rc) return rc;
     if (out == nullptr || host_cliques == nullptr || n_cliques < 1 || (n_cliques > 1 && dev_cliques == nullptr))
@@ -901,6 +965,12 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     p->n_cliques = n_cliques; p->K = K; p->H = H; p->L = L; p->B = B; p->cfg = *cfg;
     (void)hipGetDevice(&p->device);
     p->chunk = chunk_length(cfg);
+    if (val != nullptr) {                  // hold-out validation: one chunk = one validation period, the window rule is off (NFiSAM.py:481: `if testing_data is None`)
+        p->val.assign(val, val + n_cliques);
+        p->val_rate = slower_stop_rate;
+        p->chunk = validation_interval;
+        p->cfg.average_window = 0;
+    }
     if (hipHostMalloc((void**)&p->hst, sizeof(nfisam_train_state) * (size_t)n_cliques,
                       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&p->hst_dev, p->hst, 0) != hipSuccess) {
@@ -932,7 +1002,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
         //  which 20 iterations do not earn back -- C3, 20 iterations: 18.2 vs 18.8 us per iteration; with several chunks the
         //  launch of chunk k + 1 hides behind chunk k and two branches win from 20 iterations per chunk up: 15.2 -> 14.5)
         const bool one_short_chunk = cfg->max_iters <= p->chunk && p->chunk < 40 && getenv("NFISAM_CHAINS") == nullptr;
-        const int chains = one_short_chunk ? 1 : plan_chains(n_cliques, p->max_n, p->max_D, K, H, L);
+        const int chains = (one_short_chunk || !p->val.empty()) ? 1 : plan_chains(n_cliques, p->max_n, p->max_D, K, H, L);
         for (int g = 1; g < chains && e == hipSuccess; ++g) {
             hipStream_t st = nullptr;
             hipEvent_t ev2 = nullptr;
@@ -940,7 +1010,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
             if (e == hipSuccess) { p->side.push_back(st); e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming); }
             if (e == hipSuccess) p->side_ev.push_back(ev2);
         }
-        const bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L) && p->chunk > 1;
+        const bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L) && p->chunk > (p->val.empty() ? 1 : 2);
         for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
         const bool persist = pass == 1;
         hipGraph_t* graph_out = persist ? &p->graph_p : &p->graph;
@@ -951,7 +1021,8 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
                 e = hipEventRecord(p->ev, p->cap);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->side[g - 1], p->ev, 0);
             }
-            for (int it = 0; it < (persist ? 1 : p->chunk) && status == NFISAM_OK && e == hipSuccess; ++it)
+            if (!p->val.empty()) status = enqueue_validated_period(p, p->cap, persist);
+            for (int it = 0; p->val.empty() && it < (persist ? 1 : p->chunk) && status == NFISAM_OK && e == hipSuccess; ++it)
                 for (int g = 0; g < chains && status == NFISAM_OK; ++g)
                     status = enqueue_step(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, &p->cfg, it,
                                           g == 0 ? p->cap : p->side[g - 1], p->host.data(), g, chains, persist ? p->chunk : 0);
@@ -959,7 +1030,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
                 e = hipEventRecord(p->side_ev[g - 1], p->side[g - 1]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->cap, p->side_ev[g - 1], 0);
             }
-            if (status == NFISAM_OK && e == hipSuccess)
+            if (status == NFISAM_OK && e == hipSuccess && p->val.empty())
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
                                            p->cap, p->hst_dev);
             e = hipStreamEndCapture(p->cap, graph_out);
@@ -977,6 +1048,37 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
     return NFISAM_OK;
 }
 
+static int enqueue_validated_period(const nfisam_train_plan* p, hipStream_t s, bool persist) {
+    const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
+    const int head = p->chunk - 1;                              // iterations in front of the evaluation
+    int rc = NFISAM_OK;
+    if (head > 0) {
+        if (persist && head > 1) {
+            rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L, &p->cfg, 0, s, p->host.data(), 0, 1, head);
+        } else {
+            for (int it = 0; it < head && rc == NFISAM_OK; ++it)
+                rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L, &p->cfg, it, s, p->host.data());
+        }
+        if (rc == NFISAM_OK)
+            rc = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg, head, s, nullptr);
+        if (rc) return rc;
+    }
+    const NsfUnitOps* ops = find_ops(p->K, p->H);
+    if (ops == nullptr) return NFISAM_ERR_ARG;
+    for (int c = 0; c < p->n_cliques; ++c) {
+        const nfisam_clique& q = p->host[c];
+        const nfisam_validation& v = p->val[(size_t)c];
+        rc = ops->forward(v.x_val, q.kparams, v.n_val, q.D, p->B, p->L, 0, nullptr, nullptr, v.logprob, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nsf_validate_kernel, dim3(1), dim3(256), 0, s, (const float*)v.logprob, (int)v.n_val, q.state, p->val_rate,
+                           (int)p->cfg.max_iters, p->chunk, v.val_loss);
+        HIP_TRY(hipGetLastError());
+    }
+    rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L, &p->cfg, 0, s, p->host.data());
+    if (rc) return rc;
+    return enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg, 1, s, p->hst_dev);
+}
+
 // Waits until the bookkeeping kernel of chunk number `k` (1-based, this run) has written every clique's mirror.  The
 // device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms: the host spins for the first
 // ~50 us (the common case at the end of a short chunk), then sleeps 20 us between looks so that a worker thread or a rank
@@ -985,7 +1087,7 @@ extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, c
 // ~60 s without progress the wait gives up (-> `poisoned`: the caller must not synchronise a wedged stream either).
 static int wait_chunk(const nfisam_train_plan* p, int k, hipStream_t work, bool* poisoned) {
     const volatile nfisam_train_state* m = p->hst;
-    const struct timespec nap = {0, 20000};
+    const struct timespec nap = {0, 50000};
     for (long looks = 0;; ++looks) {
         bool all = true;
         for (int c = 0; c < p->n_cliques; ++c)
@@ -993,7 +1095,8 @@ static int wait_chunk(const nfisam_train_plan* p, int k, hipStream_t work, bool*
         if (all) break;
         if (looks > 3000000L) { *poisoned = true; return NFISAM_ERR_LAUNCH; }
         if ((looks & 0xffff) == 0xffff && hipStreamQuery(work) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
-        if (looks < 2000) __builtin_ia32_pause();
+        if (looks < 4000) __builtin_ia32_pause();
+        else if (looks < 200000) sched_yield();
         else nanosleep(&nap, nullptr);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1046,6 +1149,9 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
         if (exec && todo == p->chunk) {
             const hipError_t e = hipGraphLaunch(exec, work);
             if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+        } else if (!p->val.empty() && todo == p->chunk) {       // a validated plan without a graph: the same period, launch by launch
+            int rcv = enqueue_validated_period(p, work, false);
+            if (rcv) return rcv;
         } else {
             for (int it = 0; it < todo; ++it) {
                 int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L,

@@ -25,7 +25,7 @@ EXPORTS = [
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
     "nfisam_nsf_train_plan_begin", "nfisam_nsf_train_plan_enqueue", "nfisam_nsf_train_plan_peek", "nfisam_nsf_train_plan_stream",
-    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
+    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_create_validated", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
     "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
@@ -49,6 +49,11 @@ class Clique(C.Structure):
     _fields_ = [("x", C.c_void_p), ("kparams", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
                 ("kgrad", C.c_void_p), ("iter_loss", C.c_void_p), ("state", C.c_void_p),
                 ("n", C.c_int32), ("D", C.c_int32)]
+
+
+class Validation(C.Structure):
+    _fields_ = [("x_val", C.c_void_p), ("logprob", C.c_void_p), ("val_loss", C.c_void_p), ("n_val", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class PostClique(C.Structure):
@@ -351,9 +356,18 @@ class TrainBatch:
     once, so that one launch covers grid.y = clique."""
 
     def __init__(self, xs, kparams, K, H, B, L, lr, max_iters, average_window=50, loss_delta_tol=1e-2,
-                 beta1=0.9, beta2=0.999, eps=1e-8, early_stop=True):
+                 beta1=0.9, beta2=0.999, eps=1e-8, early_stop=True, x_val=None, validation_interval=10, slower_stop_rate=2.0):
+        """x_val (one held-out batch per clique): the plan stops by the reference's hold-out rule (NFiSAM.py:452-468,
+        nfisam_nsf_train_plan_create_validated) instead of the window rule; `val_loss[c]` then records every evaluation."""
         if len(xs) != len(kparams) or len(xs) == 0:
             raise ValueError("need one parameter blob per clique batch")
+        self.x_val = None
+        if x_val is not None:
+            if len(x_val) != len(xs) or any(v.shape[1] != x.shape[1] or v.shape[0] < 1 for v, x in zip(x_val, xs)):
+                raise ValueError("need one held-out batch [n_val, D] per clique")
+            self.x_val = [_dev(v, "x_val") for v in x_val]
+            self.validation_interval, self.slower_stop_rate = int(validation_interval), float(slower_stop_rate)
+            early_stop = False
         self.K, self.H, self.B, self.L = int(K), int(H), float(B), int(L)
         self.device = xs[0].device
         self.xs = [_dev(x, "x") for x in xs]
@@ -383,6 +397,15 @@ class TrainBatch:
             d.n, d.D = self.xs[c].shape
         raw = np.frombuffer(bytes(self.host_desc), dtype=np.uint8).copy()
         self.dev_desc = torch.from_numpy(raw).to(self.device)
+        if self.x_val is not None:
+            n_eval = max(1, int(max_iters) // max(self.validation_interval, 1))
+            self.val_scratch = [torch.empty(v.shape[0], dtype=torch.float32, device=self.device) for v in self.x_val]
+            self.val_loss = [torch.zeros(n_eval, dtype=torch.float32, device=self.device) for _ in self.x_val]
+            self.val_desc = (Validation * self.nc)()
+            for c in range(self.nc):
+                q = self.val_desc[c]
+                q.x_val, q.logprob, q.val_loss = self.x_val[c].data_ptr(), self.val_scratch[c].data_ptr(), self.val_loss[c].data_ptr()
+                q.n_val = self.x_val[c].shape[0]
 
     def step(self):
         """Enqueue ONE training iteration for all cliques (no host sync)."""
@@ -426,10 +449,14 @@ class TrainBatch:
             return
         self.close()
         plan = C.c_void_p(0)
-        rc = lib().nfisam_nsf_train_plan_create(self.host_desc,
-                                                C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None,
-                                                self.nc, self.K, self.H, C.c_float(self.B), self.L,
-                                                C.byref(self.cfg), int(bool(use_graph)), C.byref(plan))
+        dev_desc = C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None
+        if self.x_val is not None:
+            rc = lib().nfisam_nsf_train_plan_create_validated(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
+                                                              C.byref(self.cfg), self.val_desc, self.validation_interval,
+                                                              C.c_float(self.slower_stop_rate), int(bool(use_graph)), C.byref(plan))
+        else:
+            rc = lib().nfisam_nsf_train_plan_create(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
+                                                    C.byref(self.cfg), int(bool(use_graph)), C.byref(plan))
         _check(rc, "nfisam_nsf_train_plan_create")
         self._plan, self._plan_graph = plan, bool(use_graph)
 
@@ -497,6 +524,8 @@ class TrainBatch:
             if kparams is not None:
                 self.kparams[c].copy_(kparams[c])
             self.m[c].zero_(); self.v[c].zero_(); self.g[c].zero_(); self.iter_loss[c].zero_()
+            if self.x_val is not None:
+                self.val_loss[c].zero_()
         self.states.zero_()
 
     def close(self):
@@ -514,7 +543,7 @@ class TrainBatch:
     def state(self, c=0):
         s = self.states[c].cpu().numpy()
         return {"step": int(s[0]), "stop": int(s[1]), "have_avg": int(s[2]),
-                "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[4])}
+                "loss_avg": float(s[3:4].view(np.float32)[0]), "domain_err": int(s[4]), "slower_stop_iter": int(s[7])}
 
 
 def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt=None):

@@ -497,10 +497,25 @@ class NFiSAM(FactorGraphSolver):
         logger = logging.getLogger("flows on clique")
         opt_start = time.time()
         x_dev = prep["training_data"].to(device).contiguous()
-        tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
-                            average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
-        f0 = NSF_AR.from_kernel_params(prep["D"], K, B, H, prep["kp0"])
-        prep["iters"] = self._fit_with_validation(tb, prep["testing_data"].to(device).contiguous(), f0, logger)
+        x_val = prep["testing_data"].to(device).contiguous()
+        # The rule runs on the device as part of the training plan (one graph replay per validation period, no host
+        # synchronisation per evaluation: nfisam_nsf_train_plan_create_validated) when the scheduled end
+        # int(slower_stop_rate x (i + 1)) falls on a period boundary -- whole-number rates, the reference's default is 2.0;
+        # other settings are stepped from the host, iteration by iteration.
+        on_device = float(a.slower_stop_rate).is_integer() and a.slower_stop_rate >= 1 and 1 <= int(a.validation_interval) <= 129
+        if on_device:
+            tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                                early_stop=False, x_val=[x_val], validation_interval=a.validation_interval,
+                                slower_stop_rate=a.slower_stop_rate)
+            prep["iters"] = tb.run(use_graph=True)[0]
+            if prep["iters"] < a.flow_iterations:
+                logger.info(f"Slower stop at iter {prep['iters'] + 1}")
+            self.last_validation_losses = tb.val_loss[0]
+        else:
+            tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                                average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
+            f0 = NSF_AR.from_kernel_params(prep["D"], K, B, H, prep["kp0"])
+            prep["iters"] = self._fit_with_validation(tb, x_val, f0, logger)
         torch.cuda.synchronize()
         if timer is not None:
             timer.append(time.time() - opt_start)

@@ -289,6 +289,41 @@ def train(x, blob, K, H, B, L=1, lr=0.015, max_iters=10, average_window=50, loss
     return b.detach(), iter_loss, iters
 
 
+def train_with_validation(x, x_val, blob, K, H, B, L=1, lr=0.015, max_iters=10, validation_interval=10, slower_stop_rate=2.0):
+    """Full-batch Adam loop with the reference's HOLD-OUT stop rule (NFiSAM.py:451-476, case `testing_data is not None`,
+    i.e. training_set_frac < 1): in front of iteration i, if a slower stop is scheduled and i + 1 has reached it, break
+    (:453-456); else, when (i + 1) % validation_interval == 0, evaluate the held-out NLL with the current parameters (:458-463)
+    and, the first time it exceeds the previous evaluation, schedule the end at int(slower_stop_rate * (i + 1)) (:464-466),
+    otherwise remember it (:467-468); then the training step (:469-474).  No window rule in this mode (:479).
+    Returns (blob, iter_loss[max_iters] zero-padded, iters_run, [validation losses in evaluation order])."""
+    b = blob.detach().clone().requires_grad_(True)
+    opt = torch.optim.Adam([b], lr=lr)
+    iter_loss = torch.zeros(max_iters, dtype=torch.float32)
+    last_validation_loss = float("inf")
+    slower_stop_iter = None
+    val_losses = []
+    iters = 0
+    for i in range(max_iters):
+        if slower_stop_iter is not None:
+            if (i + 1) >= slower_stop_iter:
+                break
+        elif (i + 1) % validation_interval == 0:
+            with torch.no_grad():
+                new_loss = nll(x_val, b, K, H, B, L).detach()
+            val_losses.append(float(new_loss))
+            if new_loss > last_validation_loss:
+                slower_stop_iter = int(slower_stop_rate * (i + 1))
+            else:
+                last_validation_loss = new_loss
+        opt.zero_grad()
+        loss = nll(x, b, K, H, B, L)
+        iter_loss[i] = loss.detach()
+        loss.backward()
+        opt.step()
+        iters = i + 1
+    return b.detach(), iter_loss, iters, val_losses
+
+
 # ------------------------------------------------------------------ normalisation -------
 def wrap_pi(t):
     """src/utils/Functions.py:20-21"""

@@ -8,6 +8,8 @@ inputs; inputs and outputs are stored as small float32/float64 fixtures:
     tests/golden/nsf_<case>.npz        flow forward / loss / grads / Adam / inverse   (a1-a8)
     tests/golden/rqs_direct.npz        direct unconstrained_RQS / RQS / searchsorted  (a5, a6)
     tests/golden/normalize.npz         normalize_training_samples + (un)normalize     (a9, a10)
+    tests/golden/validation_loop.npz   the training loop with a held-out set (the reference's `for` statement, NFiSAM.py:451-492,
+                                       executed via `ast` extraction on the reference's own flow classes)   (a11 rule ii)
     tests/golden/se2_factors.npz       SE2Pose algebra + the `sample` bodies of the factor types of the clique
                                        simulator (f-2): SE(2) prior, odometry (3 directions), range ring / simulated
                                        range, k-way association and null-hypothesis mixtures
@@ -409,9 +411,73 @@ def gen_se2_and_factor_samplers():
     print("se2_factors done", {k: np.shape(v) for k, v in out.items() if k.startswith(("prior", "rel", "ring", "range"))})
 
 
+def gen_validation_loop():
+    """The reference's training loop WITH a held-out set (src/slam/NFiSAM.py:451-492): the `for i in range(flow_iterations)`
+    statement of `NFiSAM.fit_clique_density_model` is taken out of the reference file by `ast` (the module imports the
+    absent TransportMaps), compiled in memory and executed on the reference's own flow / model / prior classes (imported)
+    and a seeded batch.  Stored: inputs, initial state_dict, arguments, and what the loop did -- iterations run, the
+    loss record, every validation loss, the final parameters.  -> tests/golden/validation_loop.npz"""
+    path = os.path.join(REF, "slam/NFiSAM.py")
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    loop = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "fit_clique_density_model":
+            for st in ast.walk(node):
+                if isinstance(st, ast.For) and isinstance(st.iter, ast.Call) and getattr(st.iter.func, "id", "") == "range" and \
+                        st.iter.args and getattr(st.iter.args[0], "id", "") == "flow_iterations":
+                    loop = st
+    assert loop is not None
+    code = compile(ast.Module(body=[loop], type_ignores=[]), path, "exec")
+    out = {}
+    for case, (n_tr, n_val, D, K, lr, iters, interval, rate, seed) in {
+            "overfit": (96, 400, 3, 9, 0.015, 400, 10, 2.0, 11),       # a small training set: the held-out loss turns early
+            "interval7": (80, 300, 4, 5, 0.04, 300, 7, 2.0, 12),
+            "budget": (400, 400, 3, 9, 0.01, 60, 10, 2.0, 13)}.items():   # the budget runs out before the rule fires
+        torch.manual_seed(seed)
+        rng = np.random.RandomState(seed)
+        def draw(n):
+            r = 1.0 + 0.15 * rng.randn(n); ph = rng.uniform(-np.pi, np.pi, n)
+            cols = [r * np.cos(ph), r * np.sin(ph)] + [0.6 * rng.randn(n) + 0.4 * np.cos(ph) for _ in range(D - 2)]
+            x = np.stack(cols, 1)
+            return ((x - x.mean(0)) / x.std(0)).astype(np.float32)       # (each set by its OWN statistics, NFiSAM.py:379-383)
+        x_tr, x_va = draw(n_tr), draw(n_val)
+        flow = NSF_AR(dim=D, K=K, hidden_dim=H)
+        model = NormalizingFlowModel(CustomMultivariateNormal(dim=D), [flow])
+        sd0 = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+        msgs = []
+        logger = types.SimpleNamespace(info=lambda m: msgs.append(str(m)))
+        ns = dict(torch=torch, flow_iterations=iters, slower_stop_iter=None, testing_data=torch.tensor(x_va),
+                  training_data=torch.tensor(x_tr), validation_interval=interval, last_validation_loss=float("inf"),
+                  clique_density_model=model, logger=logger, optimizer=torch.optim.Adam(model.parameters(), lr=lr),
+                  iter_loss=torch.zeros(iters), average_window=50, loss_avg=None, loss_delta_tol=1e-2,
+                  self=types.SimpleNamespace(_args=types.SimpleNamespace(slower_stop_rate=rate)))
+        exec(code, ns)
+        il = ns["iter_loss"].numpy().copy()
+        vals = [float(m.split("validation loss:")[1]) for m in msgs if "validation loss:" in m]
+        out[case + "_x_train"], out[case + "_x_val"] = x_tr, x_va
+        out[case + "_args"] = np.array([D, K, H, iters, interval], dtype=np.int64)
+        out[case + "_lr_rate"] = np.array([lr, rate])
+        for k, v in state_to_np(sd0).items():
+            out[case + "_sd0_" + k] = v
+        for k, v in state_to_np(flow.state_dict()).items():
+            out[case + "_sd1_" + k] = v
+        out[case + "_iter_loss"] = il
+        out[case + "_iters_run"] = np.array(int(np.count_nonzero(il)))
+        out[case + "_val_losses"] = np.array(vals, dtype=np.float64)
+        out[case + "_slower_stop_iter"] = np.array(-1 if ns["slower_stop_iter"] is None else int(ns["slower_stop_iter"]))
+        print("validation loop", case, "iterations", int(np.count_nonzero(il)), "of", iters, "evaluations", len(vals),
+              "slower_stop_iter", ns["slower_stop_iter"])
+    np.savez_compressed(os.path.join(OUT, "validation_loop.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "validation":
+        gen_validation_loop()
+        sys.exit(0)
     for name, spec in CASES.items():
         gen_flow_case(name, *spec)
     gen_rqs_direct()
     gen_normalize()
     gen_se2_and_factor_samplers()
+    gen_validation_loop()

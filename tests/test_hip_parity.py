@@ -454,7 +454,7 @@ def test_large_launch_uses_atomics_and_still_matches_oracle(n):
     ring = 128 * 64 + 64      # per-iteration loss sums behind the gradient copies (+ 64 reserved words)
     assert nh.lib().nfisam_nsf_grad_workspace_count(n, D, K, H, L) == nh.kparam_count(D, K, H) + ring
     # <= 32 tiles of 64 particles: room for the fused-Adam launches' second set of copies and second (theta | m | v)
-    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == (63 + 32 + 3) * nh.kparam_count(D, K, H) + ring
+    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == (63 + 32 + 3 + 32) * nh.kparam_count(D, K, H) + ring
     assert nh.lib().nfisam_nsf_grad_workspace_count(6000, D, K, H, L) == 94 * nh.kparam_count(D, K, H) + ring
     blob, x = make_problem(n, D, K, H, L, seed=8, spread=1.0)
     tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, L)], K, H, B, L, lr=0.02, max_iters=5, early_stop=False)
@@ -1122,3 +1122,50 @@ def test_concurrent_plan_runs_share_the_persistent_form_safely():
             assert together[seed][2] == alone[seed][2] == 400
             np.testing.assert_array_equal(together[seed][0], alone[seed][0])
             np.testing.assert_array_equal(together[seed][1], alone[seed][1])
+
+
+# ---- hold-out validation on the device (round 4) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("use_graph", [True, False], ids=["graph", "eager"])
+@pytest.mark.parametrize("case", ["overfit", "interval7", "budget"])
+def test_validated_training_plan_against_the_reference_loop(case, use_graph):
+    """nfisam_nsf_train_plan_create_validated (the reference's hold-out stop rule, src/slam/NFiSAM.py:452-468, evaluated on the
+    device as part of the training plan: one graph replay per validation period, the first interval - 1 iterations of a period
+    as one chunk-persistent launch) against the REFERENCE'S OWN LOOP run on the reference's flow classes
+    (tests/golden/validation_loop.npz, make_golden.py: gen_validation_loop): iterations run (within one validation interval:
+    two float32 implementations may disagree about a marginal comparison; measured: equal), every validation loss, the
+    loss record (tight over the first 30 iterations, then within rounding-amplified noise) and the final parameters."""
+    from test_oracle_golden import validation_case
+    x, xv, b0, b1, D, K, H, iters, interval, lr, rate, g = validation_case(case)
+    tb = nh.TrainBatch([dev(x.numpy())], [kpack(b0.numpy(), D, K, H)], K, H, 5.0, 1, lr=lr, max_iters=iters, x_val=[dev(xv.numpy())],
+                       validation_interval=interval, slower_stop_rate=rate)
+    run = tb.run(use_graph=use_graph)[0]
+    ref_run = int(g[case + "_iters_run"])
+    assert abs(run - ref_run) <= interval, (run, ref_run)
+    il = tb.iter_loss[0].cpu().numpy()
+    ref_il, ref_vals = g[case + "_iter_loss"], g[case + "_val_losses"]
+    vals = tb.val_loss[0].cpu().numpy()
+    n_eval = min(len(ref_vals), int(np.count_nonzero(vals)))
+    assert n_eval >= len(ref_vals) - 1
+    np.testing.assert_allclose(vals[:n_eval], ref_vals[:n_eval], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(il[:30], ref_il[:30], rtol=5e-4, atol=5e-4)
+    both = min(run, ref_run)
+    assert np.median(np.abs(il[:both] - ref_il[:both])) < 5e-3
+    assert np.all(il[run:] == 0)
+    st = tb.state(0)
+    if case == "budget":
+        assert run == iters and st["slower_stop_iter"] == 0
+    else:
+        assert run < iters and st["slower_stop_iter"] == run + 1 and st["stop"] == 1     # the loop breaks in front of iteration slower_stop_iter - 1
+        assert run == ref_run, (run, ref_run)
+    got = nh.unpack(tb.kparams[0], D, K, H, 1).cpu().numpy()
+    assert np.quantile(np.abs(got - b1.numpy()), 0.5) < 5e-3 and np.all(np.isfinite(got))
+    tb.close()
+
+
+def test_validated_plan_rejects_what_the_device_rule_does_not_cover():
+    x = dev(np.random.RandomState(0).randn(128, 3))
+    kp = kpack(O.init_blob(3, 9, 8, torch.Generator().manual_seed(0)).numpy(), 3, 9, 8)
+    for interval, rate in ((10, 1.5), (0, 2.0), (200, 2.0), (10, 0.5)):
+        tb = nh.TrainBatch([x], [kp.clone()], 9, 8, 5.0, 1, lr=0.01, max_iters=50, x_val=[x], validation_interval=interval, slower_stop_rate=rate)
+        with pytest.raises(ValueError):
+            tb.prepare(True)

@@ -224,3 +224,45 @@ def test_c_oracle_early_stop_matches_torch_oracle():
     assert it == ic and it < 400 and it % 20 == 0
     np.testing.assert_allclose(lc[:ic], lt.numpy()[:it], atol=2e-3)
     assert np.all(lc[ic:] == 0)
+
+
+VALIDATION_CASES = ("overfit", "interval7", "budget")
+
+
+def validation_case(case):
+    """-> (x_train, x_val, blob0, blob1, D, K, H, max_iters, interval, lr, rate, golden dict)"""
+    g = np.load(os.path.join(GOLDEN, "validation_loop.npz"))
+    D, K, H, iters, interval = (int(v) for v in g[case + "_args"])
+    lr, rate = (float(v) for v in g[case + "_lr_rate"])
+
+    def blob(tag):
+        sd = {k[len(case) + 5:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(case + tag)}
+        return torch.as_tensor(O.blob_from_state_dict(sd, D))
+    return (torch.from_numpy(g[case + "_x_train"]), torch.from_numpy(g[case + "_x_val"]), blob("_sd0_"), blob("_sd1_"),
+            D, K, H, iters, interval, lr, rate, g)
+
+
+@pytest.mark.parametrize("case", VALIDATION_CASES)
+def test_validation_stop_rule_against_the_reference_loop(case):
+    """oracle.train_with_validation (restating src/slam/NFiSAM.py:451-476) against the reference's own `for` statement run on
+    the reference's flow classes (tests/golden/make_golden.py: gen_validation_loop): the same iterations run, the same
+    scheduled end, the same validation losses, loss record and final parameters (tolerance: float32 summation order)."""
+    x, xv, b0, b1, D, K, H, iters, interval, lr, rate, g = validation_case(case)
+    torch.set_num_threads(1)
+    b, il, run, vals = O.train_with_validation(x, xv, b0, K, H, 5.0, 1, lr=lr, max_iters=iters, validation_interval=interval,
+                                               slower_stop_rate=rate)
+    assert run == int(g[case + "_iters_run"])
+    ref_vals = g[case + "_val_losses"]
+    assert len(vals) == len(ref_vals)
+    np.testing.assert_allclose(vals, ref_vals, rtol=2e-4, atol=2e-4)
+    # The first iterations agree to rounding; an over-fitting Adam run at this learning rate then amplifies float32 rounding
+    # differences between two implementations of the same arithmetic (the reference evaluates the spline on scrambled
+    # copies, src/flows/flows.py:77-93: another summation order) into visibly different loss values -- the RULE's inputs (the
+    # validation losses above) and its outcome (iterations run) still coincide.
+    ref_il = g[case + "_iter_loss"]
+    np.testing.assert_allclose(il.numpy()[:30], ref_il[:30], rtol=2e-4, atol=2e-4)
+    assert np.median(np.abs(il.numpy()[:run] - ref_il[:run])) < 2e-3
+    assert np.all(il.numpy()[run:] == 0) and np.all(ref_il[run:] == 0)
+    assert float(torch.quantile((b - b1).abs(), 0.5)) < 5e-3 and bool(torch.isfinite(b).all())
+    if case != "budget":                                     # the rule fired: the end was scheduled at rate x (i + 1)
+        assert run == int(g[case + "_slower_stop_iter"]) - 1 and run < iters

@@ -219,6 +219,19 @@ def test_fit_with_validation_split_and_multilayer():
     it = solver.last_fit_iterations
     assert 10 <= it <= 120 and loss[it - 1] < loss[0]
     assert len(model.flows) == 2
+    # the rule ran on the device (tests/test_hip_parity.py holds it to the reference's own loop): every evaluation is on
+    # record, and a run that ended early ended where the rule scheduled it
+    vals = solver.last_validation_losses.cpu().numpy()
+    n_eval = int(np.count_nonzero(vals))
+    assert 1 <= n_eval <= it // 10 + 1 and np.all(np.isfinite(vals))
+    if it < 120:
+        first_rise = next(k for k in range(1, n_eval) if vals[k] > vals[:k].min() and vals[k] > vals[k - 1])
+        assert it == 2 * 10 * (first_rise + 1) - 1, (it, vals[:n_eval])
+    # a rate the device rule does not cover is stepped from the host: same interface, same kind of result
+    solver15 = NFiSAM(NFiSAMArgs(flow_iterations=60, num_knots=9, learning_rate=0.02, training_set_frac=0.8, validation_interval=10,
+                                 slower_stop_rate=1.5))
+    solver15.fit_clique_density_model(clique, samples, [L0, X0], None)
+    assert 10 <= solver15.last_fit_iterations <= 60
     xs = model.conditional_sample_given_observation(conditional_dim=6, sample_number=64)
     assert xs.shape == (64, 6) and np.all(np.isfinite(xs))
     with pytest.raises(NotImplementedError):

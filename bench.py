@@ -147,7 +147,7 @@ def c3_problem(seed0):
     return out
 
 
-REGIME_HIDDEN = {"plaza_clique_n2000_D15_H16": 16, "batch64_n2000_D15_H16": 16}     # hidden_dim of a regime (default H)
+REGIME_HIDDEN = {"plaza_clique_n2000_D15_H16": 16, "batch64_n2000_D15_H16": 16, "C2_single_clique_n4096_D6_L4_H16": 16}     # hidden_dim of a regime (default H)
 
 
 def regime_problem(name, seed0):
@@ -226,6 +226,10 @@ class Workload:
         il = [t.cpu().numpy() for t in tb.iter_loss]
         for v in il:
             assert np.all(np.isfinite(v)) and v[iters - 1] < v[0], (v[0], v[iters - 1])
+        # which form the plan ran in: chunk-persistent launches (a chunk's iterations in ONE launch per chain) report the XCDs
+        # their (clique, dim) groups sat on; 0 = one launch per iteration
+        self.persistent = tb.xcd_span() > 0
+        self.chunk_iters = max(c for c in range(1, min(iters, 128) + 1) if iters % c == 0)    # nsf_kernels.hip: chunk_length()
         tb.close()
         self.replays = reps
         return (float(np.median(dts)), float(np.median(gms)), float(np.mean([v[0] for v in il])),
@@ -262,12 +266,24 @@ class Workload:
     def record(self, iters, warmup, barrier, reduce_max=None):
         dt, gpu_ms, l0, l1 = self.time_iterations(iters, warmup, barrier, reduce_max)
         kus, chains = self.time_gradient_kernel()
-        ach = self.flop_per_launch / (kus * 1e-6) / 1e12
+        ach_plain = self.flop_per_launch / (kus * 1e-6) / 1e12
+        gpu_us_it = 1e3 * gpu_ms / iters
+        # The kernel of the timed region.  One launch per iteration: the gradient kernel timed alone (above).  Chunk-persistent
+        # plan: ONE launch runs `chunk_iters` iterations; its duration is taken from the HIP events around the timed region
+        # (per chunk: that launch + the chunk's closing Adam and bookkeeping kernels, ~12 us -- a lower bound of the rate).
+        if self.persistent:
+            launch_us, launch_flop = gpu_us_it * self.chunk_iters, self.flop_per_launch * self.chunk_iters
+        else:
+            launch_us, launch_flop = kus, self.flop_per_launch
+        ach = launch_flop / (launch_us * 1e-6) / 1e12
         return dict(cliques=len(self.xs), D=[int(x.shape[1]) for x in self.xs] if len(self.xs) <= 8 else int(self.xs[0].shape[1]),
                     particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, hidden_dim=self.H, iterations=iters, replays=self.replays,
                     us_per_iteration=1e6 * dt / iters, gpu_us_per_iteration_events=1e3 * gpu_ms / iters,
                     samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus, launches_per_training_iteration=chains,
                     flop_per_launch=self.flop_per_launch, achieved_tflops=ach, frac_of_fp32_peak=ach / FP32_PEAK_TFLOPS,
+                    chunk_persistent=bool(self.persistent), iterations_per_launch=self.chunk_iters if self.persistent else 1,
+                    training_launch_us=launch_us, training_launch_flop=launch_flop,
+                    one_launch_per_iteration={"kernel_us": kus, "achieved_tflops": ach_plain, "frac_of_fp32_peak": ach_plain / FP32_PEAK_TFLOPS},
                     first_loss=l0, final_loss=l1), dt
 
 
@@ -455,7 +471,7 @@ def main():
     regimes = {}
     if rank == 0 and world == 1 and not args.no_regimes:
         for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15", "plaza_clique_n2000_D15_H16",
-                     "batch64_n2000_D15_H16"):
+                     "batch64_n2000_D15_H16", "C2_single_clique_n4096_D6_L4_H16"):
             prob, L = regime_problem(name, seed0=7)
             regimes[name], _ = Workload(prob, L, dev, REGIME_HIDDEN.get(name)).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
 
@@ -481,43 +497,58 @@ def main():
             "final_loss": head["final_loss"], "first_loss": head["first_loss"],
             "roofline": {"bound": "valu_issue", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "nsf_train1_kernel<9,8>", "kernel_us": head["gradient_kernel_us"],
-                         "flop_per_launch": head["flop_per_launch"],
+                         "kernel": "nsf_train1_kernel<9,8,true>" if head["chunk_persistent"] else "nsf_train1_kernel<9,8>",
+                         "kernel_us": head["training_launch_us"], "flop_per_launch": head["training_launch_flop"],
+                         "iterations_per_launch": head["iterations_per_launch"],
                          "launches_per_training_iteration": head["launches_per_training_iteration"],
                          "achieved_in_training": head["flop_per_launch"] / (head["gpu_us_per_iteration_events"] * 1e-6) / 1e12,
+                         "one_launch_per_iteration": head["one_launch_per_iteration"],
                          "note": "fp32 INSTRUCTION-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, HBM does not bind), priced "
-                                 "against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  Per (dim, 64-particle "
-                                 "tile) unit a wave issues ~560 VALU instructions (~450 of them the spline, 64 transcendentals), "
-                                 "164 v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane), 48-64 v_mfma_f32_16x16x4 "
-                                 "(the weight-gradient GEMMs) and ~220 LDS instructions; on gfx950 f32 MFMA and VALU issue of a "
-                                 "SIMD do not overlap (profiles/history/r02_mfma_valu_issue_microbench.txt), so their times add, and under "
-                                 "load a VALU instruction costs ~2.9 cycles of the port (profiles/r03_phase_cycles_stamps3.txt): "
-                                 "the 64-clique batch (`regimes.batch64_n2000_D15`, the throughput regime) runs at ~95 % of what "
-                                 "this instruction mix allows (DESIGN.md §3.1c).  333 MFLOP per launch = 2.1 us at peak: the C3 "
-                                 "launch is 3072 waves of ONE unit each at 3 waves per SIMD, i.e. a third of it is prologue / "
-                                 "epilogue latency (memory round trips, one barrier).  `kernel_us` times the gradient kernel as "
-                                 "ONE launch over all (clique, dim) groups, back to back in a graph; a training plan issues it as "
-                                 "`launches_per_training_iteration` concurrent launches over disjoint groups (parallel graph "
-                                 "branches) and the same kernel also applies the previous iteration's Adam update on its way into "
-                                 "LDS (no separate Adam launch): `achieved_in_training` = flop_per_launch / GPU time per training "
-                                 "iteration of the timed region.  Algorithmic HBM bytes per launch: 608 KB (x) + 112 KB "
-                                 "(parameters); `traffic` is null because it is not measured in this run (PMC passes: profiles/, "
-                                 "see `traffic_profiled`)."},
+                                 "against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  `kernel` is the kernel the "
+                                 "TIMED REGION ran.  Chunk-persistent form (nsf_train1_kernel<9,8,true>, DESIGN.md §3.1e/f): one "
+                                 "launch per parallel graph branch runs `iterations_per_launch` training iterations (gradient + the "
+                                 "previous iteration's Adam update; the blocks of a (clique, dim) group exchange their gradient "
+                                 "copies as tagged words, no kernel boundary); `flop_per_launch` = 333 MFLOP x iterations per launch "
+                                 "summed over the concurrent launches, `kernel_us` = the HIP-event GPU time of the timed region per "
+                                 "chunk, i.e. that launch PLUS the chunk's closing Adam and bookkeeping kernels (~12 us per chunk: "
+                                 "rocprofv3's average for the kernel alone is that much shorter).  One launch per iteration "
+                                 "(nsf_train1_kernel<9,8>): `kernel_us` times the gradient kernel as ONE launch over all groups, "
+                                 "200 back to back in a graph (`one_launch_per_iteration` holds that figure in either case).  Per "
+                                 "(dim, 64-particle tile) unit a wave issues ~560 VALU instructions (~450 of them the spline, 64 "
+                                 "transcendentals), 164 v_mfma_f32_4x4x1 (the conditioner mat-vecs, particle on the lane), 48-64 "
+                                 "v_mfma_f32_16x16x4 (the weight-gradient GEMMs) and ~220 LDS instructions; f32 MFMA and VALU issue of "
+                                 "a SIMD do not overlap on gfx950 (profiles/history/r02_mfma_valu_issue_microbench.txt).  C3 is 2496 "
+                                 "(dim, tile) units on 1024 SIMDs: per iteration and wave ~12 k cycles of arithmetic and ~15 k of "
+                                 "staging (the group's 8 gradient copies -> Adam -> panel), epilogue (block sum, copy out) and "
+                                 "barriers at three waves per SIMD (profiles/r04_phase_cycles_persistent.txt) -- a latency-plus-issue "
+                                 "regime; the 64-clique batch (`regimes.batch64_n2000_D15`) is the throughput regime at ~95 % of what "
+                                 "its instruction mix allows (DESIGN.md §3.1c).  Algorithmic HBM bytes per iteration: 608 KB (x, "
+                                 "read once per CHUNK by the persistent form: the tile stays in LDS) + 112 KB (parameters); "
+                                 "`traffic` = HBM-side bytes per launch from separate rocprofv3 --pmc passes of an earlier run of "
+                                 "this workload (lower bound of the gfx950 FETCH_SIZE range, see `traffic_profiled`), not measured "
+                                 "in this run."},
             "regimes": regimes,
         }
-        tj = os.path.join(ROOT, "profiles", "r03_train_kernel_traffic.json")
-        if os.path.exists(tj):   # HBM bytes per launch from separate rocprofv3 --pmc passes of an EARLIER run of this workload
+        import glob
+        tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_kernel_traffic.json")))
+        if tjs:   # HBM bytes per launch from separate rocprofv3 --pmc passes of an EARLIER run of this workload (latest round)
             try:
-                out["roofline"]["traffic_profiled"] = dict(json.load(open(tj)), source="profiles/r03_train_kernel_traffic.json")
+                t = json.load(open(tjs[-1]))
+                out["roofline"]["traffic_profiled"] = dict(t, source="profiles/" + os.path.basename(tjs[-1]))
+                if t.get("kernel") == out["roofline"]["kernel"] or not head["chunk_persistent"]:
+                    out["roofline"]["traffic"] = t.get("hbm_side_bytes_per_launch_lower")
+                    out["roofline"]["traffic_provenance"] = ("profiled earlier (%s): lower bound of the HBM-side bytes per launch of %s"
+                                                             % (os.path.basename(tjs[-1]), t.get("kernel")))
             except Exception:   # noqa: BLE001
                 pass
-        uj = os.path.join(ROOT, "profiles", "r03_issue_utilisation.json")
+        ujs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_utilisation.json")))
+        uj = ujs[-1] if ujs else ""
         if os.path.exists(uj):   # VALU issue / MFMA busy fractions from the same EARLIER profiled run (not measured here)
             try:
                 u = json.load(open(uj))
                 out["roofline"]["issue_profiled"] = {k: {f: u[k][f] for f in ("valu_issue_frac", "mfma_busy_frac", "issue_frac")}
                                                      for k in ("C3", "batch64")}
-                out["roofline"]["issue_profiled"]["source"] = "profiles/r03_issue_utilisation.json"
+                out["roofline"]["issue_profiled"]["source"] = "profiles/" + os.path.basename(uj)
             except Exception:   # noqa: BLE001
                 pass
         if args.no_update_bench or world > 1:       # end-to-end update timing and CPU baseline: N = 1 only

@@ -190,9 +190,13 @@ class _Staging:
 _staging = threading.local()
 
 
-def upload(*arrays, device):
+def upload(*arrays, device, cached=False):
     """Small numpy arrays -> device tensors of the same dtype and shape, ONE asynchronous copy for all of them on the
-    current stream (each array starts 64-byte aligned in the transfer)."""
+    current stream (each array starts 64-byte aligned in the transfer).  The result is ordered behind the copy on THAT
+    stream only: a tensor that is kept and later used on other streams (`cached=True`: a model's circular flags, tables that
+    outlive the call) is copied the plain way instead -- from pageable memory, host-synchronous, complete when the call
+    returns and therefore safe on any stream.  A non-CUDA `device` never goes through the pinned ring (a `.to` of a pinned
+    slice onto the CPU would alias the ring)."""
     arrays = [np.ascontiguousarray(a) for a in arrays]
     if not arrays:
         return []
@@ -203,7 +207,7 @@ def upload(*arrays, device):
     raw = np.zeros(max(total, 1), dtype=np.uint8)
     for a, o in zip(arrays, offs):
         raw[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
-    if total > _Staging.CHUNK or not torch.cuda.is_available():
+    if total > _Staging.CHUNK or cached or not torch.cuda.is_available() or torch.device(device).type != "cuda":
         dev = torch.from_numpy(raw).to(device)
     else:
         rings = _staging.__dict__.setdefault("rings", {})

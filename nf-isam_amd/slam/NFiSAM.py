@@ -98,7 +98,7 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
         if self._norm_cache is None or self._norm_cache[0] != str(device):
             mean = torch.as_tensor(self.samples_mean, dtype=torch.float32).to(device).contiguous()
             std = torch.as_tensor(self.samples_std, dtype=torch.float32).to(device).contiguous()
-            circ, = _nh.upload(np.asarray(self.circular_dim_list, dtype=np.uint8), device=device)
+            circ, = _nh.upload(np.asarray(self.circular_dim_list, dtype=np.uint8), device=device, cached=True)
             self._norm_cache = (str(device), mean, std, circ)
         return self._norm_cache[1:]
 
@@ -300,6 +300,8 @@ class NFiSAM(FactorGraphSolver):
                              "hidden_dim in {4, 8, 16} (nf-isam_amd/csrc/nsf_units.h)" % (a.num_knots, a.hidden_dim))
         if int(a.flow_number) < 1:
             raise ValueError("flow_number must be >= 1")
+        import threading
+        self._train_lock = threading.RLock()     # train_prepared: one caller at a time per solver
 
     # The loss curves of the update's fits (reference attribute: FactorGraphSolver._temp_training_loss, clique name ->
     # list of per-iteration losses) are fetched from the device when somebody LOOKS at them: one copy for all fits recorded
@@ -402,6 +404,13 @@ class NFiSAM(FactorGraphSolver):
         Training plans (device buffers + the captured hipGraph of one chunk of iterations) are kept per batch shape
         and re-used: the batches and the fresh parameters are copied into the plan's buffers, Adam moments / state /
         loss record are cleared in place.  Fills prep["trained"], ["iters"], ["iter_loss"]."""
+        # One caller at a time per solver: the plan cache below is an LRU whose eviction CLOSES a TrainBatch, and a worker
+        # thread of slam.ReplicaNFiSAM may be inside this function (an odd-shaped batch) while the scheduler retries a failed
+        # clique through the same solver (re-entrant: the retry below calls back in).
+        with self._train_lock:
+            return self._train_prepared_locked(preps, retry)
+
+    def _train_prepared_locked(self, preps: List[dict], retry: bool) -> None:
         a = self._args
         K, H, B, L = preps[0]["cfg"]
         device = preps[0]["device"]

@@ -292,8 +292,8 @@ class ReplicaNFiSAM:
             for r in ready:
                 prep, owner[r] = owner[r], None
                 step, _, err = states[r]
-                if err:                                    # non-finite loss: the batch path's handling (one retry from fresh parameters)
-                    self.solvers[0].train_prepared([prep])
+                if err:                                    # non-finite loss: the batch path's handling (one retry from fresh parameters),
+                    self.solvers[r].train_prepared([prep])  # on the replica's OWN solver: `last_fit_retried` and the plan cache are its
                 else:
                     prep["trained"], prep["iters"], prep["iter_loss"] = tb.kparams[r].clone(), step, tb.iter_loss[r].clone()
                 self.fit_iterations[r] += int(prep["iters"])

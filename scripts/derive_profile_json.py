@@ -9,7 +9,21 @@ SIMDS, SES = 1024, 32
 
 
 def kernel_of(d):
-    return next(v for k, v in d.items() if "nsf_train1_kernel" in k)
+    """the training kernel of the run: the chunk-persistent instantiation (<K, H, true>) when the plan took it (its launches
+    run a whole chunk of iterations), else the one-launch-per-iteration kernel"""
+    ks = [k for k in d if "nsf_train1_kernel" in k]
+    per = [k for k in ks if "true" in k]
+    name = (per or ks)[0]
+    return dict(d[name], _name=name, _persistent=bool(per))
+
+
+def iterations_per_launch(src, key):
+    """bench.py's own line of the profiled run (collect_profiles.sh keeps it): iterations a launch of the training kernel runs"""
+    try:
+        line = json.load(open(src + "/%s_bench_line.json" % key))
+        return int(line["roofline"].get("iterations_per_launch", 1))
+    except Exception:   # noqa: BLE001
+        return 1
 
 
 out = {"_formulas": {
@@ -24,11 +38,14 @@ out = {"_formulas": {
     "scalar_cache_hit_rate": "SQC_DCACHE_HITS / (SQC_DCACHE_HITS + SQC_DCACHE_MISSES)"}}
 for name, key in (("C3", "c3"), ("batch64", "b64")):
     k = kernel_of(pm[key])
+    ipl = iterations_per_launch(src, key) if k["_persistent"] else 1
     cyc = k["SQ_BUSY_CYCLES"] / SES
     valu = 2.0 * k["SQ_ACTIVE_INST_VALU"] / (cyc * SIMDS)
     mfma = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS)
     out[name] = {
-        "kernel": "nsf_train1_kernel<9,8>", "kernel_cycles": cyc, "waves_launched": k["SQ_WAVES"],
+        "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_kernel<9,8>", "iterations_per_launch": ipl,
+        "kernel_cycles": cyc, "kernel_cycles_per_iteration": cyc / ipl, "waves_launched": k["SQ_WAVES"],
+        "valu_instructions_per_iteration": k["SQ_INSTS_VALU"] / ipl, "mfma_instructions_per_iteration": k["SQ_INSTS_MFMA"] / ipl,
         "valu_instructions": k["SQ_INSTS_VALU"], "mfma_instructions": k["SQ_INSTS_MFMA"], "lds_instructions": k["SQ_INSTS_LDS"],
         "salu_instructions": k["SQ_INSTS_SALU"], "smem_instructions": k["SQ_INSTS_SMEM"],
         "valu_issue_frac": valu, "mfma_busy_frac": mfma, "issue_frac": valu + mfma,
@@ -39,6 +56,7 @@ for name, key in (("C3", "c3"), ("batch64", "b64")):
 json.dump(out, open(dst + "_issue_utilisation.json", "w"), indent=1)
 
 k = kernel_of(pm["c3"])
+ipl = iterations_per_launch(src, "c3") if k["_persistent"] else 1
 P = [None]
 alg = 723552                                         # bench.py: 608 KB (x) + 112 KB (parameters) for the C3 launch
 # C3 parameter counts (K = 9, H = 8): count(D) = 32 + (D-1)*368 + 8*(D-1)*D/2
@@ -48,7 +66,8 @@ copies = 8
 grad_bytes = copies * sum(Pc) * 4
 state_bytes = 3 * sum(Pc) * 4
 traffic = {
-    "kernel": "nsf_train1_kernel<9,8>", "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
+    "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_kernel<9,8>", "iterations_per_launch": ipl,
+    "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
               "(the launch also applies the previous iteration's Adam update)",
     "launches_averaged": int(k.get("_n", 0)) or None,
     "FETCH_SIZE_KB_raw": k["FETCH_SIZE"], "WRITE_SIZE_KB_raw": k["WRITE_SIZE"],
@@ -68,6 +87,20 @@ traffic = {
             "(L2 / Infinity-Cache hits after the first).  At ~300 GB/s of fabric traffic the kernel is nowhere near the HBM "
             "roofline; the figure that matters is the issue utilisation (*_issue_utilisation.json)." % (grad_bytes / 1e6, state_bytes / 1e6, k["WRITE_SIZE"] * 1024 / 1e6),
 }
+traffic["hbm_side_bytes_per_iteration_lower"] = traffic["hbm_side_bytes_per_launch_lower"] / ipl
+traffic["hbm_side_bytes_per_iteration_upper"] = traffic["hbm_side_bytes_per_launch_upper"] / ipl
+if k["_persistent"]:
+    # the persistent launch reads the particle batch ONCE per chunk (the tiles stay in LDS): algorithmic bytes per launch =
+    # x once + the parameters / moments in and out; per iteration nothing HAS to cross the L2-fabric boundary at all
+    alg = 608000 + 3 * sum(Pc) * 4 * 2
+    traffic["algorithmic_bytes_per_launch"] = alg
+    traffic["note"] = ("chunk-persistent launch of %d iterations (NFISAM_CHAINS=1: one launch per chunk); separate rocprofv3 --pmc FETCH_SIZE / "
+                       "--pmc WRITE_SIZE passes, means over the launches of the run.  The counters sit at the L2-fabric boundary and "
+                       "include Infinity-Cache hits; FETCH_SIZE counts 64 B per 128-B request for wide streaming reads on gfx950 "
+                       "(both bounds given).  Per iteration every block writes its gradient copy as (value, tag) pairs with "
+                       "write-through stores (2 x %.2f MB = the WRITE side) and the 8 blocks of a (clique, dim) group read the 8 copies "
+                       "back (L2 hits when the group sits on one XCD: the FETCH side stays small); the particle batch is read once per "
+                       "launch." % (ipl, grad_bytes / 1e6))
 traffic["ratio_to_algorithmic"] = [traffic["hbm_side_bytes_per_launch_lower"] / alg, traffic["hbm_side_bytes_per_launch_upper"] / alg]
 json.dump(traffic, open(dst + "_train_kernel_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)); print(json.dumps(traffic, indent=1)[:1500])

@@ -7,19 +7,17 @@ Oracle for this test = the reference's own stored results for this exact problem
 (tests/golden/small_range_case1.npz, see make_small_range_fixture.py): its NF-iSAM posterior samples
 (run1, steps 0-5) and the dynamic-nested-sampling "ground truth" posteriors (dyn1, steps 0-3).
 
-Metric = the reference's: biased MMD with an RBF kernel, sigma = sqrt(dim), on the xy columns
-(src/utils/Statistics.py:68-84; mmd_rmse_time_da_plot_grid.py:167,245).
+Metric = the reference's estimator (biased MMD, RBF kernel, sigma = sqrt(dim), xy columns: src/utils/Statistics.py:68-84;
+mmd_rmse_time_da_plot_grid.py:167,245) on columns STANDARDISED by the spread of the sample set compared against.  In raw
+metres -- the reference's usage -- the statistic is at its floor sqrt(1/n + 1/m) at steps 0-1 whatever the samples are (an RBF
+of width sqrt(dim) m in a 100 m world: eight re-runs of the reference all score 0.055 against the stored run AND against
+nested sampling there), so round 3's "<= 0.08 at steps 0-2" could not fail; the raw values are still printed.
 
-Stated tolerances (training is stochastic; the reference never seeds torch, so parity is distributional):
-  * steps 0-2 (near-Gaussian / single ring): MMDb <= 0.08 against nested sampling AND against the
-    reference's NF run — the noise floor of two 1000-sample sets is 0.045-0.063 (SURVEY.md §4);
-  * step 3 (bimodal landmark): <= 0.315 = 1.5 x 0.21, the reference's own run-to-run spread at this step
-    (SURVEY.md §4: stored run vs re-run 0.21; stored run vs nested 0.14);
-  * steps 4-5 (no nested-sampling blobs in the checkout, a single stored reference run): <= 0.55 against
-    that run (8 seeds on MI355X: 0.18-0.37, one seed 0.45 after a rounding-level kernel change), plus first/second-moment
-    checks against the known ground-truth geometry.  0.55 = 1.5 x the REFERENCE'S OWN run-to-run spread at these steps
-    (tests/golden/pipeline_small_range.npz, five reference runs: median pairwise MMDb 0.34 / 0.38, maximum 0.57 / 0.70);
-    tests/test_pipeline_gpu.py holds the same steps to that five-seed band directly.
+Tolerances (training is stochastic; the reference never seeds torch, so parity is distributional): statistic = MMDb of
+this run to the stored result; bound per step = max(0.08, 1.5 x the LARGEST value the reference's own re-runs reach against
+that same stored result) -- eight runs of the reference with these arguments (tests/golden/pipeline_small_range.npz,
+make_pipeline_fixture.py; round 3 used a scalar 0.45 / 0.55 at steps 4-5 that had been moved once).  Steps 0-3 are held to
+the nested-sampling posteriors the same way; steps 4-5 also to first / second moments of the known ground-truth geometry.
 Every variant is run with three seeds and every seed has to meet the tolerances.
 """
 import json
@@ -69,6 +67,19 @@ def _one_run(tmp_path, device_simulation, seed):
                                      device_simulation=device_simulation)
     rd = run_dirs[0]
     assert json.loads(open(os.path.join(rd, "parameters")).read())["num_knots"] == 9
+    fx = np.load(os.path.join(GOLDEN, "pipeline_small_range.npz"))       # eight re-runs of the reference, same arguments
+
+    def standardised(a_xy, b_xy):
+        sc = np.maximum(b_xy.std(0), 1e-3)
+        return MMDb(a_xy / sc, b_xy / sc)
+
+    def bar(i, target_xy, order):
+        """1.5 x the largest distance of a reference re-run to `target_xy` at step i (floor 0.08)"""
+        vals = []
+        for sd in fx["seeds"]:
+            assert [str(v) for v in fx["seed%d_step%d_ordering" % (sd, i)]] == order
+            vals.append(standardised(xy(order, fx["seed%d_step%d_samples" % (sd, i)].astype(np.float64))[0], target_xy))
+        return max(0.08, 1.5 * max(vals)), max(vals)
     truth = {"X0": (0, 0), "X1": (0, 30), "X2": (30, 30), "X3": (60, 30), "X4": (90, 30), "X5": (90, 0),
              "L1": (30, -30), "L2": (60, -30)}
     expected_cols = [7, 10, 13, 16, 19, 22]
@@ -84,14 +95,16 @@ def _one_run(tmp_path, device_simulation, seed):
         assert len(l) == 2000 and it % 50 == 0 and 100 <= it <= 2000 and np.all(l[it:] == 0)
         ours_xy, cols = xy(order, ours)
         ref_xy, _ = xy(order, g["run1_step%d" % i])
-        m_ref = MMDb(ours_xy, ref_xy)
-        # steps 4-5 are compared with the reference's SINGLE stored run of a multi-modal posterior: loose
-        tol_ref = 0.08 if i <= 2 else (0.315 if i == 3 else 0.55)
-        assert m_ref <= tol_ref, (i, m_ref)
+        m_ref, (tol_ref, worst_rerun) = standardised(ours_xy, ref_xy), bar(i, ref_xy, order)
+        print("step %d vs the stored run: %.3f (reference re-runs reach %.3f; raw metres %.3f)" % (i, m_ref, worst_rerun, MMDb(ours_xy, ref_xy)))
+        assert m_ref <= tol_ref, (i, m_ref, tol_ref)
         if i <= 3:
-            dyn_xy, _ = xy(str(g["dyn1_step%d_ordering" % i]).split(), g["dyn1_step%d" % i])
-            m_dyn = MMDb(ours_xy, dyn_xy)
-            assert m_dyn <= (0.08 if i <= 2 else 0.315), (i, m_dyn)
+            dyn_order = str(g["dyn1_step%d_ordering" % i]).split()
+            assert sorted(dyn_order) == sorted(order)
+            dyn_xy, _ = xy(dyn_order, g["dyn1_step%d" % i])
+            m_dyn, (tol_dyn, worst_dyn) = standardised(ours_xy, dyn_xy), bar(i, dyn_xy, order)
+            print("step %d vs nested sampling: %.3f (reference re-runs reach %.3f)" % (i, m_dyn, worst_dyn))
+            assert m_dyn <= tol_dyn, (i, m_dyn, tol_dyn)
         # poses are well determined by odometry: within 4 sigma of the ground truth
         for v in order:
             if v.startswith("X"):

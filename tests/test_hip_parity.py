@@ -111,7 +111,10 @@ class TestAgainstReferenceGolden:
         # coordinate is held to the strict tolerance, and nothing may be off by more than the steps taken.
         g0 = np.abs(O.blob_from_state_dict(sd_of(g, "g0"), D))
         noisy = g0 < NOISE_GRAD
-        assert noisy.mean() < 0.25, noisy.mean()
+        # measured per golden case (fraction of exempt coordinates): 0 (d1_k9, d5_k3_h4) .. 0.0204 (n64_d4_k15: 15 bins on 64
+        # particles); the guard is twice the largest, so that a misplaced gradient row cannot hide in the exemption
+        print("exempt (noise-level reference gradient) fraction of %s: %.4f" % (os.path.basename(path), noisy.mean()))
+        assert noisy.mean() <= 2 * 0.0204, noisy.mean()
         for steps, atol in ((1, 2e-4), (2, 4e-4), (10, 2e-3)):
             ref = O.blob_from_state_dict(sd_of(g, "p%d" % steps), D)
             err = np.abs(snaps[steps] - ref)

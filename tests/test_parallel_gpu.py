@@ -197,4 +197,14 @@ def test_bench_under_the_launcher_over_rccl_prints_only_the_contract_line():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 1e7
+    # The closing barrier of a timed replay is an RCCL collective (tens of microseconds): it must sit OUTSIDE the clock -- the
+    # same 20-step plan timed without a process group, on this same box, within 10 % (round 3 had the barrier inside:
+    # a 0.36 ms region of an exchange-free job would have read 10-25 % of fake scaling loss at N > 1).
+    for k in ("BENCH_FORCE_DIST",):
+        env.pop(k, None)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-regimes",
+                        "--no-update-bench", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr[-2000:]
+    alone = json.loads([l for l in q.stdout.split("\n") if l.strip()][-1])
+    assert abs(d["per_gpu_value"] / alone["per_gpu_value"] - 1.0) < 0.10, (d["per_gpu_value"], alone["per_gpu_value"])
     # (when RCCL prints its banner -- it does with this image's defaults -- it is in p.stderr, not in front of the record)

@@ -246,13 +246,15 @@ struct PersistAdam {
     int kstride;
     unsigned* ctr;                                           // the dim's control word: bit 31 = the group's abort flag
     int spin_log2;
+    int max_iters;                                           // (the launch's arguments the staging needs, by value)
+    float lr, beta1, beta2, eps, log_b1, log_b2;
     AdamCoef kc;
 };
 
 // -> 0: staged; 1: the clique is finished (the block returns); 2: gave up waiting for a copy (the group's abort flag is up)
 template <int K, int H>
 __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
-                                                        int i, int tid, int NT, int st_step, int st_stop, const TrainArgs& a, int n, int iter) {
+                                                        int i, int tid, int NT, int st_step, int st_stop, int n, int iter) {
     using CP = CondPanel<K, H>;
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
@@ -265,7 +267,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     const bool pending = fa.tagged != nullptr;
     int gave_up = 0;
     // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
-    if (st_stop != 0 || st_step + iter >= a.max_iters) return 1;     // block-uniform
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
     for (int base = 0; base < nj; base += 2 * NT) {
         const int ja = base + tid, jb = base + NT + tid;
         const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
@@ -294,7 +296,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
                 }
                 // (the iteration's bias corrections while the loads are under way: ~80 instructions that depend on nothing loaded)
                 if (base == 0 && spins == 0u)
-                    fa.kc = adam_coef(a.adam.lr, a.adam.beta1, a.adam.beta2, a.adam.eps, a.log_b1, a.log_b2, st_step + iter, n);
+                    fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
                 bool ok = true;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {

@@ -792,7 +792,13 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     // The descriptor comes back with one s_load_dwordx16 per iteration (scalar cache), under the staging's own loads.
     int tl_ = threadIdx.x;
     cclique* cp = cp0;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tl_), "+s"(cp));
+    // (PERSIST: the launch's argument block is read through a laundered pointer into the kernel-argument segment, field by
+    //  field where a phase needs it -- ~20 scalars that would otherwise be loaded once and held around the whole loop; with the
+    //  ~45 loop-carried scalars the body spilled 166 SGPRs into VGPR lanes, 350 v_readlane / v_writelane per iteration and wave)
+    typedef const __attribute__((address_space(4))) TrainArgs cargs;
+    cargs* ap_ = (cargs*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + 40);
+    if constexpr (PERSIST) asm volatile("" : "+v"(tl_), "+s"(cp), "+s"(ap_));
+#define AF(f) (PERSIST ? ap_->f : a.f)
     const int lane = tl_ & 63;
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
     // atomics, which count against both memory counters)
@@ -806,21 +812,21 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const int D = cp->D;
     const int slot = (bx << ws) + w;                          // this wave's tile group
     const int p0 = slot << (6 + ts);
-    float B = a.B;
+    float B = AF(B);
     if constexpr (PERSIST) asm volatile("" : "+s"(B));         // (the spline's per-bin constants are functions of B: not to be hoisted into VGPRs)
-    const bool slab = a.slab != 0;
+    const bool slab = AF(slab) != 0;
     const size_t gstride = (size_t)LY::count(D);
-    gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
+    gfloat* ring = G + (slab ? (size_t)AF(n_copies) : (size_t)1) * gstride;
     // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
     // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
     gfloat* const G0 = G;
     gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
-    gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
+    gfloat* alt = Gset1 + (size_t)AF(n_copies) * gstride;
     // chunk-persistent form: two sets of TAGGED copies behind the second state buffer, 2 floats (value, tag) per parameter
     gfloat* const tg0 = alt + 3 * gstride;
-    const size_t tg_set = (size_t)a.n_copies * 2 * gstride;
-    const int par = (a.fused_adam != 0) ? (it & 1) : 0;
-    const bool pending = a.fused_adam != 0 && it > 0;
+    const size_t tg_set = (size_t)AF(n_copies) * 2 * gstride;
+    const int par = (AF(fused_adam) != 0) ? (it & 1) : 0;
+    const bool pending = AF(fused_adam) != 0 && it > 0;
     const gfloat* Gprev = par ? G0 : Gset1;                   // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
@@ -841,7 +847,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
     const int r16 = lane & 15, kq = lane >> 4;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
-    if (it == (PERSIST ? 0 : a.iter_idx)) { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
+    if (it == (PERSIST ? 0 : AF(iter_idx))) { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
 #endif
     // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
     // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
@@ -914,7 +920,10 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 pa_.keep = tiles0 + (size_t)W * wave_floats;
                 pa_.kstride = persist_keep_stride<K, H>(xrows);
                 pa_.ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;
-                pa_.spin_log2 = a.persist_spins;
+                pa_.spin_log2 = AF(persist_spins);
+                pa_.max_iters = AF(max_iters);
+                pa_.lr = AF(adam.lr); pa_.beta1 = AF(adam.beta1); pa_.beta2 = AF(adam.beta2); pa_.eps = AF(adam.eps);
+                pa_.log_b1 = AF(log_b1); pa_.log_b2 = AF(log_b2);
                 if (it == 1 && threadIdx.x == 0) {             // (diagnostic: the XCCs a group's blocks run on, bits 23-30 of the dim's control word)
                     unsigned xcc;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -922,7 +931,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 }
                 pa_.looks = 0u;
                 { float d0_ = lossv, d1_ = r0; PSTAMP(10, d0_, d1_); }       // (loop top -> here: descriptor, pointers)
-                const int rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it);
+                const int rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                 if (rc_ == 1) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
                 { float d0_ = smem[PANEL_BASE], d1_ = (float)rc_; PSTAMP(11, d0_, d1_); }   // the staging: loads, looks, Adam, LDS stores
@@ -1124,8 +1133,31 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
 
     // ---- the gradient of this dim's parameter block ----
     int tl3_ = threadIdx.x;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tl3_));
+    cclique* cpe = cp0;
+    cargs* ape_ = (cargs*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + 40);
+    if constexpr (PERSIST) asm volatile("" : "+v"(tl3_), "+s"(cpe), "+s"(ape_));
     const int lane_e = tl3_ & 63, r16_e = lane_e & 15, kq_e = lane_e >> 4;
+  {
+    // (PERSIST: what the epilogue needs of the clique's descriptor and of the launch's arguments is derived AGAIN here, from
+    //  laundered pointers, under the same names: the versions of the loop's top die in front of the tile loop instead of
+    //  sitting in scalar registers -- i.e. in spill lanes -- across it)
+#undef AF
+#define AF(f) (PERSIST ? ape_->f : a.f)
+    gfloat* G = (gfloat*)cpe->kgrad;
+    gstate* st = (gstate*)cpe->state;
+    const int n = cpe->n;
+    const bool slab = AF(slab) != 0;
+    const size_t gstride = (size_t)LY::count((int)cpe->D);
+    gfloat* ring = G + (slab ? (size_t)AF(n_copies) : (size_t)1) * gstride;
+    gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+    gfloat* const tg0 = Gset1 + (size_t)AF(n_copies) * gstride + 3 * gstride;
+    const size_t tg_set = (size_t)AF(n_copies) * 2 * gstride;
+    const int par = (AF(fused_adam) != 0) ? (it & 1) : 0;
+    if (par) G = Gset1;
+    if (slab) G += (size_t)bx * gstride;
+    gfloat* Gb = G + LY::off(i > 0 ? i : 1);
+    const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;
+    const bool has_tile = (((bx << ws) + w) << (6 + ts)) < n;
     if (slab) {
         // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
         // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
@@ -1176,7 +1208,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             for (int ww = 0; ww < alive; ++ww) bl += tiles0[(size_t)ww * wave_floats + (16 + H) * XS + 64];
             gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
                                                     (((i * members + bx) >> 1) & (LOSS_SLOTS - 1))]
-                                          : (gfloat*)a.loss_sum;
+                                          : (gfloat*)AF(loss_sum);
             if (dst != nullptr) gsink(dst, bl, false);
         }
         for (int e = threadIdx.x; e < nj4 && w < alive; e += 64 * alive) {
@@ -1189,7 +1221,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             // SAME launch -- every word goes out with its tag (the iteration's number in the run) as an 8-byte pair, by
             // agent-scope (sc1) write-through stores that nobody waits for: the readers poll the tags themselves.
             // The chunk's LAST copy is read by the next kernel (nsf_adam_kernel, close_chunk): the plain layout.
-            if (PERSIST && it + 1 < a.persist_iters) {
+            if (PERSIST && it + 1 < AF(persist_iters)) {
                 const float tagf = __uint_as_float((uint32_t)(st_step + it + 1));
                 gfloat* dst = tg0 + (size_t)par * tg_set + (size_t)bx * 2 * gstride + 2 * (size_t)(((i == 0) ? 0 : LY::off(i)) + 4 * e);
                 const f32x4 lo = {sum.x, tagf, sum.y, tagf}, hi = {sum.z, tagf, sum.w, tagf};
@@ -1244,20 +1276,22 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const float tot = slab ? 0.0f : wave_sum(lossv);
     if (lane_e == 0 && has_tile && !slab) {
         gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
-                                                ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
-                                      : (gfloat*)a.loss_sum;
+                                                ((((bx << ws) + w) * 7 + i * 13) & (LOSS_SLOTS - 1))]
+                                      : (gfloat*)AF(loss_sum);
         if (dst != nullptr) gsink(dst, tot, false);
     }
+  }
     if constexpr (!PERSIST) {
         break;
     } else {
-        if (++it >= a.persist_iters) break;                 // (no barrier: the next staging waits for the copies' tags)
+        if (++it >= AF(persist_iters)) break;                 // (no barrier: the next staging waits for the copies' tags)
     }
   }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
     if (STAMP_SEL && lane0 < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane0] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane0];
 #endif
 }
+#undef AF
 
 #undef STAMP_SEL
 #undef STAMP_SLOT

@@ -348,6 +348,120 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     return gave_up ? 2 : 0;
 }
 
+// ---- the same exchange with the Adam update DIVIDED among the group's blocks (contended launches) --------------------------
+// stage_cond_panel_persist lets every block of a (clique, dim) group derive the whole dim's update: right for a lone
+// wave per SIMD (one memory round trip), wasteful when three waves share a SIMD's issue port -- on C3 the 8 blocks x 256
+// threads of a group each load 16 tagged pairs and run Adam twice, 25 MB of L2 reads and ~10 % of the launch's VALU
+// instructions per iteration, and the staging takes 7.5 k of a wave's 27.6 k cycles.  Here block b owns the slice
+// [b S, (b + 1) S) of the dim's parameters (S = ceil(nj / members) <= 256: one thread per parameter, the first waves of the
+// block): it alone loads that slice's copies, keeps its m, v, theta in LDS, applies Adam (the same function on the same sums:
+// the same bits), records the slice in the clique's buffers and PUBLISHES the new theta as (value, tag) pairs in a
+// per-clique exchange buffer; then every thread of every block fetches the two parameters it stages into the panel from
+// that buffer, again until the tags are this iteration's.  Two dependent round trips instead of one, an eighth of the
+// loads and of the arithmetic.  The exchange buffer needs no second copy: a block can publish theta of iteration k + 1
+// only after it has seen everybody's gradient copy of iteration k, which a block writes after it has read theta of iteration k.
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist_split(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                              int i, int tid, int NT, int st_step, int st_stop, int n, int iter, int bx,
+                                                              __attribute__((address_space(1))) float* xch) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    typedef const __attribute__((address_space(1))) unsigned long long* gq;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    const int S = (nj + fa.copies - 1) / fa.copies;                  // slice of this block: parameters [bx S, min((bx + 1) S, nj))
+    const uint32_t tag2 = fa.tag + 1u;                               // the tag of this iteration's theta (= state->step + it + 1)
+    int gave_up = 0;
+    auto look_again = [&](unsigned& spins) -> bool {                 // -> true: give up
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+#if defined(NSF_STAMPS)
+        ++fa.looks;
+#endif
+        if ((spins & 63u) == 0u) {
+            const bool timeout = spins > (1u << fa.spin_log2);
+            if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) return true;
+        }
+        return false;
+    };
+    // one thread per parameter of the slice (S <= 110 for a group of eight blocks: the block's first waves; a clique of few
+    // particles has few blocks and long slices: the threads go round)
+    for (int q = tid; q < S && bx * S + q < nj; q += NT) {
+        const int ia = j0 + bx * S + q;
+        if (!pending) {
+            // the chunk's first iteration: nothing to apply; the owners pick up their slice's state from the clique's arrays
+            fa.keep[q] = t_src[ia];
+            fa.keep[fa.kstride + q] = fa.m_src[ia];
+            fa.keep[2 * fa.kstride + q] = fa.v_src[ia];
+            continue;
+        }
+        float ta = fa.keep[q], ma = fa.keep[fa.kstride + q], va = fa.keep[2 * fa.kstride + q];
+        float ga[8];
+        unsigned spins = 0;
+        for (;;) {
+            unsigned long long qa[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + (size_t)(c < fa.copies ? c : 0) * fa.cstride + 2 * (size_t)ia),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (spins == 0u && q == tid) fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag;
+                ga[c] = __uint_as_float((uint32_t)qa[c]);
+            }
+            if (ok) break;
+            if (gave_up || look_again(spins)) { gave_up = 1; break; }
+        }
+        FusedAdam sum_order;
+        sum_order.copies = fa.copies;
+        adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+        fa.keep[q] = ta; fa.keep[fa.kstride + q] = ma; fa.keep[2 * fa.kstride + q] = va;
+        fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va;      // (every block records ITS slice: read by later kernels)
+        const unsigned long long pub = ((unsigned long long)tag2 << 32) | (unsigned long long)__float_as_uint(ta);
+        __hip_atomic_store((unsigned long long*)(xch + 2 * (size_t)ia), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int base = 0; base < nj; base += 2 * NT) {
+        const int ja = base + tid, jb = base + NT + tid;
+        const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
+        const int ia = j0 + ca, ib = j0 + cb;
+        uint32_t da = map[ca], db = map[cb];
+        float ta, tb;
+        if (!pending) {
+            ta = t_src[ia]; tb = t_src[ib];
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(da), "+v"(db));
+        } else {
+            unsigned spins = 0;
+            for (;;) {
+                const unsigned long long qa = __hip_atomic_load((const unsigned long long*)(gq)(xch + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long qb = __hip_atomic_load((const unsigned long long*)(gq)(xch + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ta = __uint_as_float((uint32_t)qa); tb = __uint_as_float((uint32_t)qb);
+                if ((uint32_t)(qa >> 32) == tag2 && (uint32_t)(qb >> 32) == tag2) break;
+                if (gave_up || look_again(spins)) { gave_up = 1; break; }
+            }
+        }
+        if (ja < nj) { lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta; }
+        if (jb < nj) { lds0[db & 0x7fffu] = (db & PANEL_SCALED) ? tb * kTanhScale : tb; lds0[db >> 16] = tb; }
+    }
+    if (i > 0 && !pending) {
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    return gave_up ? 2 : 0;
+}
+
 // acc[g * SPLIT + (q % SPLIT)][u] += sum over the quads q < NK/4 of  A[4g + u][4q + v] * b[4q + v]
 // for the NG output groups g; `rows` = the panel matrix at this lane's row (base + (lane & 3) * stride).
 // Software pipeline: the reads of slab s+1 (SG groups x one quad, 16 bytes each) are issued before the MFMAs of slab s,

@@ -599,7 +599,7 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     // + the fused-Adam launches' second set of gradient copies (64-particle tiles) and second state buffer (theta | m | v)
     const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
     // + the chunk-persistent form's two sets of TAGGED copies (8 blocks of 4 waves at most, 2 floats per parameter)
-    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 32) * kcount(D, K, H) : 0;
+    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 32 + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && H == 8 && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
     // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)

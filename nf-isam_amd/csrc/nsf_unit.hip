@@ -931,7 +931,18 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 }
                 pa_.looks = 0u;
                 { float d0_ = lossv, d1_ = r0; PSTAMP(10, d0_, d1_); }       // (loop top -> here: descriptor, pointers)
-                const int rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                int rc_;
+                if (AF(persist_split) != 0) {
+                    // every block records its slice of the state (fa.*_dst are the first block's otherwise)
+                    const bool to_own = pending && par == 0;
+                    pa_.t_dst = to_own ? (gfloat*)own_t : alt;
+                    pa_.m_dst = to_own ? (gfloat*)own_m : alt + gstride;
+                    pa_.v_dst = to_own ? (gfloat*)own_v : alt + 2 * gstride;
+                    rc_ = stage_cond_panel_persist_split<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it,
+                                                               bx, tg0 + 2 * tg_set);
+                } else {
+                    rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                }
                 if (rc_ == 1) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
                 { float d0_ = smem[PANEL_BASE], d1_ = (float)rc_; PSTAMP(11, d0_, d1_); }   // the staging: loads, looks, Adam, LDS stores
@@ -2832,6 +2843,13 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int octets = (a.groups + 7) / 8;
         const int gz = (octets - ch + nch - 1) / nch;          // octets ch, ch + nch, ...
         if (nch > 255 || ch < 0 || ch >= nch) return NFISAM_ERR_ARG;
+        {   // contended launches (more than one block per CU: several waves share a SIMD) divide the Adam update among a group's blocks
+            static const char* se = getenv("NFISAM_PERSIST_SPLIT");
+            long blocks = 0;
+            const nfisam_clique* hc = (a.cliques == nullptr) ? &a.single : a.host_cliques;
+            for (int c = 0; c < n_cliques && hc != nullptr; ++c) blocks += (long)hc[c].D * ((hc[c].n + 4 * TILE - 1) / (4 * TILE));
+            a.persist_split = (se != nullptr) ? (se[0] == '1') : (blocks > 256);
+        }
         static const int spin_log2 = getenv("NFISAM_PERSIST_SPINS") != nullptr ? atoi(getenv("NFISAM_PERSIST_SPINS")) : 22;           // (test knob)
         a.persist_spins = spin_log2 < 1 ? 1 : (spin_log2 > 30 ? 30 : spin_log2);
         static const bool drop = getenv("NFISAM_PERSIST_DROP") != nullptr && getenv("NFISAM_PERSIST_DROP")[0] == '1';                  // (test knob)

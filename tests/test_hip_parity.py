@@ -457,7 +457,7 @@ def test_large_launch_uses_atomics_and_still_matches_oracle(n):
     ring = 128 * 64 + 64      # per-iteration loss sums behind the gradient copies (+ 64 reserved words)
     assert nh.lib().nfisam_nsf_grad_workspace_count(n, D, K, H, L) == nh.kparam_count(D, K, H) + ring
     # <= 32 tiles of 64 particles: room for the fused-Adam launches' second set of copies and second (theta | m | v)
-    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == (63 + 32 + 3 + 32) * nh.kparam_count(D, K, H) + ring
+    assert nh.lib().nfisam_nsf_grad_workspace_count(2000, D, K, H, L) == (63 + 32 + 3 + 32 + 2) * nh.kparam_count(D, K, H) + ring
     assert nh.lib().nfisam_nsf_grad_workspace_count(6000, D, K, H, L) == 94 * nh.kparam_count(D, K, H) + ring
     blob, x = make_problem(n, D, K, H, L, seed=8, spread=1.0)
     tb = nh.TrainBatch([dev(x)], [kpack(blob, D, K, H, L)], K, H, B, L, lr=0.02, max_iters=5, early_stop=False)
@@ -995,7 +995,7 @@ np.savez(sys.argv[1], **out)
 '''
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(700)
 def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tmp_path):
     """The chunk-persistent form of the dim-major kernel (a chunk's iterations in ONE launch per chain, the blocks of a
     (clique, dim) group meeting at a barrier per iteration; default for launches that are resident at once) against
@@ -1013,18 +1013,24 @@ def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tm
     script.write_text(PERSIST_WORKER % dict(root=root))
     res = {}
     for knob, env in (("1", dict(NFISAM_PERSIST="1")), ("0", dict(NFISAM_PERSIST="0")),
-                      ("scatter", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_SCATTER="1"))):
+                      ("scatter", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_SCATTER="1")),
+                      ("split", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_SPLIT="1")),
+                      ("whole", dict(NFISAM_PERSIST="1", NFISAM_PERSIST_SPLIT="0", NFISAM_PERSIST_SCATTER="1"))):
         out = str(tmp_path / ("persist_%s.npz" % knob))
         p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         res[knob] = dict(np.load(out))
-    assert res["1"].keys() == res["0"].keys() == res["scatter"].keys()
+    assert res["1"].keys() == res["0"].keys() == res["scatter"].keys() == res["split"].keys() == res["whole"].keys()
     for k in res["1"]:
         if k.startswith("span_"):
             continue
         np.testing.assert_array_equal(res["1"][k], res["0"][k], err_msg=k)
         np.testing.assert_array_equal(res["scatter"][k], res["0"][k], err_msg="scattered: " + k)
+        # the two ways of staging the update -- every block derives the whole dim's (default for launches of at most one block
+        # per CU) / every block derives its slice and publishes it (default beyond) -- forced onto every shape:
+        np.testing.assert_array_equal(res["split"][k], res["0"][k], err_msg="update divided among the blocks: " + k)
+        np.testing.assert_array_equal(res["whole"][k], res["0"][k], err_msg="whole update per block, scattered: " + k)
     spans = {k[5:]: (int(res["1"][k]), int(res["0"][k]), int(res["scatter"][k])) for k in res["1"] if k.startswith("span_")}
     print("XCDs per (clique, dim) group: persistent / one launch per iteration / scattered", spans)
     for name, (normal, plain, scattered) in spans.items():

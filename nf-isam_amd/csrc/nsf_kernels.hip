@@ -702,8 +702,24 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
     long blocks = 0;
     for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
-    const NsfUnitOps* ops = find_ops(K, H);
-    const long places = ops != nullptr ? ops->persist_places(max_D) : 0;
+    // (asked once per (K, H, clique width, device): the query costs a device-properties call, and replica schedulers
+    //  create plans by the hundred)
+    static std::mutex mu;
+    static std::vector<std::pair<long, long>> cache;             // key -> places
+    int devn = 0;
+    (void)hipGetDevice(&devn);
+    const long key = ((long)devn << 40) | ((long)K << 32) | ((long)H << 24) | (long)max_D;
+    long places = -1;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto& kv : cache) if (kv.first == key) places = kv.second;
+    }
+    if (places < 0) {
+        const NsfUnitOps* ops = find_ops(K, H);
+        places = ops != nullptr ? ops->persist_places(max_D) : 0;
+        std::lock_guard<std::mutex> lk(mu);
+        cache.emplace_back(key, places);
+    }
     long limit = places - places / 8;
     if (const char* e = getenv("NFISAM_PERSIST_BLOCKS")) limit = atol(e);    // (measurement aid)
     return blocks <= limit;

@@ -682,6 +682,496 @@ constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);  
 #ifndef NSF_PERSIST_WAVES
 #define NSF_PERSIST_WAVES 3      // resident waves per SIMD the chunk-persistent instantiation is compiled for (round 3: 2 -- it spilled at 3)
 #endif
+// ---- the one-launch-per-iteration form: ROUND 3'S KERNEL, VERBATIM ---------------------------------------------------------
+// Round 4 rebuilt the chunk-persistent form (nsf_train1_kernel below: loop roots laundered per phase, flag-in-data exchange,
+// divided update).  The same source compiled for ONE pass came out 2-5 % slower than round 3's kernel (167 instead of 163
+// VGPRs, another schedule: C3 as one launch 14.6 vs 13.95 us, the 64-clique batch 86.0 vs 84.9, scripts/ab.py against a
+// build of round 3's tree on one box), so the launches that run one iteration per launch -- every batch too large to be
+// resident at once, the replicas' conveyor, the eager tail of a run -- keep round 3's text as it was.
+template <int K, int H>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(H == 16 ? 2 : 3, 8)))
+nsf_train1_plain_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
+                  int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
+    constexpr bool PERSIST = false;                           // (the text of round 3's kernel: its persistent branches compile away)
+    using LY = Layout<K, H>;
+    using CP = CondPanel<K, H>;
+    constexpr int PoP = LY::PoP;
+    constexpr int NT = (PoP + 15) / 16;
+    constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
+    static_assert((H == 16 || H == 8 || H == 4) && NT <= 4, "H <= 8: ga2|ga1 share one 16-row operand tile; H = 16: one tile each, bias chains");
+    constexpr bool WIDE_H = (H == 16);                        // no spare column for the bias in [h | 1]: db2 / db1 come from chains against a constant 1
+    constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int bx = blockIdx.y;                                // tile group inside the (clique, dim)
+    // (chains: an iteration may be split into n launches on parallel graph branches, see nfisam_nsf_train_plan_create;
+    //  launch c takes the octets of groups c, c + n, ...)
+    const int grp = blockIdx.x + 8 * (blockIdx.z * ((h_shifts >> 24) & 0xff) + ((h_shifts >> 16) & 0xff));
+    if (grp >= h_groups) return;                              // padding of the group count to a multiple of 8
+    const int gq = h_magic != 0u ? (int)__umulhi((unsigned)grp, h_magic) : grp;    // grp / cliques
+    const int by = grp - gq * h_grid_cliques;                 // clique
+    const int i = h_xrows - 1 - gq;                           // this block's dim: the long ones first
+    typedef const __attribute__((address_space(4))) nfisam_clique cclique;
+    typedef const __attribute__((address_space(4))) char cchar;
+    cclique* cp = (h_cliques != nullptr)
+                      ? (cclique*)(h_cliques + by)
+                      : (cclique*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + TRAIN1_FEW_OFFSET) + by;
+    (void)few;
+    // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
+    // atomics, which count against both memory counters)
+    const gfloat* x = (const gfloat*)cp->x;
+    const float* kparams = cp->kparams;
+    gfloat* G = (gfloat*)cp->kgrad;
+    const gfloat* own_m = (const gfloat*)cp->adam_m;
+    const gfloat* own_v = (const gfloat*)cp->adam_v;
+    typedef __attribute__((address_space(1))) nfisam_train_state gstate;
+    gstate* st = (gstate*)cp->state;
+    const int n = cp->n;
+    const int D = cp->D;
+    if (i >= D) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ws = (h_shifts >> 8) & 0xff, ts = h_shifts & 0xff;
+    const int W = 1 << ws, T = 1 << ts;
+    const int slot = (bx << ws) + w;                          // this wave's tile group
+    const int p0 = slot << (6 + ts);
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+    STAMP(10);
+#endif
+    int st_stop = 0, st_step = 0;
+    if (st != nullptr) {
+        st_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float B = a.B;
+    const bool slab = a.slab != 0;
+    const size_t gstride = (size_t)LY::count(D);
+    gfloat* ring = G + (slab ? (size_t)a.n_copies : (size_t)1) * gstride;
+    // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
+    // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
+    gfloat* const G0 = G;
+    gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+    gfloat* alt = Gset1 + (size_t)a.n_copies * gstride;
+    int it = PERSIST ? 0 : a.iter_idx;                        // iteration inside the chunk
+    int par = (a.fused_adam != 0) ? (it & 1) : 0;
+    bool pending = a.fused_adam != 0 && it > 0;
+    const gfloat* Gprev = par ? G0 : Gset1;                   // copy 0 of the previous iteration
+    if (par) G = Gset1;
+    if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
+    const int xrows = h_xrows;                                // rows of a particle tile in LDS (largest D of the launch)
+    const float* pan = smem + PANEL_BASE;                     // the block's conditioner panel (nsf_cond_mfma.h)
+    // a row of ones for the bias / unused columns of the MFMA operands: a lane that must supply 1.0 READS it from here
+    // (its operand pointer is selected once per tile) instead of selecting 1.0 over a loaded value at every k-step.
+    // Every wave writes the same 68 words; its own LDS operations are in order, so it reads what it wrote.
+    float* ones = smem + PANEL_BASE + CP::floats(xrows);
+    float* tiles0 = ones + ONES_ROW;
+    const int wave_floats = train1_wave_floats(xrows, H);
+    // fixed-size rows first: their offsets from the wave's base are immediates of the LDS instructions (fewer address registers)
+    float* stg = tiles0 + (size_t)w * wave_floats;            // [16][XS] staging rows
+    float* hrow = stg + 16 * XS;                              // [H][XS] h1 of the tile (an operand of the last gradient GEMM)
+    const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
+    float* xt = hrow + H * XS;                                // [xrows][XS] particle tile, dimension-major
+    float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
+    const int r16 = lane & 15, kq = lane >> 4;
+    ones[lane] = 1.0f;
+    if (lane < ONES_ROW - 64) ones[64 + lane] = 1.0f;
+    const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
+    gfloat* Gb = G + LY::off(i > 0 ? i : 1);
+    const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
+    if (PERSIST && bx >= members) return;
+    const bool has_tile = p0 < n;
+
+    STAMP_DECL
+    STAMP(0);
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+    if (lane < 16) smem[PANEL_BASE - 64 + w * 16 + lane] = 0.0f;
+    { float d0_ = 0.f, d1_ = 0.f; PSTAMP(0, d0_, d1_); }
+#endif
+    f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cb2[NT], cb1 = {0.f, 0.f, 0.f, 0.f};                 // WIDE_H only
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float r0 = 0.0f, lossv = 0.0f;
+
+    // tile loader: every lane reads the columns 0..i of its own particle row (16-byte loads at the row's 4-byte
+    // alignment; the conditioner's inputs and x_i itself) and drops them into the dimension-major LDS tile: no index
+    // arithmetic, no column the dim does not need.  Rows beyond n re-read row n-1 (masked out of loss and gradient).
+    // Fetch (global -> registers) and store (registers -> LDS) are separate so that the first tile's loads are in
+    // flight while the block stages its weight panel.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto fetch = [&](int pt, int c0, float (&xr)[16]) {
+        const int pr = (pt + lane < n) ? pt + lane : n - 1;
+        const gfloat* row = x + (size_t)pr * D;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k <= i) {                                 // wave-uniform
+                if (k + 3 < D) {
+                    const f32x4u u = *(const __attribute__((address_space(1))) f32x4u*)(row + k);
+                    v = f32x4{u.x, u.y, u.z, u.w};
+                } else {
+                    v.x = row[k];
+                    if (k + 1 < D) v.y = row[k + 1];
+                    if (k + 2 < D) v.z = row[k + 2];
+                }
+            }
+            xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+        }
+    };
+    auto store = [&](int c0, const float (&xr)[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+    };
+    auto load_tile = [&](int pt, int c_first) {
+        for (int c0 = c_first; c0 <= i; c0 += 16) {
+            float xr[16];
+            fetch(pt, c0, xr);
+            store(c0, xr);
+        }
+    };
+  for (;;) {                                                  // (PERSIST: the iterations of the chunk; else one pass)
+    {
+        // the one workgroup barrier in front of the tile loop: the block's waves share the (clique, dim) and so the panel
+        float xr[16];
+        const bool first = !PERSIST || it == 0;               // the particle tile stays in LDS between the iterations of a chunk
+        if (!PERSIST && p0 < n) fetch(p0, 0, xr);               // (PERSIST: once per chunk, after the staging: fewer live registers)
+        {
+            FusedAdam fa;
+            fa.grads = pending ? Gprev : nullptr;
+            fa.gstride = gstride;
+            fa.copies = members;
+            // state before the pending update: the buffer of the previous iteration's parity (even: the clique's own)
+            const gfloat* own_t = (const gfloat*)kparams;
+            const bool src_alt = pending && par == 0;
+            const gfloat* t_src = src_alt ? alt : own_t;
+            fa.m_src = src_alt ? alt + gstride : own_m;
+            fa.v_src = src_alt ? alt + 2 * gstride : own_v;
+            const bool writer = pending && bx == 0;
+            fa.t_dst = writer ? (src_alt ? (gfloat*)own_t : alt) : nullptr;
+            fa.m_dst = writer ? (src_alt ? (gfloat*)own_m : alt + gstride) : nullptr;
+            fa.v_dst = writer ? (src_alt ? (gfloat*)own_v : alt + 2 * gstride) : nullptr;
+            if (!stage_cond_panel<K, H, PERSIST>(smem, (const float*)t_src, fa, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, a, n, it)) return;
+            __syncthreads();
+        }
+        if (!PERSIST && p0 >= n) return;
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(11);
+#endif
+        if (first && has_tile) {
+            if (PERSIST) fetch(p0, 0, xr);
+            store(0, xr);
+            load_tile(p0, 16);
+        }
+    }
+
+    if constexpr (PERSIST) {                                  // (zeroed HERE, not at the loop's end: nothing of them is live across the staging)
+        lossv = 0.0f; r0 = 0.0f;
+        c1 = f32x4{0.f, 0.f, 0.f, 0.f}; c0 = c1; cb1 = c1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
+    }
+    for (int tt = 0; tt < T && has_tile; ++tt) {
+        const int pt = p0 + tt * TILE;
+        if (pt >= n) break;
+        PSTAMP(1, lossv, r0);
+        if (tt > 0) load_tile(pt, 0);
+        wave_lds_sync();
+        PSTAMP(2, lossv, r0);
+        const bool valid = pt + lane < n;
+        float h1[H], h2[H], th[PoP], gth[PoP];
+        if (i == 0) {
+#pragma unroll
+            for (int o = 0; o < PoP; o += 4) {
+                const cm_f32x4 v4 = *(const cm_f32x4*)(pan + o);
+                th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
+            }
+        } else {
+            cond_forward_mfma<K, H>(pan, i, CP::s0_of(i), xt, XS, lane, lane, h1, h2, th);
+            // operands of the gradient GEMMs, parked while the lanes are busy with the spline
+            lds_rows_store<0, H, 0, H>(stg_lane, h2);
+            lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
+        }
+        PSTAMP(3, th[0], th[PoP - 1]);
+        SplineT<K> S;
+        float z, lad;
+        spline_train_fwd<K, PoP>(xt[i * XS + lane], th, B, S, z, lad);
+        PSTAMP(4, z, lad);
+        if (valid) lossv += 0.5f * z * z - lad;
+        spline_train_bwd<K, PoP>(S, B, valid ? z : 0.0f, valid ? -1.0f : 0.0f, gth);
+        PSTAMP(5, gth[0], gth[LY::HP]);
+        if (i == 0) {   // init_param: plain sum over particles of gth
+            constexpr int N0 = (PoP <= 32) ? 32 : 64;
+            float v[N0];
+#pragma unroll
+            for (int t = 0; t < N0; ++t) v[t] = (t < PoP) ? gth[t] : 0.0f;
+            r0 += butterfly<N0>(v, lane);
+            wave_lds_sync();                                    // the tile is overwritten by the next iteration's loads
+            continue;
+        }
+        // ---- per-particle back-propagation through the conditioner (4x4x1 MFMA chains, nsf_cond_mfma.h) ----
+        float ga2[H], ga1[H];
+        cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
+        PSTAMP(6, ga1[0], ga2[H - 1]);
+        // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
+        //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
+        // The 16 staging rows carry four generations of operands: [h2 | h1], gth tile 0, gth tile 1, [ga2 | ga1].  A
+        // generation is read into registers completely, then the NEXT one is written before this one's MFMAs are
+        // issued: the LDS writes complete under the 16 x 32 MFMA cycles and only the reads' round trip stays exposed.
+        const float* pa = stg + r16 * XS + kq;
+        float breg[NS], areg[NS];
+        {
+            wave_lds_sync();
+            const float* pah = ((r16 < H) ? stg + r16 * XS : ones) + kq;
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) breg[s4] = pah[4 * s4];
+            wave_lds_sync();
+        }
+        PSTAMP(7, breg[0], breg[NS - 1]);
+        {   // phase A: dW2t | db2 = [h2, 1]^T (x) gth ;  phase B: dW1t | db1 = [h1,1]^T (x) ga2 ;  dW0t | db0 = [x,1]^T (x) ga1
+            lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 1; t <= NT; ++t) {
+                if (t == 1 && NT > 1) lds_rows_store<0, 16, 16, PoP>(stg_lane, gth);
+                if (t == 2 && NT > 2) lds_rows_store<0, 16, 32, PoP>(stg_lane, gth);
+                if (t == 3 && NT > 3) lds_rows_store<0, 16, 48, PoP>(stg_lane, gth);
+                if (t == NT) {
+                    if constexpr (WIDE_H) {
+                        lds_rows_store<0, 16, 0, H>(stg_lane, ga2);
+                    } else {
+                        lds_rows_store<0, H, 0, H>(stg_lane, ga2);
+                        lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    cacc[t - 1] = mfma4(areg[s4], breg[s4], cacc[t - 1]);
+                    if constexpr (WIDE_H) cb2[t - 1] = mfma4(areg[s4], 1.0f, cb2[t - 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wave_lds_sync();
+                if (t < NT) {
+#pragma unroll
+                    for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+                    wave_lds_sync();
+                }
+            }
+            if constexpr (WIDE_H) {
+                // ga2 (16 rows) x [h1]: dW1t, and x 1: db1; then ga1 (16 rows) x [x_0 .. x_{i-1} | 1]: dW0t | db0
+                const float* pb1 = hrow + r16 * XS + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) areg[s4] = pa[4 * s4];
+                wave_lds_sync();
+                lds_rows_store<0, 16, 0, H>(stg_lane, ga1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    c1 = mfma4(areg[s4], pb1[4 * s4], c1);
+                    cb1 = mfma4(areg[s4], 1.0f, cb1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wave_lds_sync();
+                const float* pb0 = ((r16 < i) ? xt + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c0 = mfma4(areg[s4], pb0[4 * s4], c0);
+                }
+            } else if (merged) {
+                // i <= 16 - (H + 1): the columns [h1 (H) | 1 | x_0 .. x_{i-1}] of BOTH products fit one 16-column operand
+                // (they share the bias column): one MFMA chain instead of two.  Rows 0..H-1 (ga2) x columns 0..H give
+                // dW1t | db1, rows H.. (ga1) x columns H.. give db0 | dW0t; the cross terms are not used.
+                const int kx = r16 - (H + 1);
+                const bool one = (r16 == H) || kx >= i;
+                const float* pbm = (one ? ones : ((r16 < H) ? hrow + r16 * XS : xt + kx * XS)) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c1 = mfma4(areg[s4], pbm[4 * s4], c1);
+                }
+            } else {
+                const float* pb0 = ((r16 < i) ? xt + r16 * XS : ones) + kq;     // input columns 0..15 (column i = bias)
+                const float* pb1 = ((r16 < H) ? hrow + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    areg[s4] = pa[4 * s4];
+                    c1 = mfma4(areg[s4], pb1[4 * s4], c1);
+                    c0 = mfma4(areg[s4], pb0[4 * s4], c0);
+                }
+            }
+            for (int ct = 1; ct * 16 <= i; ++ct) {              // D > 16: further column tiles add into the wave's own copy
+                const int cab = ct * 16 + r16;
+                const float* pb0 = ((cab < i) ? xt + cab * XS : ones) + kq;
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) cx = mfma4(areg[s4], pb0[4 * s4], cx);
+                if ((WIDE_H || (kq >= QH && kq < 2 * QH)) && cab <= i) {
+                    float* dst = &ctacc[(cab - 16) * H + 4 * (WIDE_H ? kq : kq - QH)];
+                    if (slab) {
+                        if (tt > 0) { cx.x += dst[0]; cx.y += dst[1]; cx.z += dst[2]; cx.w += dst[3]; }
+                        dst[0] = cx.x; dst[1] = cx.y; dst[2] = cx.z; dst[3] = cx.w;
+                    } else {
+                        gsink4(&Gb[cab * H + 4 * (WIDE_H ? kq : kq - QH)], cx, false);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        PSTAMP(8, c1.x, cacc[0].x);
+    }
+
+    // ---- the gradient of this dim's parameter block ----
+    if (slab) {
+        // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
+        // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
+        // and write the copy with consecutive 16-byte stores.
+        float* frag = stg;                                     // 24 rows: room for every dim's block
+        if (!has_tile) {
+            // (PERSIST: a wave without particles stays for the staging of the following iterations)
+        } else if (i == 0) {
+            if (lane < PoP) frag[lane] = r0;
+        } else {
+            float* fw = frag + LY::oW2(i);
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[r16 * PoP + 16 * t + 4 * kq] = cacc[t];
+            }
+            if (kq < QH && r16 <= H) *(f32x4*)&(frag + LY::oW1(i))[r16 * H + 4 * kq] = c1;
+            if constexpr (WIDE_H) {                           // the bias rows (every column of a bias chain holds the same sums) + dW0t | db0
+                if (r16 == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (16 * t + 4 * kq + 3 < PoP) *(f32x4*)&fw[H * PoP + 16 * t + 4 * kq] = cb2[t];
+                    *(f32x4*)&(frag + LY::oW1(i))[H * H + 4 * kq] = cb1;
+                }
+                if (r16 <= i) *(f32x4*)&frag[r16 * H + 4 * kq] = c0;
+            } else if (merged) {                                     // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
+                const int k0 = (r16 == H) ? i : r16 - (H + 1);
+                if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) *(f32x4*)&frag[k0 * H + 4 * (kq - QH)] = c1;
+            } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
+                *(f32x4*)&frag[r16 * H + 4 * (kq - QH)] = c0;
+            }
+            for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
+        }
+        // the block's loss: the waves' sums added in wave order by ONE thread (below), then one atomic per block into a ring
+        // slot shared by at most two blocks of the clique while D x blocks <= 128 -- a sum of two floats does not depend on
+        // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
+        {
+            const float wtot = wave_sum(lossv);
+            if (lane == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
+        }
+        __syncthreads();                                      // waves without a tile left before the panel barrier
+        const int waves_c = (n + (TILE << ts) - 1) >> (6 + ts);
+        const int alive = (waves_c - (bx << ws) < W) ? waves_c - (bx << ws) : W;
+        const int nj4 = ((i == 0) ? PoP : LY::block(i)) >> 2;
+        gvf4_t* Gc = (gvf4_t*)(G + ((i == 0) ? 0 : LY::off(i)));
+        if (threadIdx.x == 64 * (alive - 1)) {                 // (the block's LAST wave with a tile: it has the fewest fragments to add below)
+            float bl = 0.0f;
+            for (int ww = 0; ww < alive; ++ww) bl += tiles0[(size_t)ww * wave_floats + (16 + H) * XS + 64];
+            gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                    (((i * members + bx) >> 1) & (LOSS_SLOTS - 1))]
+                                          : (gfloat*)a.loss_sum;
+            if (dst != nullptr) gsink(dst, bl, false);
+        }
+        for (int e = threadIdx.x; e < nj4 && w < alive; e += 64 * alive) {
+            f32x4 sum = *(const f32x4*)&tiles0[4 * e];
+            for (int ww = 1; ww < alive; ++ww) {
+                const f32x4 o = *(const f32x4*)&tiles0[(size_t)ww * wave_floats + 4 * e];
+                sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+            }
+            Gc[e] = sum;
+        }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 2
+        STAMP(12);
+#endif
+    } else if (i == 0) {
+        if (lane < PoP) gsink(&G[lane], r0, false);
+    } else {
+        gfloat* Gw = Gb + LY::oW2(i);
+        {
+            // atomics: (H+1) x PoP floats through LDS in two halves of the staging tile, flat order (consecutive addresses)
+            constexpr int TOT = (WIDE_H ? H : H + 1) * PoP;     // (H = 16: the bias row comes from its own chain, below)
+            static_assert(TOT <= 16 * XS, "the transposed dW2 block fits the staging rows");
+            if (r16 <= H) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) {
+                        float* d = &stg[r16 * PoP + 16 * t + 4 * kq];
+                        d[0] = cacc[t].x; d[1] = cacc[t].y; d[2] = cacc[t].z; d[3] = cacc[t].w;
+                    }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < (TOT + 63) / 64; ++c) {
+                const int f = c * 64 + lane;
+                if (f < TOT) gsink(&Gw[f], stg[f], false);
+            }
+        }
+        if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(i))[r16 * H + 4 * kq], c1, false);
+        if constexpr (WIDE_H) {
+            if (r16 == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw[H * PoP + 16 * t + 4 * kq], cb2[t], false);
+                gsink4(&(Gb + LY::oW1(i))[H * H + 4 * kq], cb1, false);
+            }
+            if (r16 <= i) gsink4(&Gb[r16 * H + 4 * kq], c0, false);
+        } else if (merged) {
+            const int k0 = (r16 == H) ? i : r16 - (H + 1);
+            if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < i))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1, false);
+        } else if (kq >= QH && kq < 2 * QH && r16 <= i) {
+            gsink4(&Gb[r16 * H + 4 * (kq - QH)], c0, false);
+        }
+    }
+    PSTAMP(9, lossv, r0);
+    const float tot = slab ? 0.0f : wave_sum(lossv);
+    if (lane == 0 && has_tile && !slab) {
+        gfloat* dst = (st != nullptr) ? &ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS +
+                                                ((slot * 7 + i * 13) & (LOSS_SLOTS - 1))]
+                                      : (gfloat*)a.loss_sum;
+        if (dst != nullptr) gsink(dst, tot, false);
+    }
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (++it >= a.persist_iters) break;
+        // ---- the group's blocks meet: this block's copy is in L2 (vmcnt: its stores are acknowledged), then everybody's is ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;       // zero at the start of every chunk (nsf_bookkeep_kernel)
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(it * members);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {                   // a member that never became resident: give up loudly (non-finite loss -> domain error)
+                    if (st != nullptr) ring[((st_step + it) & (LOSS_RING - 1)) * LOSS_SLOTS] = __builtin_nanf("");
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        par = it & 1;
+        pending = a.fused_adam != 0;
+        Gprev = par ? G0 : Gset1;
+        G = (par ? Gset1 : G0) + (slab ? (size_t)bx * gstride : (size_t)0);
+        Gb = G + LY::off(i > 0 ? i : 1);
+    }
+  }
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
+    if (STAMP_SEL && lane < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane];
+#endif
+}
+
+
 // chunk-persistent form: floats of each of the three arrays (theta | m | v of the block's dim) kept in LDS behind the waves' tiles
 template <int K, int H>
 __host__ __device__ constexpr int persist_keep_stride(int max_D) {
@@ -2825,7 +3315,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
         const bool persist = a.persist_iters > 0;
         if (persist && (T != 1 || !a.slab || !a.fused_adam || a.L != 1 || max_D > FUSED_COUNTERS)) return NFISAM_ERR_ARG;
-        rc = persist ? set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch) : set_lds(nsf_train1_kernel<KK, HH>, lds_launch);
+        rc = persist ? set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch) : set_lds(nsf_train1_plain_kernel<KK, HH>, lds_launch);
         if (rc) return rc;
         // few cliques: their descriptors travel in the kernel arguments (host copy: the plan's, or the single one)
         static_assert(offsetof(Train1Head, shifts) == 32 && sizeof(Train1Head) == 40, "scalar head of the kernel arguments");
@@ -2859,7 +3349,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
                                dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
                                a.t_shift | (scatter ? 0x80 : 0) | (drop ? 0x40 : 0) | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
         else if (gz > 0)
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+            hipLaunchKernelGGL((nsf_train1_plain_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
                                a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
                                a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
         HIP_TRY(hipGetLastError());

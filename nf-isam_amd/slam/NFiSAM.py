@@ -75,6 +75,9 @@ class NFiSAMArgs(SolverArgs):
         self.tl_cnt = 0
 
 
+_CIRC_FLAGS = {}     # (device, circular flags as bytes) -> uint8 device tensor, immutable (NormalizingFlowModelWithSeparator._norm_dev)
+
+
 class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler):
     """Joint density of a clique's (observation | separator | frontal) columns as a normalizing
     flow with input normalisation (reference: NFiSAM.py:68-199)."""
@@ -96,9 +99,23 @@ class NormalizingFlowModelWithSeparator(NormalizingFlowModel, ConditionalSampler
     # ---- device copies of the normalisation constants --------------------------------------
     def _norm_dev(self, device):
         if self._norm_cache is None or self._norm_cache[0] != str(device):
-            mean = torch.as_tensor(self.samples_mean, dtype=torch.float32).to(device).contiguous()
-            std = torch.as_tensor(self.samples_std, dtype=torch.float32).to(device).contiguous()
-            circ, = _nh.upload(np.asarray(self.circular_dim_list, dtype=np.uint8), device=device, cached=True)
+            circ8 = np.asarray(self.circular_dim_list, dtype=np.uint8)
+            if torch.is_tensor(self.samples_mean) and self.samples_mean.is_cuda and torch.is_tensor(self.samples_std) and self.samples_std.is_cuda:
+                # (the device normalisation produced them where they are needed)
+                mean = self.samples_mean.to(device=device, dtype=torch.float32).contiguous()
+                std = self.samples_std.to(device=device, dtype=torch.float32).contiguous()
+                # the flags by CONTENT: a run has a handful of patterns (which columns are angles), so after the first models of
+                # a run no copy happens at all (the first one is host-synchronous: complete on return, safe on any stream)
+                key = (str(device), circ8.tobytes())
+                circ = _CIRC_FLAGS.get(key)
+                if circ is None:
+                    circ, = _nh.upload(circ8, device=device, cached=True)
+                    _CIRC_FLAGS[key] = circ
+            else:
+                # ONE host-synchronous copy for the three (kept for the model's life and used on any stream: `cached`)
+                mean, std, circ = _nh.upload(torch.as_tensor(self.samples_mean, dtype=torch.float32).numpy(),
+                                             torch.as_tensor(self.samples_std, dtype=torch.float32).numpy(), circ8,
+                                             device=device, cached=True)
             self._norm_cache = (str(device), mean, std, circ)
         return self._norm_cache[1:]
 

@@ -12,6 +12,11 @@ if os.environ.get("AB_LIB"):
     import torch
     import nfisam_hip as nh
     nh.LIB_PATH = os.path.join(os.path.dirname(nh.LIB_PATH), os.environ["AB_LIB"])
+    if os.environ.get("AB_OLD_ABI"):       # a library of an earlier round: only the entry points it has (plans without the newer diagnostics)
+        import ctypes
+        _old = ctypes.CDLL(nh.LIB_PATH)
+        nh.EXPORTS[:] = [e for e in nh.EXPORTS if hasattr(_old, e)]
+        nh.TrainBatch.xcd_span = lambda self: 0
     import bench as BM
     dev = torch.device("cuda:0")
     out = {}
@@ -20,8 +25,12 @@ if os.environ.get("AB_LIB"):
         if name == "c3":
             prob, L = BM.c3_problem(0), 1
         else:
-            prob, L = BM.regime_problem({"plaza": "plaza_clique_n2000_D15", "b64": "batch64_n2000_D15",
-                                         "c2": "C2_single_clique_n4096_D6_L4"}[name], 0)
+            if name == "r8":                # eight Plaza-shaped cliques: the replica conveyor's launch
+                prob, L = BM.regime_problem("batch64_n2000_D15", 0)
+                prob = prob[:8]
+            else:
+                prob, L = BM.regime_problem({"plaza": "plaza_clique_n2000_D15", "b64": "batch64_n2000_D15",
+                                             "c2": "C2_single_clique_n4096_D6_L4"}[name], 0)
         w = BM.Workload(prob, L, dev)
         r, _ = w.record(300, 30, torch.cuda.synchronize)
         out[name] = (r["gradient_kernel_us"], r["us_per_iteration"])

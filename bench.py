@@ -535,10 +535,12 @@ def main():
             try:
                 t = json.load(open(tjs[-1]))
                 out["roofline"]["traffic_profiled"] = dict(t, source="profiles/" + os.path.basename(tjs[-1]))
-                if t.get("kernel") == out["roofline"]["kernel"] or not head["chunk_persistent"]:
-                    out["roofline"]["traffic"] = t.get("hbm_side_bytes_per_launch_lower")
-                    out["roofline"]["traffic_provenance"] = ("profiled earlier (%s): lower bound of the HBM-side bytes per launch of %s"
-                                                             % (os.path.basename(tjs[-1]), t.get("kernel")))
+                if t.get("kernel") == out["roofline"]["kernel"]:
+                    per_it = t.get("hbm_side_bytes_per_iteration_lower", t.get("hbm_side_bytes_per_launch_lower"))
+                    out["roofline"]["traffic"] = per_it * head["iterations_per_launch"]
+                    out["roofline"]["traffic_provenance"] = ("profiled earlier (%s): lower bound of the HBM-side bytes per ITERATION of %s "
+                                                             "(separate --pmc FETCH_SIZE / WRITE_SIZE passes) x the %d iterations of a launch "
+                                                             "of this run" % (os.path.basename(tjs[-1]), t.get("kernel"), head["iterations_per_launch"]))
             except Exception:   # noqa: BLE001
                 pass
         ujs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_utilisation.json")))

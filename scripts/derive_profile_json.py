@@ -11,7 +11,7 @@ SIMDS, SES = 1024, 32
 def kernel_of(d):
     """the training kernel of the run: the chunk-persistent instantiation (<K, H, true>) when the plan took it (its launches
     run a whole chunk of iterations), else the one-launch-per-iteration kernel"""
-    ks = [k for k in d if "nsf_train1_kernel" in k]
+    ks = [k for k in d if "nsf_train1_" in k]
     per = [k for k in ks if "true" in k]
     name = (per or ks)[0]
     return dict(d[name], _name=name, _persistent=bool(per))
@@ -43,7 +43,7 @@ for name, key in (("C3", "c3"), ("batch64", "b64")):
     valu = 2.0 * k["SQ_ACTIVE_INST_VALU"] / (cyc * SIMDS)
     mfma = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS)
     out[name] = {
-        "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_kernel<9,8>", "iterations_per_launch": ipl,
+        "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_plain_kernel<9,8>", "iterations_per_launch": ipl,
         "kernel_cycles": cyc, "kernel_cycles_per_iteration": cyc / ipl, "waves_launched": k["SQ_WAVES"],
         "valu_instructions_per_iteration": k["SQ_INSTS_VALU"] / ipl, "mfma_instructions_per_iteration": k["SQ_INSTS_MFMA"] / ipl,
         "valu_instructions": k["SQ_INSTS_VALU"], "mfma_instructions": k["SQ_INSTS_MFMA"], "lds_instructions": k["SQ_INSTS_LDS"],
@@ -66,7 +66,7 @@ copies = 8
 grad_bytes = copies * sum(Pc) * 4
 state_bytes = 3 * sum(Pc) * 4
 traffic = {
-    "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_kernel<9,8>", "iterations_per_launch": ipl,
+    "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_plain_kernel<9,8>", "iterations_per_launch": ipl,
     "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
               "(the launch also applies the previous iteration's Adam update)",
     "launches_averaged": int(k.get("_n", 0)) or None,
@@ -90,17 +90,22 @@ traffic = {
 traffic["hbm_side_bytes_per_iteration_lower"] = traffic["hbm_side_bytes_per_launch_lower"] / ipl
 traffic["hbm_side_bytes_per_iteration_upper"] = traffic["hbm_side_bytes_per_launch_upper"] / ipl
 if k["_persistent"]:
-    # the persistent launch reads the particle batch ONCE per chunk (the tiles stay in LDS): algorithmic bytes per launch =
-    # x once + the parameters / moments in and out; per iteration nothing HAS to cross the L2-fabric boundary at all
-    alg = 608000 + 3 * sum(Pc) * 4 * 2
+    # algorithmic bytes per sample-iteration = 4 D (x) + the parameters once per iteration: 723552 B per C3
+    # iteration, x units of one launch = its iterations (the persistent form itself reads x only once per launch: the tiles
+    # stay in LDS -- it needs fewer bytes than the survey's figure, which is kept as the yardstick)
+    alg = 723552 * ipl
     traffic["algorithmic_bytes_per_launch"] = alg
+    traffic["algorithmic_bytes_per_iteration"] = 723552
     traffic["note"] = ("chunk-persistent launch of %d iterations (NFISAM_CHAINS=1: one launch per chunk); separate rocprofv3 --pmc FETCH_SIZE / "
                        "--pmc WRITE_SIZE passes, means over the launches of the run.  The counters sit at the L2-fabric boundary and "
                        "include Infinity-Cache hits; FETCH_SIZE counts 64 B per 128-B request for wide streaming reads on gfx950 "
-                       "(both bounds given).  Per iteration every block writes its gradient copy as (value, tag) pairs with "
-                       "write-through stores (2 x %.2f MB = the WRITE side) and the 8 blocks of a (clique, dim) group read the 8 copies "
-                       "back (L2 hits when the group sits on one XCD: the FETCH side stays small); the particle batch is read once per "
-                       "launch." % (ipl, grad_bytes / 1e6))
+                       "(both bounds given).  WRITE side: per iteration every block sends its gradient copy out as (value, tag) pairs "
+                       "with agent-scope WRITE-THROUGH stores (2 x %.2f MB: the tags double the bytes, and write-through means every "
+                       "store reaches the fabric instead of staying in L2 -- the price of an exchange that is correct from any XCD), "
+                       "the blocks publish the updated parameters the same way (2 x %.2f MB) and record theta, m, v (%.2f MB).  FETCH "
+                       "side: a parameter's 8 copies are read by ONE thread of the group (update divided among the blocks), every "
+                       "block reads the published parameters; L2 hits when the group sits on one XCD.  ~0.4 TB/s in all: latency, not "
+                       "bandwidth, is what the exchange costs (DESIGN.md 3.1f)." % (ipl, grad_bytes / 1e6, sum(Pc) * 4 / 1e6, state_bytes / 1e6))
 traffic["ratio_to_algorithmic"] = [traffic["hbm_side_bytes_per_launch_lower"] / alg, traffic["hbm_side_bytes_per_launch_upper"] / alg]
 json.dump(traffic, open(dst + "_train_kernel_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)); print(json.dumps(traffic, indent=1)[:1500])

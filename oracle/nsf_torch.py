@@ -18,6 +18,8 @@ What is restated (reference file:line, relative to /root/reference):
   linear tails outside [-B, B]                          src/flows/utils.py:31-49
   layer chaining + N(0,I) prior log-prob                src/flows/models.py:11-35
   NLL loss, Adam, window early-stop                     src/slam/NFiSAM.py:425,451-491
+  the same loop with a held-out set (hold-out stop)     src/slam/NFiSAM.py:452-468   (pinned by tests/golden/validation_loop.npz:
+                                                        the reference's own `for` statement run on its own flow classes)
   (un)normalisation with circular dims                  src/slam/NFiSAM.py:96-118,515-548
 
 Deliberate difference from the reference: `forward` returns z and log-det in the correct

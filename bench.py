@@ -235,6 +235,24 @@ class Workload:
         return (float(np.median(dts)), float(np.median(gms)), float(np.mean([v[0] for v in il])),
                 float(np.mean([v[iters - 1] for v in il])))
 
+    def time_persistent_kernel(self, iters, reps=7):
+        """Duration of the chunk-persistent launch(es) of ONE chunk of the same plan shape, by itself: a second plan whose
+        chunk is two graphs (training launches | closing Adam + bookkeeping) with two HIP timing events recorded on the
+        stream around the first (nfisam_nsf_train_plan_kernel_ms); median over `reps` runs of `iters` iterations, the last
+        chunk of each.  -> ms per launch (both parallel branches side by side)"""
+        tb = self.batch(iters)
+        tb.prepare(use_graph=True, timing=True)
+        ms = []
+        for r in range(reps + 1):
+            if r > 0:
+                tb.reset(self.kp0)
+            tb.run(use_graph=True)
+            self.torch.cuda.synchronize()
+            if r > 0:                                # (the first run pages the kernels in)
+                ms.append(tb.kernel_ms())
+        tb.close()
+        return float(np.median(ms))
+
     def time_gradient_kernel(self, reps=200):
         """Average duration of the gradient kernel as ONE launch over all (clique, dim) groups: `reps` launches captured in
         a graph (no host launch gaps), HIP events on the stream they run on; includes one ~1.5 us kernel boundary.  (A
@@ -269,10 +287,11 @@ class Workload:
         ach_plain = self.flop_per_launch / (kus * 1e-6) / 1e12
         gpu_us_it = 1e3 * gpu_ms / iters
         # The kernel of the timed region.  One launch per iteration: the gradient kernel timed alone (above).  Chunk-persistent
-        # plan: ONE launch runs `chunk_iters` iterations; its duration is taken from the HIP events around the timed region
-        # (per chunk: that launch + the chunk's closing Adam and bookkeeping kernels, ~12 us -- a lower bound of the rate).
+        # plan: ONE launch (per parallel graph branch) runs `chunk_iters` iterations; it is timed by itself right behind the
+        # timed region, in a plan of the same shape that records two HIP timing events on the stream around the persistent
+        # launch(es) of a chunk (time_persistent_kernel) -- as the plain kernel always was.
         if self.persistent:
-            launch_us, launch_flop = gpu_us_it * self.chunk_iters, self.flop_per_launch * self.chunk_iters
+            launch_us, launch_flop = 1e3 * self.time_persistent_kernel(iters), self.flop_per_launch * self.chunk_iters
         else:
             launch_us, launch_flop = kus, self.flop_per_launch
         ach = launch_flop / (launch_us * 1e-6) / 1e12
@@ -509,9 +528,11 @@ def main():
                                  "launch per parallel graph branch runs `iterations_per_launch` training iterations (gradient + the "
                                  "previous iteration's Adam update; the blocks of a (clique, dim) group exchange their gradient "
                                  "copies as tagged words, no kernel boundary); `flop_per_launch` = 333 MFLOP x iterations per launch "
-                                 "summed over the concurrent launches, `kernel_us` = the HIP-event GPU time of the timed region per "
-                                 "chunk, i.e. that launch PLUS the chunk's closing Adam and bookkeeping kernels (~12 us per chunk: "
-                                 "rocprofv3's average for the kernel alone is that much shorter).  One launch per iteration "
+                                 "summed over the concurrent launches, `kernel_us` = the duration of that launch (both branches) between "
+                                 "two HIP timing events recorded on its stream, measured right behind the timed region in a plan of "
+                                 "the same shape whose chunk end is a graph of its own (rocprofv3's per-launch average for the same "
+                                 "command: profiles/; `achieved_in_training` divides by the timed region's own GPU time per "
+                                 "iteration, closing Adam and bookkeeping kernels included).  One launch per iteration "
                                  "(nsf_train1_kernel<9,8>): `kernel_us` times the gradient kernel as ONE launch over all groups, "
                                  "200 back to back in a graph (`one_launch_per_iteration` holds that figure in either case).  Per "
                                  "(dim, 64-particle tile) unit a wave issues ~560 VALU instructions (~450 of them the spline, 64 "

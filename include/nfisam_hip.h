@@ -303,6 +303,12 @@ int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam
                                  int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int use_graph,
                                  nfisam_train_plan** out);
 int nfisam_nsf_train_plan_run(nfisam_train_plan* plan, int32_t* iters_run, nfisam_stream_t stream);
+/* ABI 1400, measurement only.  A plan created with `use_graph = 3` (graph | timing) splits a chunk-persistent chunk into two
+ * graphs -- the training launch(es), then the closing Adam update + bookkeeping -- and records two timing events on the
+ * stream around the first: after a run and a synchronisation, `ms` = GPU time of the persistent launch(es) of the most
+ * recent chunk (bench.py's `roofline.kernel_us`).  One more graph launch per chunk: not for production plans.
+ * NFISAM_ERR_ARG for plans without the events, NFISAM_ERR_LAUNCH when no persistent chunk has run. */
+int nfisam_nsf_train_plan_kernel_ms(const nfisam_train_plan* plan, float* ms);
 int nfisam_nsf_train_plan_destroy(nfisam_train_plan* plan);
 
 /* Stepping a graph plan by hand (ABI 1320; the slot scheduler of slam/ReplicaNFiSAM.py: independent runs whose cliques

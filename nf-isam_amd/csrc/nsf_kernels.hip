@@ -908,6 +908,9 @@ struct nfisam_train_plan {
                                            // `begin` records p->ev -- re-recording an event a stream still waits for ties that wait to
                                            // the NEW record on this runtime (the stream then waits for itself)
     // hold-out validation (nfisam_nsf_train_plan_create_validated): a chunk is one validation period
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;   // (use_graph & 2) timing events recorded around a persistent chunk's training launches
+    hipGraph_t graph_end = nullptr;              // ... whose chunk end (closing Adam + bookkeeping) is then a graph of its own
+    hipGraphExec_t exec_end = nullptr;
     std::vector<nfisam_validation> val;    // per clique, or empty
     float val_rate = 0.0f;
     bool stepping = false;                 // between `begin` and `end` (counted in g_hand_stepped)
@@ -928,7 +931,11 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->exec_p) (void)hipGraphExecDestroy(p->exec_p);
     if (p->graph_p) (void)hipGraphDestroy(p->graph_p);
+    if (p->exec_end) (void)hipGraphExecDestroy(p->exec_end);
+    if (p->graph_end) (void)hipGraphDestroy(p->graph_end);
     if (p->ev) (void)hipEventDestroy(p->ev);
+    if (p->evk0) (void)hipEventDestroy(p->evk0);
+    if (p->evk1) (void)hipEventDestroy(p->evk1);
     for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slot_ev) if (e) (void)hipEventDestroy(e);
     if (p->ev_end) (void)hipEventDestroy(p->ev_end);
@@ -1009,6 +1016,10 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
         int status = NFISAM_OK;
         hipError_t e = hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+        if (e == hipSuccess && (use_graph & 2) != 0) {          // measurement: the chunk's training launches between two timing events
+            e = hipEventCreate(&p->evk0);
+            if (e == hipSuccess) e = hipEventCreate(&p->evk1);
+        }
         // Chains: with one layer the (clique, dim) groups are independent optimisation problems for a whole chunk (every
         // group's blocks read and write that group's parameters, moments and gradient copies only), so an iteration may
         // be split into n launches that form n PARALLEL branches of the graph: the branches drift apart, and one
@@ -1046,10 +1057,22 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
                 e = hipEventRecord(p->side_ev[g - 1], p->side[g - 1]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->cap, p->side_ev[g - 1], 0);
             }
-            if (status == NFISAM_OK && e == hipSuccess && p->val.empty())
+            // (measurement plans: the persistent chunk's graph ends behind the training launches; its closing Adam update and
+            //  bookkeeping are a graph of their own, so that two timing events can be recorded on the stream in between --
+            //  events recorded INSIDE a captured graph cannot be asked for their elapsed time)
+            const bool split_end = persist && p->evk0 != nullptr && p->val.empty();
+            if (status == NFISAM_OK && e == hipSuccess && p->val.empty() && !split_end)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
                                            p->cap, p->hst_dev);
             e = hipStreamEndCapture(p->cap, graph_out);
+            if (split_end && e == hipSuccess && status == NFISAM_OK) {
+                e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk, p->cap, p->hst_dev);
+                    e = hipStreamEndCapture(p->cap, &p->graph_end);
+                }
+                if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec_end, p->graph_end, nullptr, nullptr, 0);
+            }
         }
         if (e == hipSuccess && status == NFISAM_OK)
             e = hipGraphInstantiate(persist ? &p->exec_p : &p->exec, *graph_out, nullptr, nullptr, 0);
@@ -1162,7 +1185,13 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     auto launch_chunk = [&]() -> int {
         const int left = p->cfg.max_iters - launched * p->chunk;
         const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
-        if (exec && todo == p->chunk) {
+        if (exec && todo == p->chunk && persist && p->exec_end != nullptr) {      // (measurement plan, see plan_create_impl)
+            hipError_t e = hipEventRecord(p->evk0, work);
+            if (e == hipSuccess) e = hipGraphLaunch(exec, work);
+            if (e == hipSuccess) e = hipEventRecord(p->evk1, work);
+            if (e == hipSuccess) e = hipGraphLaunch(p->exec_end, work);
+            if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+        } else if (exec && todo == p->chunk) {
             const hipError_t e = hipGraphLaunch(exec, work);
             if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
         } else if (!p->val.empty() && todo == p->chunk) {       // a validated plan without a graph: the same period, launch by launch
@@ -1228,6 +1257,15 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     }
     if (iters_run != nullptr) for (int c = 0; c < p->n_cliques; ++c) iters_run[c] = p->hst[c].step;
     return status;
+}
+
+// GPU time of the training launches of the plan's most recent PERSISTENT chunk replay (a plan created with `use_graph | 2`:
+// the chunk's closing Adam update and bookkeeping are a second graph and two timing events are recorded on the stream
+// around the first).  The caller has synchronised with the plan's work.  Measurement only: one more graph launch per chunk.
+extern "C" int nfisam_nsf_train_plan_kernel_ms(const nfisam_train_plan* p, float* ms) {
+    if (p == nullptr || ms == nullptr || p->evk0 == nullptr || p->evk1 == nullptr) return NFISAM_ERR_ARG;
+    HIP_TRY(hipEventElapsedTime(ms, p->evk0, p->evk1));
+    return NFISAM_OK;
 }
 
 // Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on, as of the last closed chunk (0: no

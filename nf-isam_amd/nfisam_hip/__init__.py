@@ -25,7 +25,7 @@ EXPORTS = [
     "nfisam_nsf_backward", "nfisam_nsf_train_step", "nfisam_nsf_train_loop", "nfisam_nsf_train_plan_create",
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
     "nfisam_nsf_train_plan_begin", "nfisam_nsf_train_plan_enqueue", "nfisam_nsf_train_plan_peek", "nfisam_nsf_train_plan_stream",
-    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_create_validated", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
+    "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_kernel_ms", "nfisam_nsf_train_plan_create_validated", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
     "nfisam_normalize_columns", "nfisam_simulate_clique",
 ]
 
@@ -446,21 +446,23 @@ class TrainBatch:
                                                  self.max_D, self.K, self.H, C.c_float(self.B), self.L, _stream())
         _check(rc, "nfisam_nsf_train_gradient")
 
-    def prepare(self, use_graph=True):
+    def prepare(self, use_graph=True, timing=False):
         """Validate descriptors and (optionally) capture + instantiate the hipGraph of one chunk of
-        iterations.  One-time set-up; `run` calls it on first use."""
-        if getattr(self, "_plan", None) is not None and self._plan_graph == bool(use_graph):
+        iterations.  One-time set-up; `run` calls it on first use.  `timing`: the graph carries two timing events around
+        the chunk's training launches (`kernel_ms`; measurement only)."""
+        if getattr(self, "_plan", None) is not None and self._plan_graph == bool(use_graph) and (not timing or getattr(self, "_plan_timing", False)):
             return
+        self._plan_timing = bool(timing) and bool(use_graph)
         self.close()
         plan = C.c_void_p(0)
         dev_desc = C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None
         if self.x_val is not None:
             rc = lib().nfisam_nsf_train_plan_create_validated(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
                                                               C.byref(self.cfg), self.val_desc, self.validation_interval,
-                                                              C.c_float(self.slower_stop_rate), int(bool(use_graph)), C.byref(plan))
+                                                              C.c_float(self.slower_stop_rate), int(bool(use_graph)) | (2 if self._plan_timing else 0), C.byref(plan))
         else:
             rc = lib().nfisam_nsf_train_plan_create(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
-                                                    C.byref(self.cfg), int(bool(use_graph)), C.byref(plan))
+                                                    C.byref(self.cfg), int(bool(use_graph)) | (2 if self._plan_timing else 0), C.byref(plan))
         _check(rc, "nfisam_nsf_train_plan_create")
         self._plan, self._plan_graph = plan, bool(use_graph)
 
@@ -474,6 +476,13 @@ class TrainBatch:
         self.last_iters = [int(v) for v in iters]          # valid also when a clique hit a domain error
         _check(rc, "nfisam_nsf_train_plan_run")
         return self.last_iters
+
+    def kernel_ms(self):
+        """GPU milliseconds of the training launches of the most recent chunk replay (plans prepared with `timing=True`;
+        synchronise first)."""
+        ms = C.c_float(0.0)
+        _check(lib().nfisam_nsf_train_plan_kernel_ms(self._plan, C.byref(ms)), "nfisam_nsf_train_plan_kernel_ms")
+        return float(ms.value)
 
     def xcd_span(self):
         """Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on (0: none ran; diagnostic)."""

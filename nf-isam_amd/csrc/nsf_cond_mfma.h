@@ -82,10 +82,9 @@ struct FusedAdam {
 };
 
 // sum of parameter j's gradient copies, in nsf_adam_kernel's one-thread-per-parameter order (at most 8 copies: the host checks)
-// COH: the word was written by ANOTHER block of this launch (chunk-persistent kernel: the blocks of a (clique, dim) group
-// meet at a group barrier): an agent-scope (sc1) load -- served by L2, not by this CU's vector cache, and coherent with the
-// agent-scope write-through stores of a block on ANOTHER XCD (group_store / the gradient copy's sc1 store); the grid puts a
-// group on one XCD, where both stay L2 hits, but nothing depends on that placement.
+// COH = true was round 3's in-launch exchange (agent-scope loads / stores of words another block of the launch wrote); the
+// chunk-persistent kernel exchanges tagged pairs since round 4 (stage_cond_panel_persist*), so only COH = false is
+// instantiated: the one-launch-per-iteration kernel reads what the PREVIOUS launch wrote.
 template <bool COH>
 __device__ __forceinline__ float group_load(const __attribute__((address_space(1))) float* p) {
     if constexpr (COH) return __hip_atomic_load((const float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,11 +92,8 @@ __device__ __forceinline__ float group_load(const __attribute__((address_space(1
 }
 template <bool COH>
 __device__ __forceinline__ void group_store(__attribute__((address_space(1))) float* p, float v) {
-#ifndef NSF_PERSIST_PLAIN_STORES       // (A/B build: round 3's plain stores, coherent through ONE XCD's L2 only)
     if constexpr (COH) __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-#endif
-    *p = v;
+    else *p = v;
 }
 template <bool COH = false>
 __device__ __forceinline__ void fused_load_grads(const FusedAdam& fa, int j, float (&gv)[8]) {

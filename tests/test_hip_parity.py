@@ -1178,3 +1178,30 @@ def test_validated_plan_rejects_what_the_device_rule_does_not_cover():
         tb = nh.TrainBatch([x], [kp.clone()], 9, 8, 5.0, 1, lr=0.01, max_iters=50, x_val=[x], validation_interval=interval, slower_stop_rate=rate)
         with pytest.raises(ValueError):
             tb.prepare(True)
+
+
+def test_timing_plan_reports_the_persistent_launch_and_changes_nothing():
+    """`prepare(timing=True)` (bench.py's `roofline.kernel_us`): the persistent chunk becomes two graphs with two timing events on
+    the stream around the training launch -- a positive duration below the whole run's, and the same bits as the ordinary plan."""
+    K, H, B = 9, 8, 5.0
+    gen = torch.Generator().manual_seed(21)
+    x = (1.2 * torch.randn(2000, 9, generator=gen)).clamp_(-4, 4).to(DEV)
+    kp = nh.pack((0.2 * torch.randn(nh.param_count(9, K, H), generator=gen)).to(DEV), 9, K, H, 1)
+    outs = []
+    for timing in (False, True):
+        tb = nh.TrainBatch([x], [kp.clone()], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
+        tb.prepare(use_graph=True, timing=timing)
+        t0 = time.perf_counter()
+        assert tb.run(use_graph=True) == [100]
+        torch.cuda.synchronize()
+        wall_ms = 1e3 * (time.perf_counter() - t0)
+        if timing:
+            assert tb.xcd_span() >= 1                      # the plan took the persistent form
+            ms = tb.kernel_ms()
+            assert 0.05 < ms < wall_ms, (ms, wall_ms)      # one chunk of 50 iterations: a few hundred microseconds
+        else:
+            with pytest.raises(ValueError):
+                tb.kernel_ms()
+        outs.append((tb.kparams[0].clone(), tb.iter_loss[0].clone()))
+        tb.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

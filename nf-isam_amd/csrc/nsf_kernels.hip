@@ -908,6 +908,8 @@ struct nfisam_train_plan {
                                            // `begin` records p->ev -- re-recording an event a stream still waits for ties that wait to
                                            // the NEW record on this runtime (the stream then waits for itself)
     // hold-out validation (nfisam_nsf_train_plan_create_validated): a chunk is one validation period
+    hipStream_t last_work = nullptr;             // the stream the last run's chunks went to (a chunk may still drain there: `ahead`)
+    bool ran = false;
     hipEvent_t evk0 = nullptr, evk1 = nullptr;   // (use_graph & 2) timing events recorded around a persistent chunk's training launches
     hipGraph_t graph_end = nullptr;              // ... whose chunk end (closing Adam + bookkeeping) is then a graph of its own
     hipGraphExec_t exec_end = nullptr;
@@ -927,6 +929,7 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     }
     if (p->stepping) { p->stepping = false; g_hand_stepped.fetch_sub(1); }
     if (p->cap) (void)hipStreamSynchronize(p->cap);       // a chunk enqueued ahead of an early stop may still be draining
+    if (p->ahead && p->ran && p->last_work != p->cap) (void)hipStreamSynchronize(p->last_work);   // ... on the caller's stream (null = the legacy stream)
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->exec_p) (void)hipGraphExecDestroy(p->exec_p);
@@ -1151,11 +1154,21 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     hipStream_t user = (hipStream_t)stream;
     hipStream_t work = user;
     const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
-    if (p->exec) {
+    // The chunks' graphs were captured on the plan's private stream; they are REPLAYED on the caller's own stream (round 4:
+    // two event record / wait pairs per run, ~12 us of a 20-iteration plan's 330, bought nothing -- a graph may be launched into
+    // any stream, the legacy null stream included; NFISAM_PLAN_STREAM=private restores the hand-over).
+    static const bool own_stream = getenv("NFISAM_PLAN_STREAM") != nullptr && strcmp(getenv("NFISAM_PLAN_STREAM"), "private") == 0;
+    if (p->exec && (own_stream || p->stepping)) {
         HIP_TRY(hipEventRecord(p->ev, user));          // order after prior work on the caller's stream
         HIP_TRY(hipStreamWaitEvent(p->cap, p->ev, 0));
         work = p->cap;
     }
+    if (p->ahead && p->ran && p->last_work != work) {              // (the previous run left a chunk draining on ANOTHER stream)
+        HIP_TRY(hipStreamSynchronize(p->last_work));
+        p->ahead = false;
+    }
+    p->last_work = work;
+    p->ran = true;
     // An error return must not leave graph work running on buffers the caller is about to reset or free: every
     // failure path drains the work stream first.
     // The chunk-persistent graph needs its blocks resident at once (persist_shape): ONE run per process uses it at a time
@@ -1294,7 +1307,11 @@ extern "C" int nfisam_nsf_train_plan_begin(nfisam_train_plan* p, nfisam_stream_t
     hipStream_t user = (hipStream_t)stream;
     HIP_TRY(hipEventRecord(p->ev, user));              // order after prior work on the caller's stream
     HIP_TRY(hipStreamWaitEvent(p->cap, p->ev, 0));
-    if (p->ahead) { HIP_TRY(hipStreamSynchronize(p->cap)); p->ahead = false; }
+    if (p->ahead) {
+        if (p->ran && p->last_work != p->cap) HIP_TRY(hipStreamSynchronize(p->last_work));     // (left there by nfisam_nsf_train_plan_run)
+        HIP_TRY(hipStreamSynchronize(p->cap));
+        p->ahead = false;
+    }
     for (int c = 0; c < p->n_cliques; ++c) p->hst[c].reserved[0] = 0;
     __atomic_thread_fence(__ATOMIC_RELEASE);
     p->enqueued.store(0);

@@ -239,7 +239,7 @@ class Workload:
         """Duration of the chunk-persistent launch(es) of ONE chunk of the same plan shape, by itself: a second plan whose
         chunk is two graphs (training launches | closing Adam + bookkeeping) with two HIP timing events recorded on the
         stream around the first (nfisam_nsf_train_plan_kernel_ms); median over `reps` runs of `iters` iterations, the last
-        chunk of each.  -> ms per launch (both parallel branches side by side)"""
+        chunk of each.  -> ms per launch"""
         tb = self.batch(iters)
         tb.prepare(use_graph=True, timing=True)
         ms = []
@@ -287,7 +287,7 @@ class Workload:
         ach_plain = self.flop_per_launch / (kus * 1e-6) / 1e12
         gpu_us_it = 1e3 * gpu_ms / iters
         # The kernel of the timed region.  One launch per iteration: the gradient kernel timed alone (above).  Chunk-persistent
-        # plan: ONE launch (per parallel graph branch) runs `chunk_iters` iterations; it is timed by itself right behind the
+        # plan: ONE launch runs `chunk_iters` iterations; it is timed by itself right behind the
         # timed region, in a plan of the same shape that records two HIP timing events on the stream around the persistent
         # launch(es) of a chunk (time_persistent_kernel) -- as the plain kernel always was.
         if self.persistent:
@@ -298,7 +298,10 @@ class Workload:
         return dict(cliques=len(self.xs), D=[int(x.shape[1]) for x in self.xs] if len(self.xs) <= 8 else int(self.xs[0].shape[1]),
                     particles_per_clique=int(self.xs[0].shape[0]), layers=self.L, hidden_dim=self.H, iterations=iters, replays=self.replays,
                     us_per_iteration=1e6 * dt / iters, gpu_us_per_iteration_events=1e3 * gpu_ms / iters,
-                    samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus, launches_per_training_iteration=chains,
+                    samples_per_s=self.n_samples * iters / dt, gradient_kernel_us=kus,
+                    # one launch per iteration: the plan issues an iteration as `chains` concurrent launches over disjoint groups;
+                    # the chunk-persistent form is ONE launch per chunk over all groups
+                    launches_per_training_iteration=(1.0 / self.chunk_iters) if self.persistent else chains,
                     flop_per_launch=self.flop_per_launch, achieved_tflops=ach, frac_of_fp32_peak=ach / FP32_PEAK_TFLOPS,
                     chunk_persistent=bool(self.persistent), iterations_per_launch=self.chunk_iters if self.persistent else 1,
                     training_launch_us=launch_us, training_launch_flop=launch_flop,
@@ -525,10 +528,10 @@ def main():
                          "note": "fp32 INSTRUCTION-ISSUE-bound kernel (SURVEY.md §8d: ~600 flop/B, HBM does not bind), priced "
                                  "against the fp32 peak (157.3 TFLOP/s = f32 MFMA = packed f32 VALU).  `kernel` is the kernel the "
                                  "TIMED REGION ran.  Chunk-persistent form (nsf_train1_kernel<9,8,true>, DESIGN.md §3.1e/f): one "
-                                 "launch per parallel graph branch runs `iterations_per_launch` training iterations (gradient + the "
+                                 "launch (over all (clique, dim) groups) runs `iterations_per_launch` training iterations (gradient + the "
                                  "previous iteration's Adam update; the blocks of a (clique, dim) group exchange their gradient "
-                                 "copies as tagged words, no kernel boundary); `flop_per_launch` = 333 MFLOP x iterations per launch "
-                                 "summed over the concurrent launches, `kernel_us` = the duration of that launch (both branches) between "
+                                 "copies as tagged words, no kernel boundary); `flop_per_launch` = 333 MFLOP x iterations per launch, "
+                                 "`kernel_us` = the duration of that launch between "
                                  "two HIP timing events recorded on its stream, measured right behind the timed region in a plan of "
                                  "the same shape whose chunk end is a graph of its own (rocprofv3's per-launch average for the same "
                                  "command: profiles/; `achieved_in_training` divides by the timed region's own GPU time per "

@@ -1471,6 +1471,14 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
 #pragma unroll
         for (int t = 0; t < NT; ++t) { cacc[t] = c1; cb2[t] = c1; }
     }
+    // Issue priority by progress ("least slack first", PERSIST): a wave that is near the end of its iteration holds up the seven
+    // other blocks of its (clique, dim) group -- they cannot stage the next iteration before its copy is out -- while a wave
+    // that has just begun its unit has the whole unit of slack.  With three waves per SIMD taking turns at the issue port
+    // regardless, the group's dependent chain ran at the pace of its unluckiest wave; with the priority raised phase by
+    // phase (conditioner forward 0 -> spline and conditioner backward 1 -> gradient GEMMs 2 -> epilogue and the next
+    // staging 3, the slice owners of the divided update included) C3 went from 13.2 to 11.2 us per iteration (scripts/ab.py,
+    // four interleaved rounds on one box); a lone wave per SIMD (one Plaza clique) is indifferent.
+    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(0);
     for (int tt = 0; tt < T && has_tile; ++tt) {
         const int pt = p0 + tt * TILE;
         if (pt >= n) break;
@@ -1500,6 +1508,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             lds_rows_store<16, H, 0, H>(stg_lane, h1);         // = hrow
         }
         PSTAMP(3, th[0], th[PoP - 1]);
+        if constexpr (PERSIST) __builtin_amdgcn_s_setprio(1);     // (behind the conditioner forward: a third of the unit done)
         SplineT<K> S;
         float z, lad;
         spline_train_fwd<K, PoP>(xt[i * XS + lane], th, B, S, z, lad);
@@ -1520,6 +1529,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         float ga2[H], ga1[H];
         cond_backward_mfma<K, H>(pan, lane, gth, h1, h2, ga2, ga1);
         PSTAMP(6, ga1[0], ga2[H - 1]);
+        if constexpr (PERSIST) __builtin_amdgcn_s_setprio(2);     // (the unit's last phase: the gradient GEMMs)
         // ---- weight gradients on the matrix cores (see nsf_train_kernel); operand rows: lane&15 = feature,
         //      lane>>4 = particle inside the k-group of 4; the bias column (and the unused columns) multiply 1 ----
         // The 16 staging rows carry four generations of operands: [h2 | h1], gth tile 0, gth tile 1, [ga2 | ga1].  A
@@ -1633,6 +1643,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     }
 
     // ---- the gradient of this dim's parameter block ----
+    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(3);     // (from here to the end of the next staging: the group's exchange)
     int tl3_ = threadIdx.x;
     cclique* cpe = cp0;
     cargs* ape_ = (cargs*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + 40);

@@ -3072,13 +3072,14 @@ static int unit_inverse(const float* z, const float* x_sep, const float* kparams
 template <int KK, int HH>
 static int unit_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols, const float* obs, int max_D, float B,
                      int L, int n, const float* Zt, float* St, hipStream_t s) {
-    // pipelined two-lanes-per-sample walk (H == 8, L == 1) when its LDS double buffer fits (a clique needs at most the
-    // parameter blocks of all its max_D dims), else the plain one-lane-per-sample walk
+    // pipelined two-lanes-per-sample walk (L == 1; hidden widths 8 and 16: a lane takes H / 2 hidden units, whole 16-byte rows)
+    // when its LDS double buffer fits (a clique needs at most the parameter blocks of all its max_D dims), else the plain
+    // one-lane-per-sample walk
     const size_t wmax = (size_t)L * (size_t)Layout<KK, HH>::off(max_D);
     const size_t lds2 = (2 * wmax + 8 * (size_t)max_D + 2 * (size_t)max_D + (size_t)3 * max_D * XS2) * sizeof(float);
     const char* walk_env = getenv("NFISAM_WALK");          // "plain" forces the one-lane walk (tests, A/B)
     const bool force_plain = (walk_env != nullptr && strcmp(walk_env, "plain") == 0);
-    if constexpr (HH == 8) {
+    if constexpr (HH % 8 == 0) {
         if (L == 1 && lds2 <= 150 * 1024 && max_D <= 64 && !force_plain) {
             int rc = set_lds(nsf_posterior_walk2_kernel<KK, HH>, lds2);
             if (rc) return rc;

@@ -581,6 +581,9 @@ def posterior_walk(entries, total_dim, n, K, H, B, L, device, generator=None, Zt
         q.sep_off = len(cols); cols.extend(int(v) for v in e["sep_cols"])
         q.front_off = len(cols); cols.extend(int(v) for v in e["front_cols"])
         max_D = max(max_D, q.D_model)
+    if sum(int(q.n_frontal) for q in table) > int(total_dim) or (cols and not 0 <= min(cols) <= max(cols) < int(total_dim)):
+        raise ValueError("the cliques' frontal columns exceed the %d columns of the sample matrix (one latent row of Zt per "
+                         "frontal column, consumed in walk order), or a column index is out of range" % total_dim)
     tbl = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(device)
     cols_t = torch.tensor(cols if cols else [0], dtype=torch.int32, device=device)
     obs_t = torch.tensor(obs if obs else [0.0], dtype=torch.float32, device=device)
@@ -642,6 +645,11 @@ def posterior_walk_raw(table: np.ndarray, cols: np.ndarray, obs: np.ndarray, tot
                        Zt=None):
     """`posterior_walk` with the clique table already assembled as a numpy array of POST_DTYPE
     (callers that walk large trees every update cache the per-clique pointers)."""
+    if int(table["n_frontal"].sum()) > int(total_dim) or (cols.size and not 0 <= int(cols.min()) <= int(cols.max()) < int(total_dim)):
+        raise ValueError("the cliques' frontal columns exceed the %d columns of the sample matrix, or a column index is out of range"
+                         % total_dim)
+    if Zt is not None and tuple(Zt.shape) != (int(total_dim), int(n)):
+        raise ValueError("Zt must be [total_dim, n] (column-major sample layout)")
     tbl, cols_t, obs_t = upload(table.view(np.uint8).reshape(-1), np.asarray(cols if cols.size else np.zeros(1), dtype=np.int32),
                                 np.asarray(obs if obs.size else np.zeros(1), dtype=np.float32), device=device)
     if Zt is None:

@@ -107,3 +107,21 @@ def test_compute_entry_points_refuse_cpu_tensors():
 def test_supported_instantiations():
     assert nh.supported(9, 8) and nh.supported(5, 8) and nh.supported(12, 8)
     assert not nh.supported(9, 7)
+
+
+def test_posterior_walk_refuses_a_table_that_would_read_past_the_latent_draws():
+    """Zt holds ONE row per frontal column, consumed in walk order (include/nfisam_hip.h: nfisam_nsf_posterior_walk): a table
+    whose frontal columns add up to more than total_dim, or with a column index outside the sample matrix, would make the
+    kernel read / write out of bounds -- the binding raises before anything is sent to the device."""
+    D, K, H = 5, 9, 8
+    def entry(front, sep):
+        return dict(kparams=torch.zeros(nh.kparam_count(D, K, H)), mean=torch.zeros(D), std=torch.ones(D),
+                    circular=torch.zeros(D, dtype=torch.uint8), D_model=D, obs=np.zeros(0), sep_cols=sep, front_cols=front)
+    with pytest.raises(ValueError, match="frontal columns exceed"):
+        nh.posterior_walk([entry([0, 1, 2], []), entry([2, 3], [0, 1])], 4, 8, K, H, 5.0, 1, torch.device("cpu"))
+    with pytest.raises(ValueError, match="out of range"):
+        nh.posterior_walk([entry([0, 1, 2], []), entry([4], [0, 1])], 4, 8, K, H, 5.0, 1, torch.device("cpu"))
+    table = np.zeros(2, dtype=nh.POST_DTYPE)
+    table["n_frontal"] = [3, 2]
+    with pytest.raises(ValueError, match="frontal columns exceed"):
+        nh.posterior_walk_raw(table, np.array([0, 1, 2, 0, 1, 2, 3]), np.zeros(0), 4, 8, D, K, H, 5.0, 1, torch.device("cpu"))

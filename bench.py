@@ -23,8 +23,9 @@ Prints ONE JSON line on rank 0 (driver contract), including
                  (157.3 TFLOP/s = f32 MFMA peak = f32 packed-VALU peak); the binding resource is VALU issue.
   regimes      : the same live measurement for the other regimes of the path: C2 (BASELINE config[1]: one
                  clique, 4 stacked layers), one Plaza1-shaped clique (n = 2000, D = 15: the latency regime of the
-                 real datasets), a batch of 64 such cliques (the throughput regime / scaling shape), and the last two with
-                 hidden_dim 16 (the reference's parameter grids sweep it, src/slam/NFiSAM.py:589-609).
+                 real datasets), a batch of 64 such cliques (the throughput regime / scaling shape), the last two with
+                 hidden_dim 16 (the reference's parameter grids sweep it, src/slam/NFiSAM.py:589-609), and C2 with
+                 hidden_dim 16 and 4 (multi-layer flows of those widths run the generic kernel: the gap on record).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
                  the reference) timed on the host cores on a bounded sample of the same workload, next to the
                  TRUE reference's figures measured in the build container (profiles/history/r02_cpu_reference_vs_port.json).
@@ -147,12 +148,13 @@ def c3_problem(seed0):
     return out
 
 
-REGIME_HIDDEN = {"plaza_clique_n2000_D15_H16": 16, "batch64_n2000_D15_H16": 16, "C2_single_clique_n4096_D6_L4_H16": 16}     # hidden_dim of a regime (default H)
+REGIME_HIDDEN = {"plaza_clique_n2000_D15_H16": 16, "batch64_n2000_D15_H16": 16, "C2_single_clique_n4096_D6_L4_H16": 16,
+                 "C2_single_clique_n4096_D6_L4_H04": 4}     # hidden_dim of a regime (default H)
 
 
 def regime_problem(name, seed0):
     """-> (list of (x, blob), L)"""
-    if name in REGIME_HIDDEN:                # the same cliques with hidden_dim 16 (the reference's grids sweep it: NFiSAM.py:589-609)
+    if name in REGIME_HIDDEN:                # the same cliques with hidden_dim 16 / 4 (the reference's grids sweep it: NFiSAM.py:589-609)
         h = REGIME_HIDDEN[name]
         base, L = regime_problem(name[:-4], seed0)
         return [(x, init_blob_np(x.shape[1], K, h, L, seed0 + c)) for c, (x, _) in enumerate(base)], L
@@ -493,7 +495,7 @@ def main():
     regimes = {}
     if rank == 0 and world == 1 and not args.no_regimes:
         for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15", "plaza_clique_n2000_D15_H16",
-                     "batch64_n2000_D15_H16", "C2_single_clique_n4096_D6_L4_H16"):
+                     "batch64_n2000_D15_H16", "C2_single_clique_n4096_D6_L4_H16", "C2_single_clique_n4096_D6_L4_H04"):
             prob, L = regime_problem(name, seed0=7)
             regimes[name], _ = Workload(prob, L, dev, REGIME_HIDDEN.get(name)).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
 

@@ -148,8 +148,10 @@ static inline int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: a
 // (with the Adam update fused into the next launch it beats the two-lanes-per-particle kernel from D = 2, n = 500 up,
 // scripts/exp/regime_grid.sh); VJP launches and L > 1 keep the split kernel while the launch is small.
 static inline bool dim_major_enabled();
-static inline int train_tile(int n_cliques, int max_n, int max_D, int H, bool nll_L1 = false) {
-    if (H != 8) return TILE;
+// `pair_h4`: hidden_dim 4 has ONE small-launch kernel, the two-dims-per-wave one (no two-lanes-per-particle kernel for
+// it): the caller says whether this launch can take it (layers or dL/dx couple the dims, the panels fit: pair_lds > 0).
+static inline int train_tile(int n_cliques, int max_n, int max_D, int H, bool nll_L1 = false, bool pair_h4 = false) {
+    if (H != 8 && !(H == 4 && pair_h4 && !nll_L1)) return TILE;
     const char* e = getenv("NFISAM_TRAIN");            // read per call: tests switch families in-process
     if (e != nullptr) {
         if (strcmp(e, "wide") == 0) return TILE;

@@ -554,6 +554,14 @@ extern "C" int nfisam_rqs(const float* inputs, const float* widths, const float*
     return NFISAM_OK;
 }
 
+// hidden_dim 4: can a multi-layer / dL/dx launch of this shape take the two-dims-per-wave kernel?  Asked of the LARGEST
+// num_knots of that width (the panels grow with K), so that the answer -- and with it the tile size, the number of
+// gradient copies and the workspace layout -- does not depend on K.
+static bool pair_h4_fits(int L, int max_D) {
+    const NsfUnitOps* o = find_ops(16, 4);
+    return o != nullptr && o->pair_lds(L, max_D) > 0;
+}
+
 extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
                                    size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
                                    float* gx, float* loss_sum, nfisam_stream_t stream) {
@@ -573,7 +581,7 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
     a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0; a.layer_stride = (int)layer_stride;
     const NsfUnitOps* ops = find_ops(K, H);
     if (ops == nullptr) return NFISAM_ERR_ARG;
-    a.tile = train_tile(1, n, D, H);
+    a.tile = train_tile(1, n, D, H, false, H == 4 && (L > 1 || gx != nullptr) && pair_h4_fits(L, D));
     return ops->train(a, 1, n, D, (hipStream_t)stream);
 }
 
@@ -601,7 +609,7 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     // + the chunk-persistent form's two sets of TAGGED copies (8 blocks of 4 waves at most, 2 floats per parameter)
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 32 + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
-    const size_t image = (L > 1 && H == 8 && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
+    const size_t image = (L > 1 && (H == 8 || H == 4) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
     // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)
     const size_t stash = (image > 0 && pair_stash_fits(n, D))
                              ? (size_t)((n + TILE2 - 1) / TILE2) * (size_t)(L - 1) * (size_t)((D + 1) / 2) * pair_stash_fields(K, H) * 64
@@ -614,7 +622,7 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
 struct TrainShape { int tile, T, slab, W; };
 static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H) {
     TrainShape sh;
-    sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1);
+    sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1, H == 4 && L > 1 && pair_h4_fits(L, max_D));
     sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile, H);
     sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
     sh.W = 0;

@@ -3152,14 +3152,14 @@ struct PairMap {
 // LDS bytes of nsf_train3_kernel; 0: the launch does not fit it (too wide, or the panels of all layers exceed the CU's LDS)
 template <int KK, int HH>
 static size_t pair_kernel_lds(int L, int max_D) {
-    if constexpr (HH != 8) {
+    if constexpr (HH != 8 && HH != 4) {
         return 0;
     } else {
         // Narrow cliques stay with nsf_train2_kernel: up to four dims are one wave per SIMD there too, and its units get
         // cheaper with the dim (measured, us per iteration split / pair: D 3, L 4: 28.8 / 30.6; D 4: 30.8 / 31.3; D 5: 33.9 /
         // 33.6; D 6 (C2): 39.1 / 34.1; D 8, L 3: 36.5 / 31.1).  NFISAM_PAIR=0 | 1 forces one of them (A/B, tests).
         const char* pe = getenv("NFISAM_PAIR");
-        const int min_D = (pe != nullptr && pe[0] == '1') ? 1 : 6;
+        const int min_D = ((pe != nullptr && pe[0] == '1') || HH != 8) ? 1 : 6;      // (hidden_dim 4 has no two-lanes-per-particle kernel to stay with)
         if ((pe != nullptr && pe[0] == '0') || max_D > PAIR_MAX_D || max_D < min_D) return 0;
         const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
         const size_t fl = (size_t)pair_tile_floats(L, max_D, 1) + (size_t)W * PAIR_WAVE_FLOATS +
@@ -3169,7 +3169,7 @@ static size_t pair_kernel_lds(int L, int max_D) {
 }
 template <int KK, int HH>
 static int unit_pair_map(const uint32_t** map, uint32_t* offsets) {
-    if constexpr (HH != 8) {
+    if constexpr (HH != 8 && HH != 4) {
         return NFISAM_ERR_ARG;
     } else {
         PairMapOffsets o;
@@ -3181,7 +3181,7 @@ static int unit_pair_map(const uint32_t** map, uint32_t* offsets) {
 
 template <int KK, int HH>
 static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
-    if constexpr (HH != 8) {
+    if constexpr (HH != 8 && HH != 4) {
         return NFISAM_ERR_ARG;
     } else {
         const long tiles = (long)((max_n + TILE2 - 1) / TILE2) * n_cliques;
@@ -3207,6 +3207,9 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
                 return NFISAM_OK;
             }
         }
+        if constexpr (HH != 8) {
+            return NFISAM_ERR_ARG;                             // (train_tile sends hidden_dim 4 here only when the pair kernel takes the launch)
+        } else {
         // L == 1 and no dL/dx requested: the dims of a tile never exchange data, so a small (latency-bound) launch
         // turns every (tile, dim) unit into its own single-wave block; big batches keep a tile's dims together.
         const bool independent_dims = (a.L == 1 && a.gx == nullptr);
@@ -3239,6 +3242,7 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         }
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;
+        }
     }
 }
 
@@ -3269,7 +3273,7 @@ struct PanelMap {
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4 || HH == 16) {
-        if constexpr (HH == 8) {
+        if constexpr (HH == 8 || HH == 4) {
             const int rc = PairMap<KK, HH>::get(nullptr, nullptr);
             if (rc) return rc;
         }

@@ -839,6 +839,48 @@ def test_multilayer_panel_image_equals_staging_from_the_parameters(shapes, L, it
         np.testing.assert_allclose(x, y, rtol=3e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("K", [9, 16, 2])
+def test_multilayer_hidden_dim_4_on_the_two_dims_per_wave_kernel(K):
+    """hidden_dim 4 with stacked layers: small launches take nsf_train3_kernel (MFMA conditioner, two dims per wave, panel
+    image) like hidden_dim 8 -- there is no two-lanes-per-particle kernel of that width, so every clique width 1..16 goes
+    there.  Against the tile-major generic kernel (`NFISAM_TRAIN=wide`, shares no code with it): the first Adam moments
+    (0.1 x gradient, 0.001 x gradient^2) and the first loss of a ragged batch; against the float64 C oracle: gradient and
+    dL/dx of single calls (`nfisam_nsf_backward`), and a six-iteration loss curve; panel image on / off bit for bit.
+    (C2's shape with hidden_dim 4: 60.3 -> 29.2 us per iteration, `regimes.C2_..._H04` of the bench line.)"""
+    H, B, L = 4, 5.0, 3
+    shapes = [(300, 5), (257, 8), (64, 1), (200, 2), (129, 11)]          # (a small launch; D = 11 x 3 layers: the panels of num_knots 16 still fit)
+    with _Env(NFISAM_TRAIN="wide"):
+        _, wide, _ = _train_layers(shapes, L, 1, 1, False, K=K, H=H)
+    _, pair, probs = _train_layers(shapes, L, 1, 1, False, K=K, H=H)
+    for c in range(len(shapes)):
+        assert not np.array_equal(wide[1][c], pair[1][c])       # two kernels (rounding differs somewhere)
+        scale = np.abs(wide[1][c]).max()
+        np.testing.assert_allclose(pair[1][c], wide[1][c], atol=1e-4 * scale, rtol=2e-3, err_msg=str((K, c)))
+        np.testing.assert_allclose(pair[3][c][:1], wide[3][c][:1], rtol=2e-5)
+    for c, (n, D) in enumerate(shapes[:3]):
+        blob, x = probs[c]
+        lossc, gradc, _, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+        kg, gx, loss = nh.backward(dev(x), kpack(blob, D, K, H, L), K, H, B, L, nll_mode=True, want_gx=True)
+        assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L, (K, c)
+        grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3, atol=2e-5 * L)
+        ex = np.abs(gx.cpu().numpy() / n - gxc)            # (a particle next to a knot may pick the other bin in fp32: dL/dx jumps there)
+        assert np.quantile(ex, 0.98) < 2e-3 * np.abs(gxc).max() + 2e-5 * L and ex.max() < 0.05 * max(1.0, np.abs(gxc).max()), (K, c)
+    iters = 6
+    with _Env(NFISAM_PAIR_IMAGE="0"):
+        _, ref, _ = _train_layers(shapes, L, iters, 50, True, K=K, H=H, lr=0.02, early_stop=False)
+    done, out, probs = _train_layers(shapes, L, iters, 50, True, K=K, H=H, lr=0.02, early_stop=False)
+    assert done == [iters] * len(shapes)
+    for c, (n, D) in enumerate(shapes):
+        for a, b in zip(ref[:3], out[:3]):
+            assert np.array_equal(a[c], b[c]), (K, c)
+        if c < 2:
+            blob, x = probs[c]
+            _, l64, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.02, max_iters=iters, early_stop=False, dtype=np.float64)
+            # (three layers at this step size amplify rounding from the fourth iteration on: test_multilayer_training_follows_the_oracle)
+            np.testing.assert_allclose(out[3][c][:3], l64[:3], atol=2e-4, rtol=1e-5, err_msg=str((K, c)))
+            np.testing.assert_allclose(out[3][c][:iters], l64[:iters], rtol=2e-2, err_msg=str((K, c)))
+
+
 def test_multilayer_training_follows_the_oracle():
     """Eight Adam iterations of multi-layer flows through the training plan (gradient kernel + Adam kernel + panel image)
     against the oracle's loop.  Three layers at this step size amplify rounding (the oracle in fp32 and in fp64 are 3e-2

@@ -679,6 +679,19 @@ constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);  
 // buffers, so nobody overwrites what a slower block still reads), and the fused Adam update of the next iteration reads
 // the copies back from the XCD's L2 (device-scope loads: the CU's vector cache may hold the lines of two iterations ago).
 // The particle tile stays in LDS; no kernel boundary, no cold prologue.  Same arithmetic in the same order: bit-identical.
+// Waves per SIMD the dim-major kernels are compiled for: three (168 VGPRs) -- what contended launches want (C3's 624 blocks are
+// resident at once only at three blocks per CU; the 64-clique batch runs 3 waves per SIMD).  From num_knots 12 up (10 for the
+// chunk-persistent form) that allocation spills (K = 12: 17 / 39 VGPRs, K = 15: 65 / 60; reloads in the middle of the dependent
+// chain), which is what a LONE wave per SIMD feels: those (K, H <= 8) pairs get a second, LEAN instantiation with 256 VGPRs
+// (no scratch) that the launcher takes whenever the launch is resident at two blocks per CU anyway -- single cliques, i.e. every
+// fit of a real run (one Plaza-shaped clique, K = 15: 10.6 -> 9.8 us per iteration, K = 12: 9.7 -> 9.45; the reference's examples
+// use K = 12 and 15 too: icra_paper/run_nfisam.py:151, toy_examples/R2RangeGaussian_example/five_node_range_gaussian_incremental.py:85).
+#ifndef NSF_PLAIN_MAX_K3
+#define NSF_PLAIN_MAX_K3 11
+#endif
+#ifndef NSF_PERSIST_MAX_K3
+#define NSF_PERSIST_MAX_K3 9
+#endif
 #ifndef NSF_PERSIST_WAVES
 #define NSF_PERSIST_WAVES 3      // resident waves per SIMD the chunk-persistent instantiation is compiled for (round 3: 2 -- it spilled at 3)
 #endif
@@ -688,8 +701,8 @@ constexpr int TRAIN1_FEW_OFFSET = 40 + (int)((sizeof(TrainArgs) + 7) / 8 * 8);  
 // VGPRs, another schedule: C3 as one launch 14.6 vs 13.95 us, the 64-clique batch 86.0 vs 84.9, scripts/ab.py against a
 // build of round 3's tree on one box), so the launches that run one iteration per launch -- every batch too large to be
 // resident at once, the replicas' conveyor, the eager tail of a run -- keep round 3's text as it was.
-template <int K, int H>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(H == 16 ? 2 : 3, 8)))
+template <int K, int H, bool LEAN = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || LEAN) ? 2 : 3, 8)))
 nsf_train1_plain_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     constexpr bool PERSIST = false;                           // (the text of round 3's kernel: its persistent branches compile away)
@@ -1179,8 +1192,8 @@ __host__ __device__ constexpr int persist_keep_stride(int max_D) {
     const int b = max_D > 1 ? LY::block(max_D - 1) : 0;
     return ((b > LY::PoP ? b : LY::PoP) + 3) & ~3;
 }
-template <int K, int H, bool PERSIST = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
+template <int K, int H, bool PERSIST = false, bool LEAN = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || LEAN || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
@@ -3289,19 +3302,47 @@ static size_t train1_lds_bytes(int max_D, int W, bool persist = false) {
             (persist ? (size_t)3 * persist_keep_stride<KK, HH>(max_D) : 0)) * sizeof(float);
 }
 // co-resident blocks of nsf_train1_kernel<K, H, true> on this device (what its registers and LDS allow per CU x CUs)
+// blocks of 256 threads with `lds` bytes of dynamic LDS that the current device holds at once for `kernel`
+template <typename Kern>
+static long resident_blocks(Kern kernel, size_t lds) {
+    if (set_lds(kernel, lds) != NFISAM_OK) return 0;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return (long)per_cu * (long)prop.multiProcessorCount;
+}
 template <int KK, int HH>
 static long unit_persist_places(int max_D) {
     if constexpr (HH != 8 && HH != 4 && HH != 16) {
         return 0;
     } else {
-        const size_t lds = train1_lds_bytes<KK, HH>(max_D, 4, true);
-        if (set_lds(nsf_train1_kernel<KK, HH, true>, lds) != NFISAM_OK) return 0;
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nsf_train1_kernel<KK, HH, true>, 256, lds) != hipSuccess) return 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        return (long)per_cu * (long)prop.multiProcessorCount;
+        return resident_blocks(nsf_train1_kernel<KK, HH, true>, train1_lds_bytes<KK, HH>(max_D, 4, true));
     }
+}
+// the LEAN instantiations (two waves per SIMD, no scratch) exist for the (K, H) pairs whose three-wave build spills
+template <int KK, int HH> constexpr bool lean_plain_v = HH <= 8 && KK > NSF_PLAIN_MAX_K3;
+template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PERSIST_MAX_K3;
+// does a launch of `blocks` four-wave blocks fit the device at the lean build's occupancy (all resident: nothing gained by a
+// third wave per SIMD)?  Cached per max_D; the chunk-persistent form keeps the 1/8 margin of persist_shape (nsf_kernels.hip).
+template <int KK, int HH, bool PERSIST>
+static bool lean_launch_fits(long blocks, int max_D) {
+    static long places[2][FUSED_COUNTERS + 1] = {};
+    static int devs[2][FUSED_COUNTERS + 1] = {};
+    if (max_D < 1 || max_D > FUSED_COUNTERS) return false;
+    const char* le = getenv("NFISAM_LEAN");                  // "0": never (A/B, tests; read per call)
+    if (le != nullptr && le[0] == '0') return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    long& pl = places[PERSIST ? 1 : 0][max_D];
+    int& pd = devs[PERSIST ? 1 : 0][max_D];
+    if (pl == 0 || pd != dev + 1) {
+        if constexpr (PERSIST) pl = resident_blocks(nsf_train1_kernel<KK, HH, true, true>, train1_lds_bytes<KK, HH>(max_D, 4, true));
+        else pl = resident_blocks(nsf_train1_plain_kernel<KK, HH, true>, train1_lds_bytes<KK, HH>(max_D, 4, false));
+        if (pl <= 0) pl = -1;
+        pd = dev + 1;
+    }
+    return pl > 0 && blocks <= (PERSIST ? pl - pl / 8 : pl);
 }
 
 template <int KK, int HH>
@@ -3331,7 +3372,26 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if (const char* pe = getenv("NFISAM_LDS_PAD_KB")) lds_launch += (size_t)atoi(pe) * 1024;   // experiments: fewer blocks per CU
         const bool persist = a.persist_iters > 0;
         if (persist && (T != 1 || !a.slab || !a.fused_adam || a.L != 1 || max_D > FUSED_COUNTERS)) return NFISAM_ERR_ARG;
-        rc = persist ? set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch) : set_lds(nsf_train1_plain_kernel<KK, HH>, lds_launch);
+        // the (clique, dim, 256 particles) blocks this launch really has
+        long real_blocks = 0;
+        {
+            const nfisam_clique* hc = (a.cliques == nullptr) ? &a.single : a.host_cliques;
+            if (hc != nullptr)
+                for (int c = 0; c < n_cliques; ++c) real_blocks += (long)hc[c].D * ((hc[c].n + W * T * TILE - 1) / (W * T * TILE));
+            else
+                real_blocks = (long)n_cliques * max_D * gx;
+        }
+        // LEAN build (two waves per SIMD, no scratch: see the kernels' attribute) when the launch is resident at that occupancy anyway
+        bool lean = false;
+        if constexpr (lean_persist_v<KK, HH>) { if (persist && W == 4) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D); }
+        if constexpr (lean_plain_v<KK, HH>) { if (!persist && W == 4) lean = lean_launch_fits<KK, HH, false>(real_blocks, max_D); }
+        if (persist) {
+            rc = set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch);
+            if constexpr (lean_persist_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true>, lds_launch); }
+        } else {
+            rc = set_lds(nsf_train1_plain_kernel<KK, HH>, lds_launch);
+            if constexpr (lean_plain_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_plain_kernel<KK, HH, true>, lds_launch); }
+        }
         if (rc) return rc;
         // few cliques: their descriptors travel in the kernel arguments (host copy: the plan's, or the single one)
         static_assert(offsetof(Train1Head, shifts) == 32 && sizeof(Train1Head) == 40, "scalar head of the kernel arguments");
@@ -3360,14 +3420,30 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         a.persist_spins = spin_log2 < 1 ? 1 : (spin_log2 > 30 ? 30 : spin_log2);
         static const bool drop = getenv("NFISAM_PERSIST_DROP") != nullptr && getenv("NFISAM_PERSIST_DROP")[0] == '1';                  // (test knob)
         static const bool scatter = getenv("NFISAM_PERSIST_SCATTER") != nullptr && getenv("NFISAM_PERSIST_SCATTER")[0] == '1';   // (test knob)
-        if (gz > 0 && persist)
+        const int pshifts = a.t_shift | (scatter ? 0x80 : 0) | (drop ? 0x40 : 0) | (a.w_shift << 8) | (ch << 16) | (nch << 24);
+        const int shifts = a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24);
+        bool launched = false;
+        if constexpr (lean_persist_v<KK, HH>) {
+            if (gz > 0 && persist && lean) {
+                hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                                   dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+                launched = true;
+            }
+        }
+        if constexpr (lean_plain_v<KK, HH>) {
+            if (gz > 0 && !persist && lean) {
+                hipLaunchKernelGGL((nsf_train1_plain_kernel<KK, HH, true>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+                                   a.magic_cliques, a.groups, a.grid_cliques, a.xrows, shifts, a, few);
+                launched = true;
+            }
+        }
+        if (launched) {
+        } else if (gz > 0 && persist)
             hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
-                               dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
-                               a.t_shift | (scatter ? 0x80 : 0) | (drop ? 0x40 : 0) | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
+                               dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
         else if (gz > 0)
             hipLaunchKernelGGL((nsf_train1_plain_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
-                               a.magic_cliques, a.groups, a.grid_cliques, a.xrows,
-                               a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24), a, few);
+                               a.magic_cliques, a.groups, a.grid_cliques, a.xrows, shifts, a, few);
         HIP_TRY(hipGetLastError());
         return NFISAM_OK;
     }

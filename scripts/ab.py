@@ -18,6 +18,8 @@ if os.environ.get("AB_LIB"):
         nh.EXPORTS[:] = [e for e in nh.EXPORTS if hasattr(_old, e)]
         nh.TrainBatch.xcd_span = lambda self: 0
     import bench as BM
+    if os.environ.get("AB_K"):             # another num_knots than the bench's 9
+        BM.K = int(os.environ["AB_K"])
     dev = torch.device("cuda:0")
     out = {}
     which = os.environ.get("AB_REGIMES", "c3,plaza,b64").split(",")

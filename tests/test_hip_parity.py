@@ -1083,6 +1083,46 @@ def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tm
     assert np.all(np.isfinite(res["1"]["plaza_0_loss"][:230])) and res["1"]["plaza_0_loss"][229] < res["1"]["plaza_0_loss"][0]
 
 
+@pytest.mark.parametrize("K", [10, 12, 15, 16])
+def test_lean_builds_of_wide_splines_agree_with_the_three_wave_builds(K):
+    """num_knots >= 12 (the chunk-persistent form: >= 10) spill at the three waves per SIMD the dim-major kernels are compiled
+    for; launches that are resident at two blocks per CU anyway (single cliques: every fit of a real run) take a second
+    instantiation compiled for two waves per SIMD, without scratch (nsf_unit.hip: LEAN; the reference's examples use K = 12 and
+    15).  Same source, another register allocation and instruction selection: the first gradient agrees to rounding (the
+    parameters after one Adam step to ~1e-6, i.e. they are NOT bit-identical: K = 12 differs by 3e-7), so against
+    `NFISAM_LEAN=0`: parameters after 1 and 5 iterations (a coordinate whose gradient is at rounding level may step the other
+    way: 2 x lr), the loss record of the first ten iterations to 1e-6, and the loss after 130 iterations through the
+    chunk-persistent graph + the eager tail to 3 %; a 20-clique batch (too many blocks for the lean build: the same kernel
+    both ways) must not change at all."""
+    H, B, lr = 8, 5.0, 0.01
+    def run(shapes, iters, window, use_graph, seed=3):
+        gen = torch.Generator().manual_seed(seed)
+        xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(DEV) for n, D in shapes]
+        kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(DEV), D, K, H, 1) for n, D in shapes]
+        tb = nh.TrainBatch(xs, kp, K, H, B, 1, lr=lr, max_iters=iters, average_window=window, loss_delta_tol=0.0, early_stop=True)
+        done = tb.run(use_graph=use_graph)
+        torch.cuda.synchronize()
+        out = (done, [t.cpu().numpy().copy() for t in tb.kparams], [t.cpu().numpy().copy()[:iters] for t in tb.iter_loss])
+        tb.close()
+        return out
+    for iters, window, graph in ((1, 1, False), (5, 5, False), (130, 50, True)):
+        with _Env(NFISAM_LEAN="0"):
+            ref = run([(2000, 15)], iters, window, graph)
+        got = run([(2000, 15)], iters, window, graph)
+        assert ref[0] == got[0] == [iters]
+        np.testing.assert_allclose(got[2][0][:10], ref[2][0][:10], rtol=1e-6)
+        if iters <= 5:
+            d = np.abs(got[1][0] - ref[1][0])
+            assert np.quantile(d, 0.999) < 1e-5 and d.max() <= 2 * lr * iters + 1e-6, (K, iters, np.quantile(d, 0.999), d.max())
+        else:
+            assert abs(got[2][0][iters - 1] / ref[2][0][iters - 1] - 1.0) < 0.03, (K, got[2][0][iters - 1], ref[2][0][iters - 1])
+    with _Env(NFISAM_LEAN="0"):
+        ref = run([(2000, 9)] * 20, 12, 6, True)
+    got = run([(2000, 9)] * 20, 12, 6, True)
+    for a, b in zip(ref[1] + ref[2], got[1] + got[2]):
+        assert np.array_equal(a, b), K
+
+
 STALL_WORKER = r'''
 import os, sys
 import numpy as np, torch

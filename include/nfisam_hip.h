@@ -64,13 +64,17 @@ typedef void* nfisam_stream_t;
 int nfisam_abi_version(void);
 /* Last HIP error code recorded by a failing call on this thread (0 if none). */
 int nfisam_last_hip_error(void);
-/* 1 if the (K, H) pair has a compiled kernel instantiation, else 0.  K in {2..16}, H in {4,8,16}. */
+/* 1 if flows with (num_knots K, hidden_dim H) run on the kernels, else 0: K in 2..16, H in 1..16.  The kernels are
+ * instantiated for H in {4, 8, 16}; every other width runs as the next compiled width with zero-padded hidden units (the
+ * reference takes any width, src/flows/flows.py:26-41): a padded unit has zero in-weights, bias and out-weights, so its
+ * activation is tanh(0) = 0 and every gradient touching it is an exact 0 -- Adam leaves the padding at zero (ABI 1500). */
 int nfisam_nsf_supported(int K, int H);
 
 /* ---- layout (host-only helpers, no GPU needed) ---------------------------------------- */
 /* Parameters per layer in the reference's order = numel of NSF_AR.parameters() (flows.py:51-60). */
 size_t nfisam_nsf_param_count(int D, int K, int H);
-/* Floats per layer in kernel layout (>= param_count because of padding). */
+/* Floats per layer in kernel layout (>= param_count because of padding; for a hidden_dim that is not a compiled width:
+ * the count of the next compiled width). */
 size_t nfisam_nsf_kparam_count(int D, int K, int H);
 /* host: map[kidx] = index into the reference-order blob, or -1 for padding. map has kparam_count entries. */
 int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map);
@@ -230,7 +234,11 @@ typedef struct nfisam_clique {
     float* kparams;              /* [L*kparam_count]                                          */
     float* adam_m;               /* [L*kparam_count] zero-initialised                         */
     float* adam_v;               /* [L*kparam_count] zero-initialised                         */
-    float* kgrad;                /* [nfisam_nsf_grad_workspace_count(max n of the batch, D,..)] workspace, zero-initialised */
+    float* kgrad;                /* [nfisam_nsf_grad_workspace_count(max n of the batch, D,..)] workspace, zero-initialised --
+                                  * and ZEROED AGAIN by the caller whenever it resets `state` (step = 0) to re-run a plan: the
+                                  * chunk-persistent kernel's blocks exchange gradient words as (value, tag) pairs whose tag is
+                                  * the iteration's number in the run (state->step + i + 1), so a workspace that still holds the
+                                  * pairs of an earlier run with the same numbering would be read as this run's (ABI 1400)     */
     float* iter_loss;            /* [max_iters] zero-initialised; per-iteration loss (NFiSAM.py:473) */
     nfisam_train_state* state;   /* zero-initialised                                          */
     int32_t n, D;
@@ -297,7 +305,9 @@ int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique
 /* The same loop with the set-up split off, so that descriptor validation and hipGraph capture /
  * instantiation happen once (outside any timed region) and the plan can be re-run, e.g. after the
  * caller re-initialised parameters / Adam moments / state in place.  `plan_run` synchronises with
- * the host after every chunk of `average_window` (50 if early stopping is off) iterations.      */
+ * the host after every chunk of `average_window` (50 if early stopping is off) iterations.
+ * Re-running a plan from step 0: re-initialise parameters, moments, `iter_loss`, `state` AND the `kgrad` workspace (zero) --
+ * see nfisam_clique.kgrad; continuing a run (state left as it is) needs nothing.                 */
 typedef struct nfisam_train_plan nfisam_train_plan;
 int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques, int n_cliques,
                                  int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int use_graph,

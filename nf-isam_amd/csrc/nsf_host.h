@@ -77,7 +77,7 @@ struct TrainArgs {
     int fused_adam;                 // nsf_train1_kernel: apply the previous iteration's Adam update on the way into LDS (nsf_cond_mfma.h)
     int persist_iters;              // nsf_train1_kernel, chunk-persistent form: iterations 0 .. persist_iters - 1 of the chunk in ONE launch (0: one iteration per launch)
     int persist_split;              // ... != 0: the Adam update of a dim is divided among the group's blocks (contended launches; nsf_cond_mfma.h)
-    int persist_spins;              // ... log2 of the polls a block waits at its group barrier before it raises the group's abort flag (22; NFISAM_PERSIST_SPINS: tests)
+    int persist_spins;              // ... log2 of the polls a block waits at its group barrier before it raises the group's abort flag (15; NFISAM_PERSIST_SPINS)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
 };

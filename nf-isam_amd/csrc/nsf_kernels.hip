@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) nsf_rqs_kernel(const float* __restrict__ 
 // =============================================================================================
 // host side
 // =============================================================================================
-extern "C" int nfisam_abi_version(void) { return 1400; }
+extern "C" int nfisam_abi_version(void) { return 1500; }
 extern "C" int nfisam_last_hip_error(void) { return nfisam_g_last_hip_error; }
 
 // (K, H) -> launchers of the kernel unit that instantiates the pair (nsf_units.h), nullptr if none does
@@ -447,7 +447,15 @@ static const NsfUnitOps* find_ops(int K, int H) {
 #undef NSF_TRY_UNIT
     return o;
 }
-extern "C" int nfisam_nsf_supported(int K, int H) { return find_ops(K, H) != nullptr ? 1 : 0; }
+// hidden_dim: the reference takes any width (src/flows/flows.py:26-41; its own grid lists 4, 6, 8, 10, 12:
+// example/slam/manhattan_world_with_range/lawnmower_4x4/run_nfisam.py:5-6), the kernels are instantiated for 4, 8 and 16.  A
+// width-H conditioner IS the next compiled width with zero rows / columns: a padded hidden unit has zero in-weights and bias
+// (h = tanh(0) = 0 exactly) and zero out-weights, so every gradient that touches it is an exact zero (its activation or the
+// back-propagated signal is a product with 0) and Adam leaves m = v = theta = 0 there -- the padding stays zero for the whole
+// fit (asserted in tests/test_hip_parity.py).  Every entry point maps H to the compiled width first; the kernel layout of a
+// width-H model is the compiled width's, `nfisam_nsf_param_count` / `nfisam_nsf_layout_map` keep the reference's counts and order.
+static inline int compiled_H(int H) { return H < 1 ? H : (H <= 4 ? 4 : (H <= 8 ? 8 : (H <= 16 ? 16 : H))); }
+extern "C" int nfisam_nsf_supported(int K, int H) { return find_ops(K, compiled_H(H)) != nullptr ? 1 : 0; }
 
 static size_t torch_block(int i, int K, int H) {
     const size_t Po = 3 * (size_t)K - 1;
@@ -461,23 +469,24 @@ extern "C" size_t nfisam_nsf_param_count(int D, int K, int H) {
 }
 extern "C" size_t nfisam_nsf_kparam_count(int D, int K, int H) {
     if (D < 1 || K < 1 || H < 1) return 0;
-    return kcount(D, K, H);
+    return kcount(D, K, compiled_H(H));
 }
 extern "C" int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map) {
     if (D < 1 || K < 1 || H < 1 || map == nullptr) return NFISAM_ERR_ARG;
     const int Po = 3 * K - 1, PoP = pop_of(K);
-    const size_t Pk = kcount(D, K, H);
+    const int Hc = compiled_H(H);                              // row / column stride of the kernel layout; units H..Hc-1 are padding
+    const size_t Pk = kcount(D, K, Hc);
     for (size_t j = 0; j < Pk; ++j) map[j] = -1;
     for (int o = 0; o < Po; ++o) map[out_col(K, o)] = o;
     size_t toff = Po, koff = PoP;
     for (int i = 1; i < D; ++i) {
         const size_t tW0 = toff, tb0 = tW0 + (size_t)H * i, tW1 = tb0 + H, tb1 = tW1 + (size_t)H * H,
                      tW2 = tb1 + H, tb2 = tW2 + (size_t)Po * H;
-        const size_t kW0 = koff, kb0 = kW0 + (size_t)i * H, kW1 = kb0 + H, kb1 = kW1 + (size_t)H * H,
-                     kW2 = kb1 + H, kb2 = kW2 + (size_t)H * PoP;
-        for (int k = 0; k < i; ++k) for (int j = 0; j < H; ++j) map[kW0 + (size_t)k * H + j] = (int32_t)(tW0 + (size_t)j * i + k);
+        const size_t kW0 = koff, kb0 = kW0 + (size_t)i * Hc, kW1 = kb0 + Hc, kb1 = kW1 + (size_t)Hc * Hc,
+                     kW2 = kb1 + Hc, kb2 = kW2 + (size_t)Hc * PoP;
+        for (int k = 0; k < i; ++k) for (int j = 0; j < H; ++j) map[kW0 + (size_t)k * Hc + j] = (int32_t)(tW0 + (size_t)j * i + k);
         for (int j = 0; j < H; ++j) map[kb0 + j] = (int32_t)(tb0 + j);
-        for (int k = 0; k < H; ++k) for (int j = 0; j < H; ++j) map[kW1 + (size_t)k * H + j] = (int32_t)(tW1 + (size_t)j * H + k);
+        for (int k = 0; k < H; ++k) for (int j = 0; j < H; ++j) map[kW1 + (size_t)k * Hc + j] = (int32_t)(tW1 + (size_t)j * H + k);
         for (int j = 0; j < H; ++j) map[kb1 + j] = (int32_t)(tb1 + j);
         for (int k = 0; k < H; ++k) for (int o = 0; o < Po; ++o) map[kW2 + (size_t)k * PoP + out_col(K, o)] = (int32_t)(tW2 + (size_t)o * H + k);
         for (int o = 0; o < Po; ++o) map[kb2 + out_col(K, o)] = (int32_t)(tb2 + o);
@@ -490,6 +499,7 @@ extern "C" int nfisam_nsf_layout_map(int D, int K, int H, int32_t* map) {
 extern "C" int nfisam_nsf_forward(const float* x, const float* kparams, int n, int D, int K, int H, float B,
                                   int L, size_t layer_stride, float* z, float* logdet, float* logprob,
                                   nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     // an empty batch may come with null data pointers
     if ((n != 0 && x == nullptr) || kparams == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0)) return NFISAM_ERR_ARG;
     if (layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
@@ -503,6 +513,7 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
                                   int K, int H, float B, int L, size_t layer_stride, const float* mean,
                                   const float* stdv, const uint8_t* circular, float* x_out, float* logdet,
                                   nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (D >= 1 && layer_stride != 0 && layer_stride < kcount(D, K, H)) return NFISAM_ERR_ARG;
     if ((n != 0 && (z == nullptr || x_out == nullptr)) || kparams == nullptr || n < 0 || D < 1 || Ds < 0 || Ds >= D || L < 1 ||
         !(B > 0) || (Ds > 0 && x_sep == nullptr) || (mean != nullptr && stdv == nullptr))
@@ -517,6 +528,7 @@ extern "C" int nfisam_nsf_inverse(const float* z, const float* x_sep, const floa
 extern "C" int nfisam_nsf_posterior_walk(const nfisam_post_clique* table, int n_cliques, const int32_t* cols,
                                          const float* obs, int max_D, int K, int H, float B, int L, int n,
                                          const float* Zt, float* St, nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (table == nullptr || cols == nullptr || Zt == nullptr || St == nullptr || n_cliques < 0 || n < 0 || max_D < 1 ||
         L < 1 || !(B > 0))
         return NFISAM_ERR_ARG;
@@ -565,6 +577,7 @@ static bool pair_h4_fits(int L, int max_D) {
 extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, int D, int K, int H, float B, int L,
                                    size_t layer_stride, const float* gz, const float* gl, int nll_mode, float* kgrad,
                                    float* gx, float* loss_sum, nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (D >= 1 && layer_stride != 0 && (layer_stride < kcount(D, K, H) || (layer_stride & 3) != 0)) return NFISAM_ERR_ARG;
     if ((n != 0 && x == nullptr) || kparams == nullptr || kgrad == nullptr || n < 0 || D < 1 || L < 1 || !(B > 0) ||
         (!nll_mode && gz == nullptr))
@@ -601,6 +614,7 @@ static bool use_slabs(int max_n, int tile) { return (max_n + tile - 1) / tile <=
 // Upper bound over both kernel families (the launch shape is picked per launch; several tiles per block only
 // lower the number of copies).
 extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, int L) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (n < 1 || D < 1 || K < 1 || H < 1 || L < 1) return 0;
     const size_t tiles = use_slabs(n, TILE2) ? (size_t)((n + TILE2 - 1) / TILE2)
                                              : (use_slabs(n, TILE) ? (size_t)((n + TILE - 1) / TILE) : 1);
@@ -702,8 +716,14 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 // 53 KB, i.e. D <= ~20, two beyond; H = 16: 256 VGPRs, two), of which a launch may take 7/8 -- the dispatcher is not asked to
 // pack perfectly, and a block of another kernel may sit on a CU for a while.  Other PROCESSES on the device are not seen by
 // this count; what protects against them is the barrier's timeout.  NFISAM_PERSIST=0: never.
+static inline double mono_seconds() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 static std::atomic<bool> g_persist_broken{false};     // a persistent launch of this process stalled once: never again (nfisam_nsf_train_plan_run)
-static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L) {
+static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, int max_D, int K, int H, int L,
+                          long* blocks_out = nullptr, long* places_out = nullptr) {
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
     if (!on || g_persist_broken.load() || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
@@ -730,7 +750,86 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
     }
     long limit = places - places / 8;
     if (const char* e = getenv("NFISAM_PERSIST_BLOCKS")) limit = atol(e);    // (measurement aid)
+    if (blocks_out != nullptr) *blocks_out = blocks;
+    if (places_out != nullptr) *places_out = places;
     return blocks <= limit;
+}
+
+// ---- "probe before persisting" -----------------------------------------------------------------------------------------------
+// The occupancy API answers for THIS process.  A second process on the device (two ranks sharing a GPU, somebody else's job)
+// is invisible to it, and a persistent launch whose late blocks queue behind a foreign kernel spins until its members give
+// up (NFISAM_ERR_STALL: a lost fit).  So before a plan takes the chunk-persistent form the device is ASKED, once: a launch of
+// as many trivial blocks as the plan's launch has -- 256 threads and the LDS footprint that limits a CU to the same number
+// of blocks -- in which every block arrives at a counter and waits until all have arrived or ~200 us of wall clock
+// (s_memrealtime, 100 MHz) have passed.  All there in time: the device holds that many blocks of ours at once right now.
+// A block that times out says so; the plan then keeps to one launch per iteration (same bits).  The answer is cached per
+// device for half a second (replica schedulers create plans by the hundred); NFISAM_PERSIST_PROBE=0 skips the probe.
+// A point-in-time answer by construction: what protects a run against a neighbour that arrives LATER is the timeout above.
+__global__ void __launch_bounds__(256) nsf_coresidency_probe_kernel(unsigned* ctr, unsigned n_blocks, unsigned budget_ticks) {
+    extern __shared__ float probe_lds[];
+    if (threadIdx.x != 0) return;
+    probe_lds[0] = 0.0f;                                         // (the LDS allocation is what makes the footprint: keep it referenced)
+    __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_blocks) break;
+        if (__hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;       // somebody gave up: everybody leaves
+        if (wall_clock64() - t0 > (unsigned long long)budget_ticks) {
+            __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+// -> true: `blocks` blocks of `per_cu` per compute unit are resident at once right now (or the probe is switched off / failed to run:
+// the occupancy answer stands)
+static bool device_is_quiet(long blocks, long places) {
+    static const bool on = !(getenv("NFISAM_PERSIST_PROBE") != nullptr && getenv("NFISAM_PERSIST_PROBE")[0] == '0');
+    if (!on || blocks < 1 || places < 1) return true;
+    static std::mutex mu;
+    struct Seen { int dev; long blocks; double at; bool quiet; };
+    static std::vector<Seen> seen;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const double now = mono_seconds();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Seen& q : seen)
+            if (q.dev == dev && now - q.at < 0.5 && (q.quiet ? q.blocks >= blocks : q.blocks <= blocks)) return q.quiet;
+    }
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return true;
+    const long per_cu = places / prop.multiProcessorCount;
+    if (per_cu < 1) return true;
+    // LDS per block such that per_cu blocks fit a CU's 160 KB and per_cu + 1 do not
+    size_t lds = (size_t)(160 * 1024) / (size_t)(per_cu + 1) + 1024;
+    if (lds > (size_t)(160 * 1024) / (size_t)per_cu) lds = (size_t)(160 * 1024) / (size_t)per_cu;
+    lds &= ~(size_t)255;
+    bool quiet = true;
+    unsigned* ctr = nullptr;
+    hipStream_t st = nullptr;
+    if (hipFuncSetAttribute((const void*)nsf_coresidency_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipMalloc((void**)&ctr, 2 * sizeof(unsigned)) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+        hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned), st) == hipSuccess) {
+        hipLaunchKernelGGL(nsf_coresidency_probe_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctr, (unsigned)blocks, 20000u);
+        unsigned out[2] = {0u, 0u};
+        if (hipGetLastError() == hipSuccess && hipMemcpyAsync(out, ctr, sizeof(out), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess)
+            quiet = out[1] == 0u;
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (ctr) (void)hipFree(ctr);
+    if (!quiet) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "nfisam: the device did not hold %ld blocks of this process at once (another process is using it): "
+                            "training plans keep to one launch per iteration while that lasts\n", blocks);
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t q = 0; q < seen.size();)
+        if (seen[q].dev == dev && now - seen[q].at >= 0.5) seen.erase(seen.begin() + (long)q); else ++q;
+    seen.push_back(Seen{dev, blocks, now, quiet});
+    return quiet;
 }
 
 // iteration `iter_idx` of the current chunk: gradient kernel + Adam kernel
@@ -832,6 +931,7 @@ static int plan_chains(int n_cliques, int max_n, int max_D, int K, int H, int L)
 }
 
 extern "C" int nfisam_nsf_train_chains(int n_cliques, int max_n, int max_D, int K, int H, int L) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !nfisam_nsf_supported(K, H)) return 1;
     return plan_chains(n_cliques, max_n, max_D, K, H, L);
 }
@@ -839,6 +939,7 @@ extern "C" int nfisam_nsf_train_chains(int n_cliques, int max_n, int max_D, int 
 extern "C" int nfisam_nsf_train_gradient_part(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
                                               int max_D, int K, int H, float B, int L, int chain, int n_chains,
                                               nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
         !nfisam_nsf_supported(K, H) || n_chains < 1 || chain < 0 || chain >= n_chains)
         return NFISAM_ERR_ARG;
@@ -855,6 +956,7 @@ extern "C" int nfisam_nsf_train_gradient_part(const nfisam_clique* cliques, int 
 
 extern "C" int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
                                          int max_D, int K, int H, float B, int L, nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
         !nfisam_nsf_supported(K, H))
         return NFISAM_ERR_ARG;
@@ -868,6 +970,7 @@ extern "C" int nfisam_nsf_train_gradient(const nfisam_clique* cliques, int n_cli
 extern "C" int nfisam_nsf_train_step(const nfisam_clique* cliques, int n_cliques, int cliques_on_host, int max_n,
                                      int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
                                      nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     int rc = check_cfg(cfg, K, H, L, B);
     if (rc) return rc;
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1) return NFISAM_ERR_ARG;
@@ -970,6 +1073,7 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
 extern "C" int nfisam_nsf_train_plan_create(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
                                             int n_cliques, int K, int H, float B, int L,
                                             const nfisam_adam_cfg* cfg, int use_graph, nfisam_train_plan** out) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     return plan_create_impl(host_cliques, dev_cliques, n_cliques, K, H, B, L, cfg, nullptr, 0, 0.0f, use_graph, out);
 }
 
@@ -977,6 +1081,7 @@ extern "C" int nfisam_nsf_train_plan_create_validated(const nfisam_clique* host_
                                                       int n_cliques, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
                                                       const nfisam_validation* val, int validation_interval,
                                                       float slower_stop_rate, int use_graph, nfisam_train_plan** out) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     // the scheduled end int(rate x (i + 1)) must fall on a period boundary: whole-number rates (the reference's default is 2.0)
     if (val == nullptr || validation_interval < 1 || validation_interval > LOSS_RING + 1 || !(slower_stop_rate >= 1.0f) ||
         slower_stop_rate != (float)(int)slower_stop_rate)
@@ -1048,7 +1153,10 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
             if (e == hipSuccess) { p->side.push_back(st); e = hipEventCreateWithFlags(&ev2, hipEventDisableTiming); }
             if (e == hipSuccess) p->side_ev.push_back(ev2);
         }
-        const bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L) && p->chunk > (p->val.empty() ? 1 : 2);
+        long p_blocks = 0, p_places = 0;
+        bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L, &p_blocks, &p_places) && p->chunk > (p->val.empty() ? 1 : 2);
+        // probe before persisting (device_is_quiet): is the device ours right now?  (outside the capture below)
+        if (can_persist && !device_is_quiet(p_blocks, p_places)) can_persist = false;
         for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
         const bool persist = pass == 1;
         hipGraph_t* graph_out = persist ? &p->graph_p : &p->graph;
@@ -1134,23 +1242,34 @@ static int enqueue_validated_period(const nfisam_train_plan* p, hipStream_t s, b
 }
 
 // Waits until the bookkeeping kernel of chunk number `k` (1-based, this run) has written every clique's mirror.  The
-// device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms: the host spins for the first
-// ~50 us (the common case at the end of a short chunk), then sleeps 20 us between looks so that a worker thread or a rank
-// of a parallel run does not hold a core at 100 % for the whole fit; every ~65 k looks the WORK stream -- the one the
-// chunk was enqueued on, which for plans without a graph is the caller's -- is queried for a launch failure, and after
-// ~60 s without progress the wait gives up (-> `poisoned`: the caller must not synchronise a wedged stream either).
+// device publishes the sequence word last (system-scope release); a chunk takes 0.1-1 ms.  All bounds are TIMES
+// (CLOCK_MONOTONIC), not look counts: the host pause-spins for the first ~50 us (the common case at the end of a short
+// chunk), yields (`sched_yield`: free when nobody else wants the core -- a timed sleep costs ~70 us of timer slack per look,
+// 5 % of the driver's 0.3 ms 20-step plan) up to 2 ms, and from then on sleeps 50 us between looks, so that a worker thread or a
+// rank of a parallel run does not hold a core for the whole of a slow chunk; every ~20 ms the WORK stream -- the one the
+// chunk was enqueued on, which for plans without a graph is the caller's -- is queried for a launch failure, and after 60 s
+// without progress the wait gives up (-> `poisoned`: the caller must not synchronise a wedged stream either).
 static int wait_chunk(const nfisam_train_plan* p, int k, hipStream_t work, bool* poisoned) {
     const volatile nfisam_train_state* m = p->hst;
     const struct timespec nap = {0, 50000};
+    static const double give_up_s = getenv("NFISAM_WAIT_SECONDS") != nullptr ? atof(getenv("NFISAM_WAIT_SECONDS")) : 60.0;   // (test knob)
+    double t0 = 0.0, last_query = 0.0;
     for (long looks = 0;; ++looks) {
         bool all = true;
         for (int c = 0; c < p->n_cliques; ++c)
             if (m[c].reserved[0] < k) { all = false; break; }
         if (all) break;
-        if (looks > 3000000L) { *poisoned = true; return NFISAM_ERR_LAUNCH; }
-        if ((looks & 0xffff) == 0xffff && hipStreamQuery(work) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
-        if (looks < 4000) __builtin_ia32_pause();
-        else if (looks < 200000) sched_yield();
+        if (looks < 256) { __builtin_ia32_pause(); continue; }         // (~10 us before the first clock read)
+        const double now = mono_seconds();
+        if (t0 == 0.0) { t0 = now; last_query = now; }
+        const double waited = now - t0;
+        if (waited > give_up_s) { *poisoned = true; return NFISAM_ERR_LAUNCH; }
+        if (now - last_query > 0.02) {
+            last_query = now;
+            if (hipStreamQuery(work) == hipErrorLaunchFailure) return NFISAM_ERR_LAUNCH;
+        }
+        if (waited < 50e-6) __builtin_ia32_pause();
+        else if (waited < 2e-3) sched_yield();
         else nanosleep(&nap, nullptr);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1440,6 +1559,7 @@ extern "C" int nfisam_nsf_train_plan_end(nfisam_train_plan* p, nfisam_stream_t s
 extern "C" int nfisam_nsf_train_loop(const nfisam_clique* host_cliques, const nfisam_clique* dev_cliques,
                                      int n_cliques, int K, int H, float B, int L, const nfisam_adam_cfg* cfg,
                                      int use_graph, int32_t* iters_run, nfisam_stream_t stream) {
+    H = compiled_H(H);                                        // any hidden_dim <= 16: the next compiled width, zero-padded
     nfisam_train_plan* p = nullptr;
     int rc = nfisam_nsf_train_plan_create(host_cliques, dev_cliques, n_cliques, K, H, B, L, cfg, use_graph, &p);
     if (rc) return rc;

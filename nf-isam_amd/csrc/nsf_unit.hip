@@ -16,6 +16,7 @@
 #include <stddef.h>
 #include <type_traits>
 #include <vector>
+#include <mutex>
 
 #include "nsf_host.h"
 #include "nsf_cond_mfma.h"
@@ -3283,6 +3284,9 @@ struct PanelMap {
         return NFISAM_OK;
     }
 };
+template <int KK, int HH, bool PERSIST> static bool lean_launch_fits(long blocks, int max_D);
+template <int KK, int HH> constexpr bool lean_plain_v = HH <= 8 && KK > NSF_PLAIN_MAX_K3;
+template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PERSIST_MAX_K3;
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4 || HH == 16) {
@@ -3290,6 +3294,9 @@ static int unit_prepare(int max_D) {
             const int rc = PairMap<KK, HH>::get(nullptr, nullptr);
             if (rc) return rc;
         }
+        // (the occupancy answers the launcher will want: asked here, outside the capture of the plan's graph)
+        if constexpr (lean_persist_v<KK, HH>) (void)lean_launch_fits<KK, HH, true>(1, max_D);
+        if constexpr (lean_plain_v<KK, HH>) (void)lean_launch_fits<KK, HH, false>(1, max_D);
         return max_D <= PANEL_MAP_MAX_D ? PanelMap<KK, HH>::get(max_D, nullptr) : NFISAM_OK;
     } else {
         return NFISAM_OK;
@@ -3321,26 +3328,33 @@ static long unit_persist_places(int max_D) {
     }
 }
 // the LEAN instantiations (two waves per SIMD, no scratch) exist for the (K, H) pairs whose three-wave build spills
-template <int KK, int HH> constexpr bool lean_plain_v = HH <= 8 && KK > NSF_PLAIN_MAX_K3;
-template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PERSIST_MAX_K3;
+// (lean_plain_v / lean_persist_v: declared in front of unit_prepare)
 // does a launch of `blocks` four-wave blocks fit the device at the lean build's occupancy (all resident: nothing gained by a
 // third wave per SIMD)?  Cached per max_D; the chunk-persistent form keeps the 1/8 margin of persist_shape (nsf_kernels.hip).
 template <int KK, int HH, bool PERSIST>
 static bool lean_launch_fits(long blocks, int max_D) {
-    static long places[2][FUSED_COUNTERS + 1] = {};
-    static int devs[2][FUSED_COUNTERS + 1] = {};
+    // places[device][max_D] (0: not asked yet, -1: none), under a lock: replica worker threads and multi-device processes
+    // ask concurrently.  Warmed by unit_prepare (plan creation, OUTSIDE any stream capture: the first query per key calls
+    // hipGetDeviceProperties and the occupancy API).
+    constexpr int MAXDEV = 16;
+    static std::mutex mu;
+    static long places[MAXDEV][FUSED_COUNTERS + 1] = {};
     if (max_D < 1 || max_D > FUSED_COUNTERS) return false;
     const char* le = getenv("NFISAM_LEAN");                  // "0": never (A/B, tests; read per call)
     if (le != nullptr && le[0] == '0') return false;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    long& pl = places[PERSIST ? 1 : 0][max_D];
-    int& pd = devs[PERSIST ? 1 : 0][max_D];
-    if (pl == 0 || pd != dev + 1) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return false;
+    long pl;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        pl = places[dev][max_D];
+    }
+    if (pl == 0) {
         if constexpr (PERSIST) pl = resident_blocks(nsf_train1_kernel<KK, HH, true, true>, train1_lds_bytes<KK, HH>(max_D, 4, true));
         else pl = resident_blocks(nsf_train1_plain_kernel<KK, HH, true>, train1_lds_bytes<KK, HH>(max_D, 4, false));
         if (pl <= 0) pl = -1;
-        pd = dev + 1;
+        std::lock_guard<std::mutex> lk(mu);
+        places[dev][max_D] = pl;
     }
     return pl > 0 && blocks <= (PERSIST ? pl - pl / 8 : pl);
 }
@@ -3416,7 +3430,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
             for (int c = 0; c < n_cliques && hc != nullptr; ++c) blocks += (long)hc[c].D * ((hc[c].n + 4 * TILE - 1) / (4 * TILE));
             a.persist_split = (se != nullptr) ? (se[0] == '1') : (blocks > 256);
         }
-        static const int spin_log2 = getenv("NFISAM_PERSIST_SPINS") != nullptr ? atoi(getenv("NFISAM_PERSIST_SPINS")) : 22;           // (test knob)
+        static const int spin_log2 = getenv("NFISAM_PERSIST_SPINS") != nullptr ? atoi(getenv("NFISAM_PERSIST_SPINS")) : 15;           // (~1 us per look: a member that never arrives costs tens of milliseconds, not seconds -- round 4: 22)
         a.persist_spins = spin_log2 < 1 ? 1 : (spin_log2 > 30 ? 30 : spin_log2);
         static const bool drop = getenv("NFISAM_PERSIST_DROP") != nullptr && getenv("NFISAM_PERSIST_DROP")[0] == '1';                  // (test knob)
         static const bool scatter = getenv("NFISAM_PERSIST_SCATTER") != nullptr && getenv("NFISAM_PERSIST_SCATTER")[0] == '1';   // (test knob)

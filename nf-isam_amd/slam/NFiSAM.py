@@ -314,7 +314,7 @@ class NFiSAM(FactorGraphSolver):
             raise NotImplementedError("Unknown flow type for the pipeline")
         if not _nh.supported(a.num_knots, a.hidden_dim):
             raise ValueError("num_knots=%r, hidden_dim=%r: the gfx950 kernels are instantiated for num_knots in 2..16 and "
-                             "hidden_dim in {4, 8, 16} (nf-isam_amd/csrc/nsf_units.h)" % (a.num_knots, a.hidden_dim))
+                             "hidden_dim in 1..16 (compiled widths 4, 8, 16; others zero-padded: nf-isam_amd/csrc/nsf_units.h)" % (a.num_knots, a.hidden_dim))
         if int(a.flow_number) < 1:
             raise ValueError("flow_number must be >= 1")
         import threading
@@ -529,27 +529,38 @@ class NFiSAM(FactorGraphSolver):
         # int(slower_stop_rate x (i + 1)) falls on a period boundary -- whole-number rates, the reference's default is 2.0;
         # other settings are stepped from the host, iteration by iteration.
         on_device = float(a.slower_stop_rate).is_integer() and a.slower_stop_rate >= 1 and 1 <= int(a.validation_interval) <= 129
-        if on_device:
-            tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
-                                early_stop=False, x_val=[x_val], validation_interval=a.validation_interval,
-                                slower_stop_rate=a.slower_stop_rate)
-            prep["iters"] = tb.run(use_graph=True)[0]
-            if prep["iters"] < a.flow_iterations:
-                logger.info(f"Slower stop at iter {prep['iters'] + 1}")
-            self.last_validation_losses = tb.val_loss[0]
-        else:
-            tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
-                                average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
-            f0 = NSF_AR.from_kernel_params(prep["D"], K, B, H, prep["kp0"])
-            prep["iters"] = self._fit_with_validation(tb, x_val, f0, logger)
-        torch.cuda.synchronize()
-        if timer is not None:
-            timer.append(time.time() - opt_start)
-        prep["trained"] = tb.kparams[0]
-        prep["iter_loss"] = tb.iter_loss[0]
-        model = self.finish_fit(prep)
-        tb.close()
-        return model
+        kp_init = prep["kp0"].clone()                  # (the plan trains prep["kp0"] in place)
+        tb = None
+        try:
+            if on_device:
+                tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                                    early_stop=False, x_val=[x_val], validation_interval=a.validation_interval,
+                                    slower_stop_rate=a.slower_stop_rate)
+                try:
+                    prep["iters"] = tb.run(use_graph=True)[0]
+                except _nh.PersistentStall:
+                    # as in `_train_prepared_locked`: not a numerical event -- the SAME fit runs again from its initial state
+                    # (the library keeps to one launch per iteration from now on: same bits)
+                    logger.warning("a chunk-persistent training launch stalled: re-running the hold-out fit with one launch per iteration")
+                    tb.reset(kparams=[kp_init])
+                    prep["iters"] = tb.run(use_graph=True)[0]
+                if prep["iters"] < a.flow_iterations:
+                    logger.info(f"Slower stop at iter {prep['iters'] + 1}")
+                self.last_validation_losses = tb.val_loss[0]
+            else:
+                tb = _nh.TrainBatch([x_dev], [prep["kp0"]], K, H, B, L, lr=a.learning_rate, max_iters=a.flow_iterations,
+                                    average_window=a.average_window, loss_delta_tol=a.loss_delta_tol, early_stop=False)
+                f0 = NSF_AR.from_kernel_params(prep["D"], K, B, H, prep["kp0"])
+                prep["iters"] = self._fit_with_validation(tb, x_val, f0, logger)
+            torch.cuda.synchronize()
+            if timer is not None:
+                timer.append(time.time() - opt_start)
+            prep["trained"] = tb.kparams[0]
+            prep["iter_loss"] = tb.iter_loss[0]
+            return self.finish_fit(prep)
+        finally:
+            if tb is not None:
+                tb.close()
 
     def _fit_with_validation(self, tb, testing_data, f0, logger):
         """training_set_frac < 1: hold-out early stopping (reference: NFiSAM.py:452-468)."""

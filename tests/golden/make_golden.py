@@ -64,6 +64,11 @@ CASES = {
     "n96_d5_k3_h4": (96, 5, 3, 5, 4),
     "n80_d7_k15_h16": (80, 7, 15, 6, 16),
     "n64_d4_k15_h8": (64, 4, 15, 7, 8),   # num_knots=15: toy_examples/R2RangeGaussian_example/...incremental.py:85
+    # hidden widths that are NOT a compiled kernel width (round 5: zero-padded into 8 / 16); the reference's own grid is
+    # hidden_dims = [4, 6, 8, 10, 12]: example/slam/manhattan_world_with_range/lawnmower_4x4/run_nfisam.py:5-6
+    "n72_d6_k9_h6": (72, 6, 9, 8, 6),
+    "n100_d9_k12_h12": (100, 9, 12, 9, 12),
+    "n70_d5_k9_h10": (70, 5, 9, 10, 10),
 }
 
 
@@ -474,6 +479,10 @@ def gen_validation_loop():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "validation":
         gen_validation_loop()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "flow":          # only the named flow cases
+        for name in sys.argv[2:]:
+            gen_flow_case(name, *CASES[name])
         sys.exit(0)
     for name, spec in CASES.items():
         gen_flow_case(name, *spec)

@@ -72,6 +72,22 @@ CASES = {
                   cuda_training=False, elimination_method="pose_first", posterior_sample_num=500,
                   store_clique_samples=False), 500, 400, 8),
 }
+# ---- round 5: LONG-HORIZON fixtures -----------------------------------------------------------------------------------------
+# (i) structural, EVERY update of the large datasets with flow_iterations = 20 (the fit is irrelevant to the structure: which
+#     cliques are retrained, their column patterns, D / D_s, true observations, the elimination ordering and every firing of
+#     `root_clique_density_model_to_leaf`, NFiSAM.py:550-577 / FactorGraphSolver.py:306-340); one seed, no samples stored.
+# (ii) distributional, late: Manhattan-136 COMPLETE at the reference's own budget (500 fixed iterations), posteriors kept
+#     at updates 20 / 60 / 135 only.
+# name: base case, updates (None = all), kwargs override, steps whose posterior is kept (None: none), seeds
+LONG_CASES = {
+    "plaza1_structure": ("plaza1", None, dict(flow_iterations=20), None, 1),
+    "plaza1ada_structure": ("plaza1ada", None, dict(flow_iterations=20), None, 1),
+    "manhattan136_structure": ("manhattan136", None, dict(flow_iterations=20), None, 1),
+    "manhattan136_full": ("manhattan136", None, dict(), (20, 60, 135), 3),
+}
+for _name, (_base, _upd, _over, _keep, _seeds) in LONG_CASES.items():
+    _b = CASES[_base]
+    CASES[_name] = (_b[0], _b[1], _b[2], _upd, dict(_b[4], **_over), _b[5], 0, _seeds)
 
 STUB = '''
 from abc import ABCMeta
@@ -139,6 +155,7 @@ def worker(case, seed, out_path):
     """One reference run (own process, PYTHONHASHSEED=0)."""
     import random
     ref_dir, graph_file, step, updates, kwargs, n_post, n_batch, _ = CASES[case]
+    keep_steps = LONG_CASES[case][3] if case in LONG_CASES else "all"
     tmp = tempfile.mkdtemp(prefix="nfisam_ref_")
     try:
         write_stubs(os.path.join(tmp, "stubs"))
@@ -162,15 +179,27 @@ def worker(case, seed, out_path):
                                                   prior_cov_scale=0.1)
         steps = group_nodes_factors_incrementally(nodes=nodes, factors=factors, incremental_step=step)[:updates]
         solver = RN.NFiSAM(RN.NFiSAMArgs(**kwargs))
-        fits, update_no = [], [0]
+        fits, update_no, reuses = [], [0], []
         orig_fit = RN.NFiSAM.fit_clique_density_model
         orig_update = RN.NFiSAM.update_physical_and_working_graphs
+        orig_reuse = RN.NFiSAM.root_clique_density_model_to_leaf
+
+        def reuse(self, old_clique, new_clique, device, *a, **k):
+            # FactorGraphSolver.py:306-340: last update's root became a leaf with the same variable ordering
+            reuses.append(dict(update=update_no[0] - 1, vars=sorted(v.name for v in new_clique.vars),
+                               old_frontal=sorted(v.name for v in old_clique.frontal),
+                               new_frontal=sorted(v.name for v in new_clique.frontal),
+                               new_separator=sorted(v.name for v in new_clique.separator)))
+            return orig_reuse(self, old_clique, new_clique, device, *a, **k)
+        RN.NFiSAM.root_clique_density_model_to_leaf = reuse
 
         def fit(self, clique, samples, var_ordering, timer, *a, **k):
             true_obs = self._clique_true_obs[clique]
             rows = np.random.RandomState(len(fits)).permutation(samples.shape[0])[:n_batch]
             fits.append(dict(update=update_no[0] - 1, vars=[v.name for v in var_ordering],
                              frontal=sorted(v.name for v in clique.frontal), dims=[int(v.dim) for v in var_ordering],
+                             separator=sorted(v.name for v in clique.separator), D=int(np.asarray(samples).shape[1]),
+                             Ds=int(np.asarray(samples).shape[1] - sum(int(v.dim) for v in clique.frontal)),
                              true_obs=np.asarray(true_obs, dtype=np.float64), batch=np.asarray(samples)[rows].astype(np.float32)))
             res = orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
             name = "".join(v.name for v in clique.vars)                       # NFiSAM.py:496-497: zero-padded loss record
@@ -186,18 +215,22 @@ def worker(case, seed, out_path):
         RN.NFiSAM.update_physical_and_working_graphs = update
         FGS.run_incrementally(case_dir, solver, steps, truth, False, {"show_plot": False}, False)
         run_dir = os.path.join(case_dir, "run1")
-        out = {"n_fits": len(fits), "n_steps": len(steps)}
+        out = {"n_fits": len(fits), "n_steps": len(steps), "reuses": np.array(json.dumps(reuses))}
         for i in range(len(steps)):
-            X = np.loadtxt(os.path.join(run_dir, "step%d" % i))
             names = open(os.path.join(run_dir, "step%d_ordering" % i)).read().split()
+            out["step%d_ordering" % i] = np.array(names)
+            if keep_steps != "all" and (keep_steps is None or i not in keep_steps):
+                continue
+            X = np.loadtxt(os.path.join(run_dir, "step%d" % i))
             rows = np.random.RandomState(1000 + i).permutation(X.shape[0])[:n_post]
             out["step%d_samples" % i] = X[rows].astype(np.float32)
-            out["step%d_ordering" % i] = np.array(names)
         for j, f in enumerate(fits):
             out["fit%d_meta" % j] = np.array(json.dumps(dict(update=f["update"], vars=f["vars"], frontal=f["frontal"], dims=f["dims"],
+                                                                separator=f["separator"], D=f["D"], Ds=f["Ds"],
                                                                 iterations=f.get("iterations", -1), final_loss=f.get("final_loss"))))
             out["fit%d_true_obs" % j] = f["true_obs"]
-            out["fit%d_batch" % j] = f["batch"]
+            if n_batch:
+                out["fit%d_batch" % j] = f["batch"]
         out["timing"] = np.array([float(t) for t in open(os.path.join(run_dir, "step_timing")).read().split()])
         np.savez_compressed(out_path, **out)
     finally:
@@ -227,7 +260,7 @@ def reference_held(case):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if c not in LONG_CASES])
     ap.add_argument("--seeds", type=int, default=0, help="0 = the case's default")
     ap.add_argument("--jobs", type=int, default=4)
     ap.add_argument("--worker", nargs=3, metavar=("CASE", "SEED", "OUT"))

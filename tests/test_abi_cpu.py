@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nh.EXPORTS), declared ^ set(nh.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfisam_abi_version() == 1400
+    assert lib.nfisam_abi_version() == 1500
 
 
 def test_struct_sizes_match_header(tmp_path):
@@ -106,7 +106,38 @@ def test_compute_entry_points_refuse_cpu_tensors():
 
 def test_supported_instantiations():
     assert nh.supported(9, 8) and nh.supported(5, 8) and nh.supported(12, 8)
-    assert not nh.supported(9, 7)
+    # every hidden_dim up to 16 (the reference takes any width, src/flows/flows.py:26-41): the next compiled width, zero-padded
+    assert all(nh.supported(9, H) for H in range(1, 17)) and not nh.supported(9, 17) and not nh.supported(17, 8)
+
+
+def test_uncompiled_hidden_widths_are_zero_padded_into_the_next_compiled_width():
+    """hidden_dim 6 / 12 (the reference's own grid: example/slam/manhattan_world_with_range/lawnmower_4x4/run_nfisam.py:5-6)
+    live in the kernel layout of width 8 / 16: same kernel-parameter count, the reference's parameter count and order, padding
+    entries marked -1 (packed as exact zeros), pack / unpack a bijection on the real entries."""
+    for H, Hc in ((1, 4), (3, 4), (6, 8), (7, 8), (10, 16), (12, 16)):
+        D, K = 5, 9
+        Po = 3 * K - 1
+        P = Po + sum(i * H + H + H * H + H + H * Po + Po for i in range(1, D))
+        assert nh.param_count(D, K, H) == P
+        assert nh.kparam_count(D, K, H) == nh.kparam_count(D, K, Hc)
+        m = nh.layout_map(D, K, H)
+        real = m[m >= 0]
+        assert real.size == P and np.array_equal(np.sort(real), np.arange(P))
+        blob = torch.randn(P)
+        kb = nh.pack(blob, D, K, H)
+        assert kb.numel() == nh.kparam_count(D, K, Hc) and torch.equal(nh.unpack(kb, D, K, H), blob)
+        assert torch.all(kb[torch.from_numpy(m < 0)] == 0)
+        # the same model written as a width-Hc model with zero rows / columns packs to the same kernel blob
+        wide = torch.zeros(nh.param_count(D, K, Hc))
+        t, tw = Po, Po
+        wide[:Po] = blob[:Po]
+        for i in range(1, D):
+            for (r, c, rw, cw) in ((H, i, Hc, i), (H, 1, Hc, 1), (H, H, Hc, Hc), (H, 1, Hc, 1), (Po, H, Po, Hc), (Po, 1, Po, 1)):
+                blk = torch.zeros(rw, cw)
+                blk[:r, :c] = blob[t:t + r * c].reshape(r, c)
+                wide[tw:tw + rw * cw] = blk.reshape(-1)
+                t += r * c; tw += rw * cw
+        assert torch.equal(nh.pack(wide, D, K, Hc), kb)
 
 
 def test_posterior_walk_refuses_a_table_that_would_read_past_the_latent_draws():

@@ -127,6 +127,11 @@ class TestAgainstReferenceGolden:
         tb.step()   # beyond max_iters: must be a no-op
         torch.cuda.synchronize()
         assert tb.state()["step"] == 10
+        # padding of the kernel layout (output-column padding; the zero hidden units of a hidden_dim that is not a compiled
+        # width: goldens h6 / h10 / h12) never moves: parameters and both moments stay exactly 0 there
+        pad = torch.from_numpy(nh.layout_map(D, K, H) < 0).to(DEV)
+        for t in (tb.kparams[0], tb.m[0], tb.v[0]):
+            assert float(t[pad].abs().sum()) == 0.0
 
     def test_inverse(self, path):
         g, n, D, K, H, B = load(path)
@@ -781,6 +786,74 @@ def test_every_kernel_instantiation_against_the_oracle(H):
         tb.close()
 
 
+def _widen(blob, D, K, H, Hc, L=1):
+    """A width-H reference-order blob written as the width-Hc model with zero rows / columns (numpy)."""
+    Po = 3 * K - 1
+    P, Pw = nh.param_count(D, K, H), nh.param_count(D, K, Hc)
+    out = np.zeros(L * Pw, dtype=blob.dtype)
+    for l in range(L):
+        src, dst = blob[l * P:(l + 1) * P], out[l * Pw:(l + 1) * Pw]
+        dst[:Po] = src[:Po]
+        t, tw = Po, Po
+        for i in range(1, D):
+            for (r, c, rw, cw) in ((H, i, Hc, i), (H, 1, Hc, 1), (H, H, Hc, Hc), (H, 1, Hc, 1), (Po, H, Po, Hc), (Po, 1, Po, 1)):
+                blk = np.zeros((rw, cw), dtype=blob.dtype)
+                blk[:r, :c] = src[t:t + r * c].reshape(r, c)
+                dst[tw:tw + rw * cw] = blk.reshape(-1)
+                t += r * c; tw += rw * cw
+    return out
+
+
+@pytest.mark.parametrize("H", [1, 2, 3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15])
+def test_hidden_widths_between_the_compiled_ones_run_zero_padded(H):
+    """`hidden_dim` other than 4 / 8 / 16 (the reference takes any: src/flows/flows.py:26-41; its own grid lists 6, 10, 12:
+    example/slam/manhattan_world_with_range/lawnmower_4x4/run_nfisam.py:5-6) runs as the next compiled width with zero hidden
+    units (ABI 1500).  Against the float64 C oracle AT WIDTH H: forward, NLL gradient, inverse, a 60-iteration training plan
+    (chunk-persistent form, early-stop bookkeeping) for L = 1 and forward / gradient / 5 iterations for L = 2; and the padding
+    of parameters and both Adam moments is EXACTLY zero after training -- a padded unit's activation is tanh(0) = 0 and its
+    out-weights are 0, so every gradient that touches it is a product with an exact zero."""
+    B = 5.0
+    Hc = 4 if H <= 4 else (8 if H <= 8 else 16)
+    assert nh.supported(9, H)
+    for K, n, D in ((9, 300, 6), (12, 130, 3)):
+        pad = torch.from_numpy(nh.layout_map(D, K, H) < 0).to(DEV)
+        for L in (1, 2):
+            blob, x = make_problem(n, D, K, H, L, seed=31 * H + K + L)
+            kp = kpack(blob, D, K, H, L)
+            assert kp.numel() == L * nh.kparam_count(D, K, Hc)
+            assert torch.equal(kp, kpack(_widen(blob, D, K, H, Hc, L), D, K, Hc, L))     # the same kernel blob as the explicit wide model
+            zc, ldc = CO.forward(x, blob, K, H, B, L, dtype=np.float64)
+            z, ld, _ = nh.forward(dev(x), kp, K, H, B, L)
+            np.testing.assert_allclose(z.cpu().numpy(), zc, atol=Z_ATOL * L, err_msg=str((K, H, L)))
+            np.testing.assert_allclose(ld.cpu().numpy(), ldc, atol=LD_ATOL * L, err_msg=str((K, H, L)))
+            lossc, gradc, _, _ = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+            kg, _, loss = nh.backward(dev(x), kp, K, H, B, L, nll_mode=True, want_gx=True)
+            assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L, (K, H, L)
+            grad_close(nh.unpack(kg, D, K, H, L).cpu().numpy() / n, gradc, rtol=2e-3, atol=2e-5 * L)
+            assert float(kg.reshape(L, -1)[:, pad].abs().sum()) == 0.0
+            iters = 60 if L == 1 else 5
+            tb = nh.TrainBatch([dev(x)], [kp.clone()], K, H, B, L, lr=0.01, max_iters=iters, average_window=20, loss_delta_tol=0.0,
+                               early_stop=True)
+            assert tb.run(use_graph=True) == [iters]
+            bc, lc, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.01, max_iters=iters, early_stop=False, dtype=np.float64)
+            np.testing.assert_allclose(tb.iter_loss[0].cpu().numpy()[:iters], lc[:iters], atol=2e-3, rtol=5e-4, err_msg=str((K, H, L)))
+            err = np.abs(nh.unpack(tb.kparams[0], D, K, H, L).cpu().numpy() - bc)
+            assert np.quantile(err, 0.95) < (2e-2 if L == 1 else 2e-3), (K, H, L, np.quantile(err, 0.95), err.max())
+            for t in (tb.kparams[0], tb.m[0], tb.v[0]):
+                assert float(t.reshape(L, -1)[:, pad].abs().sum()) == 0.0, (K, H, L)
+            tb.close()
+        # inverse of forward at width H
+        blob1, x1 = make_problem(n, D, K, H, 1, seed=77 + H)
+        kp1 = kpack(blob1, D, K, H, 1)
+        xb = nh.inverse(nh.forward(dev(x1), kp1, K, H, B, 1)[0], None, kp1, K, H, B, 1)
+        inside = np.abs(x1).max(1) < 4.9
+        np.testing.assert_allclose(xb.cpu().numpy()[inside], x1[inside], atol=3e-3, err_msg=str((K, H)))
+        xo, _ = CO.inverse(x1[:, 2:].copy(), x1[:, :2].copy(), blob1, K, H, B, 1, dtype=np.float64)
+        xg = nh.inverse(dev(x1[:, 2:].copy()), dev(x1[:, :2].copy()), kp1, K, H, B, 1).cpu().numpy()
+        ok = np.abs(xo).max(1) < 4.5
+        np.testing.assert_allclose(xg[ok], xo[ok], atol=3e-3)
+
+
 @pytest.mark.parametrize("H", [8, 16])
 def test_throughput_launch_with_wide_dims_matches_the_tile_major_kernels(H):
     """24 cliques of D = 18..20, n = 2000: the dim-major kernel sweeps several tiles per wave (T > 1) and accumulates the
@@ -1155,7 +1228,7 @@ def test_oversubscribed_persistent_launch_stalls_loudly_and_the_rerun_is_exact(t
     Provoked with a test knob (oversubscribing the machine does not do it: blocks are dispatched in order, 1440 blocks on 768
     places merely ran one behind the other -- measured): NFISAM_PERSIST_DROP=1 makes one block of one (clique, dim) group
     leave at once, like a member whose place is held by a foreign process that never yields; NFISAM_PERSIST_SPINS=12 shortens
-    the wait from 2^22 looks (seconds) to 4096.  The starved group's blocks give up, raise the group's abort flag and leave,
+    the wait from 2^15 looks (tens of milliseconds; round 4: 2^22, seconds) to 4096.  The starved group's blocks give up, raise the group's abort flag and leave,
     the run ends with NFISAM_ERR_STALL (nfisam_hip.PersistentStall), the process switches to one launch per iteration, and
     the same fit run again gives exactly what NFISAM_PERSIST=0 gives."""
     import subprocess, sys
@@ -1174,6 +1247,64 @@ def test_oversubscribed_persistent_launch_stalls_loudly_and_the_rerun_is_exact(t
     assert list(res["forced"]["iters"]) == list(res["plain"]["iters"]) == [100] * 3
     np.testing.assert_array_equal(res["forced"]["params"], res["plain"]["params"])
     np.testing.assert_array_equal(res["forced"]["loss"], res["plain"]["loss"])
+
+
+@pytest.mark.timeout(300)
+def test_a_busy_device_is_probed_before_a_plan_takes_the_persistent_form():
+    """"Probe before persisting" (nsf_kernels.hip: device_is_quiet): the occupancy API answers for this process's kernel alone;
+    whether the device really holds all blocks of a chunk-persistent launch AT ONCE right now is asked with one launch of as
+    many trivial blocks that must all arrive at a counter within ~200 us.  On a quiet device the plan takes the persistent
+    form (`xcd_span() >= 1`: a persistent chunk ran); while somebody else's long kernels fill the compute units (here: big
+    matrix products on a side stream -- a foreign process looks the same to the probe) a NEW plan keeps to one launch per
+    iteration (`xcd_span() == 0`), says so once on stderr, and gives the same bits.  NFISAM_PERSIST_PROBE=0: not asked."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = PROBE_WORKER % dict(root=root)
+    outs = {}
+    for name, env in (("probe", {}), ("no-probe", dict(NFISAM_PERSIST_PROBE="0"))):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = (json.loads(p.stdout.strip().splitlines()[-1]), p.stderr)
+    r, err = outs["probe"]
+    assert r["quiet_span"] >= 1, r                                   # quiet device: the persistent form ran
+    assert r["busy_span"] == 0 and "another process is using it" in err, (r, err[-500:])
+    assert r["equal"] and r["iters"] == [100, 100]
+    r0, _ = outs["no-probe"]
+    assert r0["quiet_span"] >= 1 and r0["busy_span"] >= 1 and r0["equal"], r0     # (own kernels only delay a member: no stall either)
+
+
+PROBE_WORKER = r"""
+import json, sys, time
+sys.path.insert(0, %(root)r + "/nf-isam_amd"); sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import nfisam_hip as nh
+K, H, B = 9, 8, 5.0
+dev = torch.device("cuda", 0)
+gen = torch.Generator().manual_seed(5)
+x = (1.2 * torch.randn(2000, 15, generator=gen)).clamp_(-4, 4).to(dev)
+kp0 = nh.pack((0.2 * torch.randn(nh.param_count(15, K, H), generator=gen)).to(dev), 15, K, H, 1)
+def fit():
+    tb = nh.TrainBatch([x], [kp0.clone()], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
+    tb.prepare(True)                      # <- the probe runs here (plan creation)
+    it = tb.run()
+    torch.cuda.synchronize()
+    out = (tb.xcd_span(), it[0], tb.kparams[0].cpu().numpy().copy(), tb.iter_loss[0].cpu().numpy().copy())
+    tb.close()
+    return out
+quiet = fit()
+time.sleep(0.6)                           # (the probe's answer is cached for half a second)
+side = torch.cuda.Stream()
+a = torch.randn(8192, 8192, device=dev)
+torch.cuda.synchronize()
+with torch.cuda.stream(side):
+    for _ in range(40):                   # tens of milliseconds each: the device is somebody else's for the next seconds
+        a2 = a @ a
+time.sleep(0.05)
+busy = fit()
+torch.cuda.synchronize()
+print(json.dumps(dict(quiet_span=quiet[0], busy_span=busy[0], iters=[quiet[1], busy[1]],
+                      equal=bool(np.array_equal(quiet[2], busy[2]) and np.array_equal(quiet[3], busy[3])))))
+"""
 
 
 @pytest.mark.timeout(120)

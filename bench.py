@@ -12,6 +12,11 @@ reference's default), K = 9 bins, H = 8, B = 5, Adam lr = 0.01, fixed number of 
 trained as ONE batched launch sequence (grid.y = clique).  A "step" is ONE full-batch training iteration of
 all 8 cliques (forward + analytic backward + gradient reduction + Adam).  With N > 1 every rank trains its
 own 8 cliques (weak scaling, no data-path collective: independent cliques never exchange data).
+With N > 1 a second, UNTIMED-for-`value` regime runs behind the headline and is reported as `exchange`: one incremental
+update of a branching factor graph through `slam.ParallelNFiSAM` -- a binary "meeting tree" of 2^ceil(log2 N) robots, whose
+Bayes tree has one leaf arm per rank and ceil-log2 levels of joins that cross ranks -- i.e. the path north_star describes
+("RCCL over xGMI carrying separator samples between parent/child cliques"): cross-rank tree edges, bytes, this rank's
+point-to-point and all-gather wall clock, and the update's wall clock on every rank.
 
 Launch: `python bench.py --gpus N --steps K --warmup W`.  Under torchrun (WORLD_SIZE set) this process is one
 rank; without it and N > 1 the script starts N child ranks itself BEFORE touching the GPU and relays rank 0's
@@ -398,6 +403,114 @@ def incremental_update_wallclock():
             "note": "reference column = example/.../case1/run1/step_timing (authors' GPU, same arguments)"}
 
 
+def meeting_tree(depth):
+    """A factor graph whose Bayes tree (natural ordering) is a balanced binary tree of JOINS: 2^depth robots ("arms": prior
+    pose B -odometry-> A -odometry-> X, a landmark M ranged from B and A) meet pairwise (a relative-pose factor between the
+    two end poses, the first robot then drives on to a new pose), the pairs' survivors meet again, and so on.  Cliques
+    (checked in tests/test_clique_parallel.py): per arm {B, M | A} <- {A | X}; per join {X_2j, X_2j+1 | Y_j} (root: no
+    separator) with two child subtrees whose separators are DISJOINT -- the clique simulator, like the reference's, assumes
+    the priors inside a clique do not overlap (src/sampler/SimulationBasedSampler.py:19).  `assign_subtrees` puts one arm
+    on each of 2^depth ranks; every join then has one local and one remote child: 2^depth - 1 cross-rank edges.
+    -> (variables in elimination order, factors)"""
+    from factors.Factors import (SE2R2RangeGaussianLikelihoodFactor, SE2RelativeGaussianLikelihoodFactor,
+                                 UnarySE2ApproximateGaussianPriorFactor)
+    from geometry.TwoDimension import SE2Pose
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    cov = np.diag([0.3, 0.3, 0.05]) ** 2
+    levels = [[] for _ in range(depth + 1)]
+    leaf = {"B": [], "M": [], "A": []}
+    factors = []
+
+    def build(level, idx, y0):
+        if level == 0:
+            Bv, Av, Xv = SE2Variable("B%d" % idx), SE2Variable("A%d" % idx), SE2Variable("X%d" % idx)
+            Mv = R2Variable("M%d" % idx, VariableType.Landmark)
+            leaf["B"].append(Bv); leaf["M"].append(Mv); leaf["A"].append(Av); levels[0].append(Xv)
+            factors.append(UnarySE2ApproximateGaussianPriorFactor(Bv, SE2Pose(0, y0, 0), cov))
+            factors.append(SE2RelativeGaussianLikelihoodFactor(Bv, Av, SE2Pose(10, 0, 0), covariance=cov))
+            factors.append(SE2RelativeGaussianLikelihoodFactor(Av, Xv, SE2Pose(10, 0, 0), covariance=cov))
+            factors.append(SE2R2RangeGaussianLikelihoodFactor(Bv, Mv, 15.0, 0.5))
+            factors.append(SE2R2RangeGaussianLikelihoodFactor(Av, Mv, 11.2, 0.5))
+            return Xv, (20.0, y0)
+        e1, (x1, y1) = build(level - 1, 2 * idx, y0)
+        e2, (x2, y2) = build(level - 1, 2 * idx + 1, y0 + 40.0 * 2 ** (level - 1))
+        factors.append(SE2RelativeGaussianLikelihoodFactor(e1, e2, SE2Pose(x2 - x1, y2 - y1, 0), covariance=cov))
+        if level == depth:
+            return None, None
+        Yv = SE2Variable("%s%d" % ("YZWVUT"[level - 1], idx))
+        levels[level].append(Yv)
+        factors.append(SE2RelativeGaussianLikelihoodFactor(e1, Yv, SE2Pose(10, 0, 0), covariance=cov))
+        return Yv, (x1 + 10.0, y1)
+
+    build(depth, 0, 0.0)
+    order = leaf["B"] + leaf["M"] + leaf["A"]
+    for lv in levels[:depth]:
+        order += lv
+    return order, factors
+
+
+def exchange_regime(world, rank, reps=2):
+    """One incremental update of the meeting tree through `slam.ParallelNFiSAM` (the reference's dependency:
+    src/slam/FactorGraphSolver.py:409-477 upward, :524-531 downward), `reps` times on fresh solvers (the first pays module
+    load and kernel paging); the LAST is reported.  Every rank returns its own record; rank 0 gathers them."""
+    import random
+    import torch
+    import torch.distributed as dist
+    from slam.NFiSAM import NFiSAMArgs
+    from slam.ParallelNFiSAM import ParallelNFiSAM
+    depth = max(1, int(math.ceil(math.log2(max(world, 2)))))
+    rec = None
+    for rep in range(reps):
+        random.seed(rep); np.random.seed(rep + 17 * rank); torch.manual_seed(rep + 17 * rank)
+        order, factors = meeting_tree(depth)
+        solver = ParallelNFiSAM(NFiSAMArgs(num_knots=K, flow_iterations=600, local_sample_num=2000, learning_rate=.02, hidden_dim=H,
+                                           cuda_training=True, elimination_method="natural", training_set_frac=1.0,
+                                           loss_delta_tol=.01, posterior_sample_num=500), posterior="sharded")
+        for v in order:
+            solver.add_node(v)
+        for f in factors:
+            solver.add_factor(f)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        solver.update_physical_and_working_graphs()
+        t1 = time.perf_counter()
+        res = solver.incremental_inference()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert all(np.all(np.isfinite(res[v])) for v in order)
+        up, down = solver.exchange_stats[-1], solver.posterior_exchange_stats
+        rec = dict(rank=rank, update_ms=1e3 * (t2 - t0), graph_update_ms=1e3 * (t1 - t0), upward_pass_ms=up["upward_pass_ms"],
+                   downward_pass_ms=down["downward_pass_ms"], cliques_trained_here=up["cliques_trained_here"],
+                   p2p_ms=up["p2p_ms"] + down["p2p_ms"], p2p_send_ms=up["p2p_send_ms"] + down["p2p_send_ms"],
+                   p2p_wait_ms=up["p2p_wait_ms"] + down["p2p_wait_ms"], all_gather_ms=up["all_gather_ms"] + down["all_gather_ms"],
+                   cross_rank_edges=up["cross_rank_edges"] + down["cross_rank_edges"], bytes=up["bytes"] + down["bytes"],
+                   upward=dict(up), downward=dict(down), cliques=len(solver.physical_bayes_tree.clique_ordering()),
+                   owners=solver.owner_log[-1])
+    # a raw link figure next to the pass's (which waits for producers): ping-pong of one separator batch between ranks 0 and 1
+    ping_us = None
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        buf = torch.zeros(2000, 3, dtype=torch.float32, device=dev)
+        if rank in (0, 1):
+            for it in range(25):
+                if it == 5:
+                    if dev.type == "cuda":
+                        torch.cuda.synchronize()
+                    tp = time.perf_counter()
+                if rank == 0:
+                    dist.send(buf, dst=1); dist.recv(buf, src=1)
+                else:
+                    dist.recv(buf, src=0); dist.send(buf, dst=0)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            ping_us = 1e6 * (time.perf_counter() - tp) / 40.0           # one-way time of a [2000, 3] fp32 batch (24 KB)
+    rec["p2p_one_way_us_24KB"] = ping_us
+    gathered = [None] * world
+    dist.all_gather_object(gathered, rec)
+    return gathered
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes (one rank per GPU) BEFORE this
     process touches the GPU, relay rank 0's JSON line, exit with the worst child code."""
@@ -426,6 +539,7 @@ def main():
     ap.add_argument("--regime-steps", type=int, default=200, help="iterations timed per secondary regime")
     ap.add_argument("--no-regimes", action="store_true", help="headline workload only (rocprofv3 runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the ParallelNFiSAM exchange regime")
     ap.add_argument("--no-update-bench", action="store_true",
                     help="skip the end-to-end incremental-update timing (used for rocprofv3 runs so that the kernel "
                          "statistics contain the headline workload only)")
@@ -499,6 +613,35 @@ def main():
             prob, L = regime_problem(name, seed0=7)
             regimes[name], _ = Workload(prob, L, dev, REGIME_HIDDEN.get(name)).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())
 
+    # ---- N > 1 (or the forced process group of a 1-GPU box): the path that DOES exchange -- ParallelNFiSAM on a branching tree ----
+    exchange = None
+    if use_dist and not args.no_exchange:
+        try:
+            per_rank = exchange_regime(world, rank)
+            r0 = per_rank[0]
+            exchange = {
+                "workload": "one incremental update of a binary meeting tree of %d robots (%d cliques, D = 6..9+obs, n = 2000, K=9, H=8, "
+                            "<= 600 iterations + window stop, 500 posterior samples) through slam.ParallelNFiSAM: upward pass sharded by "
+                            "subtree, child -> parent separator batches [2000, Ds] fp32 point-to-point on cross-rank tree edges, models "
+                            "replicated by two all_gathers, downward pass sharded with parent -> child batches [500, Ds]" % (2 ** max(1, int(math.ceil(math.log2(max(world, 2))))), r0["cliques"]),
+                "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": world,
+                "cross_rank_edges": r0["cross_rank_edges"], "bytes": r0["bytes"],
+                "p2p_ms": max(r["p2p_ms"] for r in per_rank), "all_gather_ms": max(r["all_gather_ms"] for r in per_rank),
+                "p2p_send_ms_max": max(r["p2p_send_ms"] for r in per_rank), "p2p_wait_ms_max": max(r["p2p_wait_ms"] for r in per_rank),
+                "p2p_one_way_us_24KB": per_rank[min(1, world - 1)]["p2p_one_way_us_24KB"] if world > 1 else None,
+                "update_ms_per_rank": [round(r["update_ms"], 3) for r in per_rank], "update_ms": max(r["update_ms"] for r in per_rank),
+                "cliques_trained_per_rank": [r["cliques_trained_here"] for r in per_rank],
+                "per_rank": [{k: r[k] for k in ("rank", "update_ms", "graph_update_ms", "upward_pass_ms", "downward_pass_ms", "p2p_ms",
+                                                "p2p_send_ms", "p2p_wait_ms", "all_gather_ms", "cliques_trained_here")} for r in per_rank],
+                "upward": {k: r0["upward"][k] for k in ("cross_rank_edges", "bytes", "all_gather_bytes")},
+                "downward": {k: r0["downward"][k] for k in ("cross_rank_edges", "bytes", "all_gather_bytes")},
+                "note": "p2p_ms / all_gather_ms = the slowest rank's wall clock inside send + recv + drain / inside the two all_gathers; "
+                        "p2p_wait_ms contains the PRODUCER'S remaining work (a parent waits for its remote child's fit), not link time -- "
+                        "p2p_one_way_us_24KB is the link's own figure (ping-pong of one [2000, 3] fp32 batch between ranks 0 and 1).  "
+                        "Not part of `value`: the headline stays the exchange-free weak-scaling line."}
+        except Exception as e:   # noqa: BLE001  (must never break the contract line)
+            exchange = {"error": repr(e)[:300]}
+
     if rank == 0:
         total = world * wl.n_samples * args.steps
         ach = head["achieved_tflops"]
@@ -554,6 +697,7 @@ def main():
                                  "this workload (lower bound of the gfx950 FETCH_SIZE range, see `traffic_profiled`), not measured "
                                  "in this run."},
             "regimes": regimes,
+            "exchange": exchange,
         }
         import glob
         tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_kernel_traffic.json")))

@@ -19,6 +19,7 @@ example) have no sibling subtrees: they run on one rank ("repli
 Nothing here touches the kernels; it is scheduling + message routing around
 `slam.NFiSAM.NFiSAM.fit_clique_density_model`.
 """
+import time
 from typing import Callable, Dict, Hashable, List, Optional, Sequence
 
 import numpy as np
@@ -157,6 +158,10 @@ class EdgeExchange:
         self._recv: Dict[Hashable, tuple] = {}    # key -> (request, buffer)
         self._sends: List[tuple] = []             # (request, buffer): kept alive until drain()
         self.log: List[tuple] = []                # ("send" | "recv", peer, key) in issue order (tests)
+        # what the pass cost this rank (bench.py's `exchange` block): seconds inside send() -- staging + isend --, seconds
+        # BLOCKED in recv() / drain() (that is the producer's remaining work plus the transfer: a dependency wait, not
+        # link time), bytes out / in
+        self.stats = {"send_s": 0.0, "wait_s": 0.0, "bytes_sent": 0, "bytes_received": 0, "sends": 0, "recvs": 0}
 
     def _buffer_device(self):
         return self.device if self.on_device else "cpu"
@@ -178,6 +183,7 @@ class EdgeExchange:
         src, dst, shape = self.edges[key]
         if src != self.rank:
             raise ValueError("edge %r is not sent by rank %d" % (key, self.rank))
+        t0 = time.perf_counter()
         t = batch.to(torch.float32).contiguous()
         if tuple(t.shape) != shape:
             raise ValueError("edge %r carries %s, announced %s" % (key, tuple(t.shape), shape))
@@ -188,30 +194,41 @@ class EdgeExchange:
         self._sends.append((dist.isend(t, dst=dst), t))
         self.log.append(("send", dst, key))
         self.cursor[dst] += 1
+        self.stats["send_s"] += time.perf_counter() - t0
+        self.stats["bytes_sent"] += 4 * t.numel()
+        self.stats["sends"] += 1
 
     def recv(self, key) -> torch.Tensor:
         src, dst, _ = self.edges[key]
         if dst != self.rank:
             raise ValueError("edge %r is not received by rank %d" % (key, self.rank))
+        t0 = time.perf_counter()
         self._post_until(src, self.pos[key] + 1)
         req, buf = self._recv[key]
         if req is not None:
             req.wait()
             self._recv[key] = (None, buf)
+            self.stats["bytes_received"] += 4 * buf.numel()
+            self.stats["recvs"] += 1
+        self.stats["wait_s"] += time.perf_counter() - t0
         return buf
 
     def drain(self):
         """End of the pass: post what was never asked for, wait for every outstanding operation (the buffers of the
         sends are kept until here)."""
+        t0 = time.perf_counter()
         for peer in self.seq:
             self._post_until(peer, len(self.seq[peer]))
         for key, (req, buf) in list(self._recv.items()):
             if req is not None:
                 req.wait()
                 self._recv[key] = (None, buf)
+                self.stats["bytes_received"] += 4 * buf.numel()
+                self.stats["recvs"] += 1
         for req, _ in self._sends:
             req.wait()
         self._sends = []
+        self.stats["wait_s"] += time.perf_counter() - t0
 
 
 def tree_edges(tree: CliqueTree, assignment: Dict[Hashable, int], order: Sequence, shape_of: Callable) -> List[tuple]:

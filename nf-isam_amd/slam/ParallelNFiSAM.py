@@ -107,6 +107,10 @@ class ParallelNFiSAM(NFiSAM):
         self._posterior_mode = posterior
         self._on_device = dist.get_backend() == "nccl"       # RCCL moves device tensors; gloo needs host tensors
         self.owner_log: List[Dict] = []                      # per update: {clique name: rank} (tests, reports)
+        # per update: what the rank-to-rank traffic of the pass was and what it cost THIS rank (bench.py's `exchange` block):
+        # cross_rank_edges / bytes are properties of the pass (identical on every rank), the *_ms are this rank's wall clock
+        self.exchange_stats: List[Dict] = []
+        self._gather_s = 0.0
 
     # ---- collectives of the replication steps ----------------------------------------------------------------
     def _comm_device(self):
@@ -114,6 +118,7 @@ class ParallelNFiSAM(NFiSAM):
 
     def _all_gather_flat(self, mine: "torch.Tensor") -> List["torch.Tensor"]:
         """Every rank's flat fp32 tensor on every rank: one all_gather of the lengths, one of the padded payloads."""
+        t0 = time.perf_counter()
         dev = self._comm_device()
         mine = mine.to(device=dev, dtype=torch.float32).contiguous().view(-1)
         size = torch.tensor([mine.numel()], dtype=torch.int64, device=dev)
@@ -125,6 +130,10 @@ class ParallelNFiSAM(NFiSAM):
         padded[:mine.numel()] = mine
         parts = [torch.empty(width, dtype=torch.float32, device=dev) for _ in range(self.world)]
         dist.all_gather(parts, padded)
+        if self._on_device:
+            torch.cuda.synchronize()                       # (RCCL collectives are asynchronous: the clock wants them done)
+        self._gather_s += time.perf_counter() - t0
+        self._gather_bytes = getattr(self, "_gather_bytes", 0) + 4 * width * self.world + 8 * self.world
         return [t[:k] for t, k in zip(parts, sizes)]
 
     def _shared_seed(self) -> int:
@@ -168,6 +177,7 @@ class ParallelNFiSAM(NFiSAM):
         exchange = EdgeExchange(edges, self.rank, device=_device(), on_device=self._on_device)
         crossing = {e[0] for e in edges}
         self.exchange_log = exchange.log
+        self._gather_s, self._gather_bytes = 0.0, 0
         trained = []
         t_begin = time.time()
         for clique in reversed(cliques):                          # leaves first, as the reference pops its ordering
@@ -212,6 +222,14 @@ class ParallelNFiSAM(NFiSAM):
         for r, blob in enumerate(blobs):
             if r != self.rank:
                 self._install_models([c for c in trained if owner[id(c)] == r], blob.cpu().numpy())
+        st = exchange.stats
+        self.exchange_stats.append(dict(
+            cliques_trained=len(retrain), cliques_trained_here=len(mine), cross_rank_edges=len(edges),
+            bytes=int(sum(4 * e[3][0] * e[3][1] for e in edges)),          # separator batches [n, Ds] fp32 that crossed ranks
+            p2p_messages_here=st["sends"] + st["recvs"], p2p_bytes_here=st["bytes_sent"] + st["bytes_received"],
+            p2p_send_ms=1e3 * st["send_s"], p2p_wait_ms=1e3 * st["wait_s"], p2p_ms=1e3 * (st["send_s"] + st["wait_s"]),
+            all_gather_ms=1e3 * self._gather_s, all_gather_bytes=int(self._gather_bytes),
+            upward_pass_ms=1e3 * (time.time() - t_begin)))
 
     # A rank's models of one update as one flat fp32 vector.  Per clique (in the pass's order):
     #   [D, n_obs, n_loss, L]  kparams[L * Pk]  mean[D]  std[D]  circular[D]  true_obs as float64 bits (2 words each)  loss[n_loss]
@@ -317,6 +335,7 @@ class ParallelNFiSAM(NFiSAM):
                     sl = sorted(child.separator, key=rmap.__getitem__)
                     exchange.send(key_of[id(child)], torch.from_numpy(np.hstack([samples[v] for v in sl]).astype(np.float32)))
         exchange.drain()
+        self._gather_s, self._gather_bytes = 0.0, 0
         # every rank ends with the samples of every variable (what `results()` hands out): one block per rank
         mine = [c for c in cliques if owner[id(c)] == self.rank]
         cols = [samples[v] for c in mine for v in sorted(c.frontal, key=rmap.__getitem__)]
@@ -330,6 +349,11 @@ class ParallelNFiSAM(NFiSAM):
             for v in theirs:
                 samples[v] = blk[:, col:col + v.dim]
                 col += v.dim
+        st = exchange.stats
+        self.posterior_exchange_stats = dict(
+            cross_rank_edges=len(edges), bytes=int(sum(4 * e[3][0] * e[3][1] for e in edges)),
+            p2p_send_ms=1e3 * st["send_s"], p2p_wait_ms=1e3 * st["wait_s"], p2p_ms=1e3 * (st["send_s"] + st["wait_s"]),
+            all_gather_ms=1e3 * self._gather_s, all_gather_bytes=int(self._gather_bytes), downward_pass_ms=1e3 * (time.time() - start))
         if timer is not None:
             timer.append(time.time() - start)
         return {v: samples[v] for v in self._elimination_ordering}

@@ -187,3 +187,38 @@ def test_edge_exchange_rejects_inconsistent_use():
         ex.send("e", torch.zeros(3, 2))            # not the announced shape
     with pytest.raises(ValueError):
         ex.recv("e")                               # rank 0 is the sender of this edge
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_meeting_tree_of_the_bench_exchange_regime_branches_and_shards_as_designed(depth):
+    """bench.py's N > 1 `exchange` regime: the binary meeting tree of 2^depth robots.  Host-only check of what the regime
+    rests on: the Bayes tree (natural ordering) has one {B, M | A} <- {A | X} arm per robot and 2^depth - 1 join cliques
+    {X_2j, X_2j+1 | Y_j} whose two child subtrees have DISJOINT separators; `assign_subtrees` over 2^depth ranks gives every
+    rank one arm and every join one local and one remote child: 2^depth - 1 cross-rank child -> parent edges."""
+    import bench
+    from slam.CliqueParallel import CliqueTree, assign_subtrees
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    order, factors = bench.meeting_tree(depth)
+    arms = 2 ** depth
+    assert len(order) == 4 * arms + (arms - 2)
+    s = NFiSAM(NFiSAMArgs(num_knots=9, hidden_dim=8, elimination_method="natural", cuda_training=True))
+    for v in order:
+        s.add_node(v)
+    for f in factors:
+        s.add_factor(f)
+    s.update_physical_and_working_graphs()
+    cl = s._working_bayes_tree.clique_ordering()
+    assert len(cl) == 2 * arms + (arms - 1)
+    joins = [c for c in cl if len(c.children) == 2]
+    assert len(joins) == arms - 1 and all(len(c.children) <= 2 for c in cl)
+    for c in joins:
+        a, b = [set(v.name for v in ch.separator) for ch in c.children]
+        assert a and b and not (a & b) and (a | b) <= set(v.name for v in c.frontal)
+    ids = {id(c): k for k, c in enumerate(cl)}
+    parent = {ids[id(c)]: (ids[id(c.parent)] if c.parent is not None else None) for c in cl}
+    cost = {ids[id(c)]: float(c.dim) ** 2 for c in cl}
+    for world in (1, 2, arms):
+        a = assign_subtrees(CliqueTree(parent, cost), world)
+        cross = sum(1 for c in cl if c.parent is not None and a[ids[id(c)]] != a[ids[id(c.parent)]])
+        assert set(a.values()) == set(range(world))
+        assert cross == (0 if world == 1 else (1 if world == 2 else arms - 1)), (world, cross)

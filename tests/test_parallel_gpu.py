@@ -159,6 +159,15 @@ def test_bench_two_ranks_prints_the_contract_line():
     assert abs(d["value"] - 2 * d["per_gpu_value"]) < 1e-6 * d["value"]
     assert d["value"] > 1e7 and 0 < d["ms_per_step"] < 5.0
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    # the regime that DOES exchange (slam.ParallelNFiSAM on the two-robot meeting tree: 5 cliques, one join): one child ->
+    # parent separator batch [2000, 3] upward and one parent -> child batch [500, 3] downward cross the two ranks
+    x = d["exchange"]
+    assert "error" not in x, x
+    assert x["world"] == 2 and x["upward"]["cross_rank_edges"] == 1 and x["downward"]["cross_rank_edges"] == 1
+    assert x["upward"]["bytes"] == 2000 * 3 * 4 and x["downward"]["bytes"] == 500 * 3 * 4 and x["bytes"] == 2500 * 3 * 4
+    assert len(x["update_ms_per_rank"]) == 2 and all(0 < t < 60000 for t in x["update_ms_per_rank"])
+    assert sum(x["cliques_trained_per_rank"]) == 5 and min(x["cliques_trained_per_rank"]) >= 2
+    assert x["p2p_ms"] > 0 and x["all_gather_ms"] > 0 and x["p2p_one_way_us_24KB"] > 0
 
 
 @pytest.mark.timeout(600)
@@ -197,6 +206,11 @@ def test_bench_under_the_launcher_over_rccl_prints_only_the_contract_line():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 1e7
+    # the exchange regime over an RCCL group of ONE rank: every all_gather / broadcast of ParallelNFiSAM runs, no edge crosses
+    x = d["exchange"]
+    assert "error" not in x, x
+    assert x["backend"].startswith("nccl") and x["world"] == 1 and x["cross_rank_edges"] == 0 and x["bytes"] == 0
+    assert x["cliques_trained_per_rank"] == [5] and x["all_gather_ms"] > 0
     # The closing barrier of a timed replay is an RCCL collective (tens of microseconds): it must sit OUTSIDE the clock -- the
     # same 20-step plan timed without a process group, on this same box, within 10 % (round 3 had the barrier inside:
     # a 0.36 ms region of an exchange-free job would have read 10-25 % of fake scaling loss at N > 1).

@@ -344,6 +344,123 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     return gave_up ? 2 : 0;
 }
 
+// The same staging for groups of MORE THAN EIGHT blocks (n > 2048: up to sixteen copies, round 5) -- a second instantiation of the
+// kernel (template flag WIDE), so that the code of the common case stays what round 4 measured (the two-pass loop in ONE function
+// cost the Plaza clique 3.7 % and C3 2.4 %, scripts/ab.py, one box).
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                        int i, int tid, int NT, int st_step, int st_stop, int n, int iter) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    typedef const __attribute__((address_space(1))) unsigned long long* gq;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    int gave_up = 0;
+    // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    for (int base = 0; base < nj; base += 2 * NT) {
+        const int ja = base + tid, jb = base + NT + tid;
+        const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
+        const int ia = j0 + ca, ib = j0 + cb;
+        uint32_t da = map[ca], db = map[cb];
+        float ta, tb, ma, va, mb, vb;
+        float ga[8], gb[8];
+        if (!pending) {                                        // launch-uniform per iteration: the chunk's first iteration
+            ta = t_src[ia]; tb = t_src[ib];
+            ma = fa.m_src[ia]; va = fa.v_src[ia];
+            mb = fa.m_src[ib]; vb = fa.v_src[ib];
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(ma), "+v"(va), "+v"(mb), "+v"(vb), "+v"(da), "+v"(db));
+        } else {
+            ta = fa.keep[ca]; ma = fa.keep[fa.kstride + ca]; va = fa.keep[2 * fa.kstride + ca];
+            tb = fa.keep[cb]; mb = fa.keep[fa.kstride + cb]; vb = fa.keep[2 * fa.kstride + cb];
+            // the copies' (value, tag) pairs of this thread's two parameters: all sixteen loads in flight, again until every
+            // tag is this iteration's (a copy whose block is still computing shows the tag of two iterations ago, or 0).
+            // A group of more than eight blocks (n > 2048: up to sixteen copies, round 5) takes two such passes; the sums are
+            // formed in nsf_adam_kernel's lane-partial order for that many copies -- p_c = g_c + g_{c+8}, then p_0 + ... + p_7 --
+            // which for eight copies or fewer IS the copy order (one pass, the code of round 4).
+            const int passes = fa.copies > 8 ? 2 : 1;          // block-uniform
+            for (int pass = 0; pass < passes && !gave_up; ++pass) {
+            const int c0 = 8 * pass;
+            unsigned spins = 0;
+            for (;;) {
+                unsigned long long qa[8], qb[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const size_t o = (size_t)(c0 + c < fa.copies ? c0 + c : 0) * fa.cstride;
+                    qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qb[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // (the iteration's bias corrections while the loads are under way: ~80 instructions that depend on nothing loaded)
+                if (base == 0 && spins == 0u && pass == 0)
+                    fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+                bool ok = true;
+                float la[8], lb[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag && (uint32_t)(qb[c] >> 32) == fa.tag;
+                    la[c] = __uint_as_float((uint32_t)qa[c]);
+                    lb[c] = __uint_as_float((uint32_t)qb[c]);
+                }
+                if (ok) {
+                    if (pass == 0) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) { ga[c] = la[c]; gb[c] = lb[c]; }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (8 + c < fa.copies) { ga[c] += la[c]; gb[c] += lb[c]; }
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+#if defined(NSF_STAMPS)
+                ++fa.looks;
+#endif
+                // every 64 looks: has a member of the group given up?  after 2^spin_log2 looks: give up (and say so)
+                if ((spins & 63u) == 0u) {
+                    const bool timeout = spins > (1u << fa.spin_log2);
+                    if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) { gave_up = 1; break; }
+                }
+            }
+            }
+        }
+        if (pending) {
+            FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
+            sum_order.copies = fa.copies < 8 ? fa.copies : 8;  // (more than eight copies: the eight lane partials)
+            adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+            adam_update(fa.kc, fused_sum_grads(sum_order, gb), mb, vb, tb);
+            if (fa.t_dst != nullptr) {                         // the dim's first block records the new state (read by later KERNELS)
+                if (ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
+                if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
+            }
+        }
+        if (ja < nj) {
+            fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
+            lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
+        }
+        if (jb < nj) {
+            fa.keep[cb] = tb; fa.keep[fa.kstride + cb] = mb; fa.keep[2 * fa.kstride + cb] = vb;
+            lds0[db & 0x7fffu] = (db & PANEL_SCALED) ? tb * kTanhScale : tb; lds0[db >> 16] = tb;
+        }
+    }
+    if (i > 0 && !pending) {                                   // (the zero weights behind W0's rows stay: the panel is the block's for the whole chunk)
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    return gave_up ? 2 : 0;
+}
+
 // ---- the same exchange with the Adam update DIVIDED among the group's blocks (contended launches) --------------------------
 // stage_cond_panel_persist lets every block of a (clique, dim) group derive the whole dim's update: right for a lone
 // wave per SIMD (one memory round trip), wasteful when three waves share a SIMD's issue port -- on C3 the 8 blocks x 256
@@ -419,6 +536,123 @@ __device__ __forceinline__ int stage_cond_panel_persist_split(float* lds0, const
         }
         FusedAdam sum_order;
         sum_order.copies = fa.copies;
+        adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+        fa.keep[q] = ta; fa.keep[fa.kstride + q] = ma; fa.keep[2 * fa.kstride + q] = va;
+        fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va;      // (every block records ITS slice: read by later kernels)
+        const unsigned long long pub = ((unsigned long long)tag2 << 32) | (unsigned long long)__float_as_uint(ta);
+        __hip_atomic_store((unsigned long long*)(xch + 2 * (size_t)ia), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int base = 0; base < nj; base += 2 * NT) {
+        const int ja = base + tid, jb = base + NT + tid;
+        const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
+        const int ia = j0 + ca, ib = j0 + cb;
+        uint32_t da = map[ca], db = map[cb];
+        float ta, tb;
+        if (!pending) {
+            ta = t_src[ia]; tb = t_src[ib];
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(da), "+v"(db));
+        } else {
+            unsigned spins = 0;
+            for (;;) {
+                const unsigned long long qa = __hip_atomic_load((const unsigned long long*)(gq)(xch + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long qb = __hip_atomic_load((const unsigned long long*)(gq)(xch + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ta = __uint_as_float((uint32_t)qa); tb = __uint_as_float((uint32_t)qb);
+                if ((uint32_t)(qa >> 32) == tag2 && (uint32_t)(qb >> 32) == tag2) break;
+                if (gave_up || look_again(spins)) { gave_up = 1; break; }
+            }
+        }
+        if (ja < nj) { lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta; }
+        if (jb < nj) { lds0[db & 0x7fffu] = (db & PANEL_SCALED) ? tb * kTanhScale : tb; lds0[db >> 16] = tb; }
+    }
+    if (i > 0 && !pending) {
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    return gave_up ? 2 : 0;
+}
+
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist_split_wide(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                              int i, int tid, int NT, int st_step, int st_stop, int n, int iter, int bx,
+                                                              __attribute__((address_space(1))) float* xch) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    typedef const __attribute__((address_space(1))) unsigned long long* gq;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    const int S = (nj + fa.copies - 1) / fa.copies;                  // slice of this block: parameters [bx S, min((bx + 1) S, nj))
+    const uint32_t tag2 = fa.tag + 1u;                               // the tag of this iteration's theta (= state->step + it + 1)
+    int gave_up = 0;
+    auto look_again = [&](unsigned& spins) -> bool {                 // -> true: give up
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+#if defined(NSF_STAMPS)
+        ++fa.looks;
+#endif
+        if ((spins & 63u) == 0u) {
+            const bool timeout = spins > (1u << fa.spin_log2);
+            if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) return true;
+        }
+        return false;
+    };
+    // one thread per parameter of the slice (S <= 110 for a group of eight blocks: the block's first waves; a clique of few
+    // particles has few blocks and long slices: the threads go round)
+    for (int q = tid; q < S && bx * S + q < nj; q += NT) {
+        const int ia = j0 + bx * S + q;
+        if (!pending) {
+            // the chunk's first iteration: nothing to apply; the owners pick up their slice's state from the clique's arrays
+            fa.keep[q] = t_src[ia];
+            fa.keep[fa.kstride + q] = fa.m_src[ia];
+            fa.keep[2 * fa.kstride + q] = fa.v_src[ia];
+            continue;
+        }
+        float ta = fa.keep[q], ma = fa.keep[fa.kstride + q], va = fa.keep[2 * fa.kstride + q];
+        float ga[8];
+        const int passes = fa.copies > 8 ? 2 : 1;                    // (more than eight copies: two passes, lane-partial order -- see stage_cond_panel_persist)
+        for (int pass = 0; pass < passes && !gave_up; ++pass) {
+        const int c0 = 8 * pass;
+        unsigned spins = 0;
+        for (;;) {
+            unsigned long long qa[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + (size_t)(c0 + c < fa.copies ? c0 + c : 0) * fa.cstride + 2 * (size_t)ia),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (spins == 0u && q == tid && pass == 0) fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+            bool ok = true;
+            float la[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag;
+                la[c] = __uint_as_float((uint32_t)qa[c]);
+            }
+            if (ok) {
+                if (pass == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ga[c] = la[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (8 + c < fa.copies) ga[c] += la[c];
+                }
+                break;
+            }
+            if (gave_up || look_again(spins)) { gave_up = 1; break; }
+        }
+        }
+        FusedAdam sum_order;
+        sum_order.copies = fa.copies < 8 ? fa.copies : 8;
         adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
         fa.keep[q] = ta; fa.keep[fa.kstride + q] = ma; fa.keep[2 * fa.kstride + q] = va;
         fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va;      // (every block records ITS slice: read by later kernels)

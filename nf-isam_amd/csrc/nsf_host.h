@@ -40,7 +40,8 @@ constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
 constexpr int ONES_ROW = 68;       // nsf_train1_kernel: LDS words of 1.0 read as the bias column of the gradient GEMM operands
 // fused Adam (nsf_cond_mfma.h): 64 reserved words behind the loss ring, then the second set of gradient copies and the
 // second state buffer; the workspace is sized for cliques of up to this many 64-particle tiles
-constexpr int FUSED_COUNTERS = 64, FUSED_MAX_COPIES = 32;
+constexpr int FUSED_COUNTERS = 64, FUSED_MAX_COPIES = 64;     // (tiles of 64 particles: up to sixteen four-wave blocks per (clique, dim) group -- n <= 4096)
+constexpr int PERSIST_MAX_COPIES = 16;                           // gradient copies (= blocks) per group the chunk-persistent form exchanges (round 5; 8 before)
 
 struct TrainArgs {
     const nfisam_clique* cliques;   // device array (batched) or nullptr

@@ -621,7 +621,9 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     // + the fused-Adam launches' second set of gradient copies (64-particle tiles) and second state buffer (theta | m | v)
     const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
     // + the chunk-persistent form's two sets of TAGGED copies (8 blocks of 4 waves at most, 2 floats per parameter)
-    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 32 + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
+    // (round 5: groups of up to sixteen blocks -- n <= 4096 -- in the chunk-persistent form: 2 sets x copies x 2 floats)
+    const size_t copies16 = (tiles64 + 3) / 4;
+    const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 4 * (copies16 > 8 ? copies16 : 8) + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && (H == 8 || H == 4) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
     // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)
@@ -727,7 +729,17 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
     if (!on || g_persist_broken.load() || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
-    if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || sh.T != 1 || sh.slab == 0 || sh.W != 4) return false;
+    // (the one-launch-per-iteration fused form sums at most eight gradient copies -- fused_adam_shape --; the persistent
+    //  exchange takes up to sixteen, round 5: single cliques of up to 4096 particles, whose plain graph is then gradient
+    //  kernel + Adam kernel per iteration; nsf_adam_kernel's lane-partial order for that many copies is the order the
+    //  persistent staging sums in, so the two graphs of such a plan still leave the same bits)
+    {
+        const char* fe = getenv("NFISAM_FUSED_ADAM");
+        if (fe != nullptr && fe[0] == '0') return false;
+    }
+    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.T != 1 || sh.slab == 0 || sh.W != 4 ||
+        (max_n + sh.slab - 1) / sh.slab > PERSIST_MAX_COPIES)
+        return false;
     long blocks = 0;
     for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
     // (asked once per (K, H, clique width, device): the query costs a device-properties call, and replica schedulers
@@ -781,6 +793,24 @@ __global__ void __launch_bounds__(256) nsf_coresidency_probe_kernel(unsigned* ct
         __builtin_amdgcn_s_sleep(8);
     }
 }
+// Diagnostic (tests/test_hip_parity.py: the probe's test; not part of the ABI header): occupies the device the way a foreign
+// process's long kernel would -- `blocks` blocks of 256 threads holding `lds_bytes` of LDS each spin for `seconds` of wall
+// clock on `stream`.
+extern "C" int nfisam_debug_occupy_device(int blocks, size_t lds_bytes, float seconds, nfisam_stream_t stream) {
+    if (blocks < 1 || !(seconds > 0.0f) || seconds > 30.0f || lds_bytes > (size_t)(160 * 1024)) return NFISAM_ERR_ARG;
+    static unsigned* ctr = nullptr;                              // (one per process: the blocks only ever add to it)
+    if (ctr == nullptr) {
+        HIP_TRY(hipMalloc((void**)&ctr, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(ctr, 0, 2 * sizeof(unsigned)));
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)nsf_coresidency_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    HIP_TRY(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(nsf_coresidency_probe_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, ctr, 0xffffffffu,
+                       (unsigned)(seconds * 1e8f));
+    HIP_TRY(hipGetLastError());
+    return NFISAM_OK;
+}
+
 // -> true: `blocks` blocks of `per_cu` per compute unit are resident at once right now (or the probe is switched off / failed to run:
 // the occupancy answer stands)
 static bool device_is_quiet(long blocks, long places) {
@@ -838,8 +868,8 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
                         hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1,
                         int persist_iters = 0) {
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
-    const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, sh);
-    if (!fused && (n_chains > 1 || persist_iters > 0)) return NFISAM_ERR_ARG;
+    const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || persist_iters > 0;   // (the persistent form applies its own updates: up to 16 copies)
+    if (!fused && n_chains > 1) return NFISAM_ERR_ARG;
     const bool image = !fused && pair_image_shape(max_D, K, H, L, sh);
     int rc = enqueue_grad(dev_cliques, single, n_cliques, max_n, max_D, K, H, B, L, cfg->max_iters, iter_idx, s,
                           fused ? cfg : nullptr, host_cliques, chain, n_chains, image, persist_iters);
@@ -879,8 +909,10 @@ static int enqueue_bookkeeping(const nfisam_clique* dev_cliques, const nfisam_cl
 // end of a chunk: (fused-Adam launches) the last iteration's pending update, then the bookkeeping
 static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                              int max_D, int K, int H, int L, const nfisam_adam_cfg* cfg, int chunk, hipStream_t s,
-                             nfisam_train_state* mirror = nullptr) {
-    if (fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H))) {
+                             nfisam_train_state* mirror = nullptr, bool persistent_chunk = false) {
+    // (`persistent_chunk`: the chunk ran as a chunk-persistent launch, whose last update is always pending -- also for
+    //  groups of 9 .. 16 copies, which the one-launch-per-iteration form does not fuse)
+    if (persistent_chunk || fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H))) {
         AdamArgs ad;
         fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
         ad.close_chunk = chunk;
@@ -1186,12 +1218,12 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
             const bool split_end = persist && p->evk0 != nullptr && p->val.empty();
             if (status == NFISAM_OK && e == hipSuccess && p->val.empty() && !split_end)
                 status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk,
-                                           p->cap, p->hst_dev);
+                                           p->cap, p->hst_dev, persist);
             e = hipStreamEndCapture(p->cap, graph_out);
             if (split_end && e == hipSuccess && status == NFISAM_OK) {
                 e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
                 if (e == hipSuccess) {
-                    status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk, p->cap, p->hst_dev);
+                    status = enqueue_chunk_end(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg, p->chunk, p->cap, p->hst_dev, true);
                     e = hipStreamEndCapture(p->cap, &p->graph_end);
                 }
                 if (e == hipSuccess && status == NFISAM_OK) e = hipGraphInstantiate(&p->exec_end, p->graph_end, nullptr, nullptr, 0);
@@ -1222,7 +1254,7 @@ static int enqueue_validated_period(const nfisam_train_plan* p, hipStream_t s, b
                 rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L, &p->cfg, it, s, p->host.data());
         }
         if (rc == NFISAM_OK)
-            rc = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg, head, s, nullptr);
+            rc = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg, head, s, nullptr, persist && head > 1);
         if (rc) return rc;
     }
     const NsfUnitOps* ops = find_ops(p->K, p->H);

@@ -1193,7 +1193,11 @@ __host__ __device__ constexpr int persist_keep_stride(int max_D) {
     const int b = max_D > 1 ? LY::block(max_D - 1) : 0;
     return ((b > LY::PoP ? b : LY::PoP) + 3) & ~3;
 }
-template <int K, int H, bool PERSIST = false, bool LEAN = false>
+// WIDE (PERSIST only, round 5): groups of more than eight blocks -- a clique of more than 2048 particles, up to
+// PERSIST_MAX_COPIES = 16 gradient copies per (clique, dim) -- whose tagged copies are fetched in two passes and summed in
+// nsf_adam_kernel's lane-partial order for that many copies (nsf_cond_mfma.h: stage_cond_panel_persist*_wide).  A second
+// instantiation rather than a run-time branch: the common case keeps the code round 4 measured.
+template <int K, int H, bool PERSIST = false, bool LEAN = false, bool WIDE = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || LEAN || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
@@ -1442,10 +1446,17 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                     pa_.t_dst = to_own ? (gfloat*)own_t : alt;
                     pa_.m_dst = to_own ? (gfloat*)own_m : alt + gstride;
                     pa_.v_dst = to_own ? (gfloat*)own_v : alt + 2 * gstride;
-                    rc_ = stage_cond_panel_persist_split<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it,
-                                                               bx, tg0 + 2 * tg_set);
+                    if constexpr (WIDE)
+                        rc_ = stage_cond_panel_persist_split_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it,
+                                                                        bx, tg0 + 2 * tg_set);
+                    else
+                        rc_ = stage_cond_panel_persist_split<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it,
+                                                                   bx, tg0 + 2 * tg_set);
                 } else {
-                    rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                    if constexpr (WIDE)
+                        rc_ = stage_cond_panel_persist_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                    else
+                        rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                 }
                 if (rc_ == 1) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
@@ -3399,7 +3410,12 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         bool lean = false;
         if constexpr (lean_persist_v<KK, HH>) { if (persist && W == 4) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D); }
         if constexpr (lean_plain_v<KK, HH>) { if (!persist && W == 4) lean = lean_launch_fits<KK, HH, false>(real_blocks, max_D); }
-        if (persist) {
+        const bool wide = persist && gx > 8;                   // groups of 9 .. 16 blocks (n > 2048): the WIDE instantiation
+        if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
+        if (persist && wide) {
+            rc = set_lds(nsf_train1_kernel<KK, HH, true, false, true>, lds_launch);
+            if constexpr (lean_persist_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true, true>, lds_launch); }
+        } else if (persist) {
             rc = set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch);
             if constexpr (lean_persist_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true>, lds_launch); }
         } else {
@@ -3439,10 +3455,19 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         bool launched = false;
         if constexpr (lean_persist_v<KK, HH>) {
             if (gz > 0 && persist && lean) {
-                hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
-                                   dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+                if (wide)
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                                       dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+                else
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                                       dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
                 launched = true;
             }
+        }
+        if (!launched && gz > 0 && persist && wide) {
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                               dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+            launched = true;
         }
         if constexpr (lean_plain_v<KK, HH>) {
             if (gz > 0 && !persist && lean) {

@@ -192,6 +192,22 @@ def worker(case, seed, out_path):
                                new_separator=sorted(v.name for v in new_clique.separator)))
             return orig_reuse(self, old_clique, new_clique, device, *a, **k)
         RN.NFiSAM.root_clique_density_model_to_leaf = reuse
+        if case in LONG_CASES:
+            # The reference samples (posterior pass, child -> parent messages) with autograd ON and keeps what it drew: the
+            # graphs behind every clique's samples stay alive, ~0.8 MB per clique and update, quadratic in the run's length
+            # (Plaza1, update 98 of 156: 34 GB -- the first attempt at this fixture died there).  The two SAMPLING entry points
+            # run under no_grad here: same values (nothing is differentiated there), no retained graphs.
+            orig_sp, orig_fs = RN.NFiSAM.sample_posterior, RN.FlowsPriorFactor.sample
+
+            def sample_posterior_ng(self, *a, **k):
+                with torch.no_grad():
+                    return orig_sp(self, *a, **k)
+
+            def factor_sample_ng(self, *a, **k):
+                with torch.no_grad():
+                    return orig_fs(self, *a, **k)
+            RN.NFiSAM.sample_posterior = sample_posterior_ng
+            RN.FlowsPriorFactor.sample = factor_sample_ng
 
         def fit(self, clique, samples, var_ordering, timer, *a, **k):
             true_obs = self._clique_true_obs[clique]
@@ -264,9 +280,14 @@ def main():
     ap.add_argument("--seeds", type=int, default=0, help="0 = the case's default")
     ap.add_argument("--jobs", type=int, default=4)
     ap.add_argument("--worker", nargs=3, metavar=("CASE", "SEED", "OUT"))
+    ap.add_argument("--merge", metavar="WORKDIR", help="only merge the workers' outputs found in WORKDIR (a run whose driver died)")
     args = ap.parse_args()
     if args.worker:
         worker(args.worker[0], int(args.worker[1]), args.worker[2])
+        return
+    if args.merge:
+        for c in args.cases:
+            merge(c, args.merge, args.seeds or CASES[c][7])
         return
     if not os.path.isdir(REF):
         raise SystemExit("needs the reference at %s (build container only)" % REF)
@@ -286,17 +307,22 @@ def main():
             raise SystemExit("reference run %s seed %d failed: see %s.log" % (c, s, o))
         print("done", c, s, flush=True)
     for c in args.cases:
-        merged = {"seeds": np.arange(n_seeds[c]), "arguments": np.array(json.dumps(CASES[c][4])),
-                  "incremental_step": np.array(CASES[c][2])}
-        merged.update(reference_held(c))
-        for s in range(n_seeds[c]):
-            d = np.load(os.path.join(work, "%s_seed%d.npz" % (c, s)))
-            for k in d.files:
-                merged["seed%d_%s" % (s, k)] = d[k]
-        path = os.path.join(HERE, "pipeline_%s.npz" % c)
-        np.savez_compressed(path, **merged)
-        print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+        merge(c, work, n_seeds[c])
     shutil.rmtree(work, ignore_errors=True)
+
+
+def merge(c, work, n_seeds):
+    """The per-seed worker outputs of case `c` in directory `work` -> tests/golden/pipeline_<c>.npz"""
+    merged = {"seeds": np.arange(n_seeds), "arguments": np.array(json.dumps(CASES[c][4])),
+              "incremental_step": np.array(CASES[c][2])}
+    merged.update(reference_held(c))
+    for s in range(n_seeds):
+        d = np.load(os.path.join(work, "%s_seed%d.npz" % (c, s)))
+        for k in d.files:
+            merged["seed%d_%s" % (s, k)] = d[k]
+    path = os.path.join(HERE, "pipeline_%s.npz" % c)
+    np.savez_compressed(path, **merged)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
 if __name__ == "__main__":

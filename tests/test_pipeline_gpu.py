@@ -138,6 +138,49 @@ def _run(tmp_path, case, fx, seed):
     return run_dir, fits, n_steps
 
 
+def _compare_step(check, seed, i, order, S, ref_raw, max_blocks=None):
+    """The step statistics of the module docstring for ONE step: ours `S` [n, columns in `order`] against the reference's
+    seeds `ref_raw`.  `max_blocks`: evaluate at most that many 4-column blocks (late steps of a long run have thousands of
+    (pose, landmark) pairs: a fixed, evenly spaced subset that always contains the consecutive-pose blocks' ends)."""
+    dims = [3 if v.startswith("X") else 2 for v in order]
+    assert S.shape[1] == sum(dims) and np.all(np.isfinite(S))
+    rr = np.random.RandomState(100 + i).permutation(S.shape[0])[:ref_raw[0].shape[0]]
+    Sr = S[rr]
+    floor = round(float(np.sqrt(2.0 / Sr.shape[0])), 4)
+    if 2 * len(order) <= JOINT_MAX_COLUMNS:
+        refs_xy = [_xy_block(order, dims, r) for r in ref_raw]
+        sc = np.maximum(np.vstack(refs_xy).std(0), 1e-3)
+        m, spread = _band(_xy_block(order, dims, Sr) / sc, [r / sc for r in refs_xy])
+        check("step-joint", seed, i, m, spread, columns=2 * len(order), floor=floor)
+    # xy columns of every variable: ours, the reference's seeds, the pooled reference scale
+    off, col = 0, {}
+    for v, d in zip(order, dims):
+        col[v] = (off, off + 2)
+        off += d
+    pooled = np.vstack(ref_raw)
+    blocks = _blocks(order)
+    if max_blocks is not None and len(blocks) > max_blocks:
+        blocks = [blocks[int(q)] for q in np.unique(np.linspace(0, len(blocks) - 1, max_blocks).round())]
+    per_block = []
+    for a, b in blocks:
+        idx = list(range(*col[a])) + list(range(*col[b]))
+        sc = np.maximum(pooled[:, idx].std(0), 1e-3)
+        mb, sb = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
+        per_block.append((mb, sb, a + "-" + b))
+    if per_block:
+        worst = max(per_block, key=lambda t: t[0])
+        check("step-blocks-max", seed, i, worst[0], max(t[1] for t in per_block), blocks=len(per_block), worst_block=worst[2], floor=floor)
+        check("step-blocks-mean", seed, i, float(np.mean([t[0] for t in per_block])), float(np.mean([t[1] for t in per_block])),
+              blocks=len(per_block), floor=floor)
+    ours_v, ref_v = [], []
+    for v in order:
+        idx = list(range(*col[v]))
+        sc = np.maximum(pooled[:, idx].std(0), 1e-3)
+        mv, sv = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
+        ours_v.append(mv); ref_v.append(sv)
+    check("step-marginals", seed, i, float(np.mean(ours_v)), float(np.mean(ref_v)), variables=len(order), floor=floor)
+
+
 def compare_case(tmp_path, case, seeds=(0, 1, 2)):
     """-> (rows, failures, timing): every comparison as a dict(kind, seed, index, ours, spread, bound, ...)."""
     fx = np.load(os.path.join(GOLDEN, "pipeline_%s.npz" % case))
@@ -179,41 +222,7 @@ def compare_case(tmp_path, case, seeds=(0, 1, 2)):
             order = open(os.path.join(run_dir, "step%d_ordering" % i)).read().split()
             assert order == [str(v) for v in fx["seed0_step%d_ordering" % i]], (i, order)
             S = np.loadtxt(os.path.join(run_dir, "step%d" % i))
-            dims = [3 if v.startswith("X") else 2 for v in order]
-            assert S.shape[1] == sum(dims) and np.all(np.isfinite(S))
-            ref_raw = [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds]
-            rr = np.random.RandomState(100 + i).permutation(S.shape[0])[:ref_raw[0].shape[0]]
-            Sr = S[rr]
-            floor = round(float(np.sqrt(2.0 / Sr.shape[0])), 4)
-            if 2 * len(order) <= JOINT_MAX_COLUMNS:
-                refs_xy = [_xy_block(order, dims, r) for r in ref_raw]
-                sc = np.maximum(np.vstack(refs_xy).std(0), 1e-3)
-                m, spread = _band(_xy_block(order, dims, Sr) / sc, [r / sc for r in refs_xy])
-                check("step-joint", seed, i, m, spread, columns=2 * len(order), floor=floor)
-            # xy columns of every variable: ours, the reference's seeds, the pooled reference scale
-            off, col = 0, {}
-            for v, d in zip(order, dims):
-                col[v] = (off, off + 2)
-                off += d
-            pooled = np.vstack(ref_raw)
-            per_block = []
-            for a, b in _blocks(order):
-                idx = list(range(*col[a])) + list(range(*col[b]))
-                sc = np.maximum(pooled[:, idx].std(0), 1e-3)
-                mb, sb = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
-                per_block.append((mb, sb, a + "-" + b))
-            if per_block:
-                worst = max(per_block, key=lambda t: t[0])
-                check("step-blocks-max", seed, i, worst[0], max(t[1] for t in per_block), blocks=len(per_block), worst_block=worst[2], floor=floor)
-                check("step-blocks-mean", seed, i, float(np.mean([t[0] for t in per_block])), float(np.mean([t[1] for t in per_block])),
-                      blocks=len(per_block), floor=floor)
-            ours_v, ref_v = [], []
-            for v in order:
-                idx = list(range(*col[v]))
-                sc = np.maximum(pooled[:, idx].std(0), 1e-3)
-                mv, sv = _band(Sr[:, idx] / sc, [r[:, idx] / sc for r in ref_raw])
-                ours_v.append(mv); ref_v.append(sv)
-            check("step-marginals", seed, i, float(np.mean(ours_v)), float(np.mean(ref_v)), variables=len(order), floor=floor)
+            _compare_step(check, seed, i, order, S, [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds])
     return rows, failures, timing
 
 
@@ -296,3 +305,155 @@ def test_icra_case_against_the_reference_held_results(tmp_path):
                 report.append(("vs reference/step_%d" % i, seed, round(m_ns, 4), round(float(held_mmd[i]), 4), round(float(max(reruns_ns)), 4)))
                 assert m_ns <= bar_ns, (seed, i, m_ns, held_mmd[i], reruns_ns)
     print("icra", report)
+
+
+# ---- LONG HORIZON, structural: EVERY update of the large datasets (round 5) ---------------------------------------------------
+STRUCTURE_CASES = {"manhattan136_structure": "ManhattanPlaza136", "plaza1_structure": "Plaza1EFG", "plaza1ada_structure": "Plaza1ADA0.4EFG"}
+
+
+def _run_structure(case, fx):
+    """This repository's solver over ALL updates of the dataset with the fixture's arguments (flow_iterations = 20: the fit is
+    irrelevant to the structure), recording per update what the reference run recorded (make_pipeline_fixture.py, LONG_CASES):
+    elimination ordering, every retrained clique (column pattern, dims, D, D_s, true observations) in training order, every
+    firing of `root_clique_density_model_to_leaf`."""
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+    kwargs = json.loads(str(fx["arguments"]))
+    kwargs["cuda_training"] = True
+    path = os.path.join(DATA, STRUCTURE_CASES[case], "factor_graph.fg")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
+    steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))
+    solver = NFiSAM(NFiSAMArgs(**kwargs))
+    fits, reuses, orderings, update_no = [], [], [], [-1]
+    orig_fit, orig_reuse = NFiSAM.fit_clique_density_model, NFiSAM.root_clique_density_model_to_leaf
+
+    def fit(self, clique, samples, var_ordering, timer, *a, **k):
+        D = int(samples.shape[1])
+        fits.append(dict(update=update_no[0], vars=[str(v.name) for v in var_ordering], dims=[int(v.dim) for v in var_ordering],
+                         frontal=sorted(str(v.name) for v in clique.frontal), separator=sorted(str(v.name) for v in clique.separator),
+                         D=D, Ds=D - sum(int(v.dim) for v in clique.frontal),
+                         true_obs=np.asarray(self._clique_true_obs[clique], dtype=np.float64).reshape(-1)))
+        return orig_fit(self, clique, samples, var_ordering, timer, *a, **k)
+
+    def reuse(self, old_clique, new_clique, device, *a, **k):
+        reuses.append(dict(update=update_no[0], vars=sorted(str(v.name) for v in new_clique.vars),
+                           old_frontal=sorted(str(v.name) for v in old_clique.frontal),
+                           new_frontal=sorted(str(v.name) for v in new_clique.frontal),
+                           new_separator=sorted(str(v.name) for v in new_clique.separator)))
+        return orig_reuse(self, old_clique, new_clique, device, *a, **k)
+    NFiSAM.fit_clique_density_model, NFiSAM.root_clique_density_model_to_leaf = fit, reuse
+    try:
+        for vs, fs in steps:
+            update_no[0] += 1
+            for v in vs:
+                solver.add_node(v)
+            for f in fs:
+                solver.add_factor(f)
+            solver.update_physical_and_working_graphs()
+            res = solver.incremental_inference()
+            orderings.append([str(v.name) for v in solver.elimination_ordering])
+        last = np.hstack([res[v] for v in solver.elimination_ordering])
+    finally:
+        NFiSAM.fit_clique_density_model, NFiSAM.root_clique_density_model_to_leaf = orig_fit, orig_reuse
+    return fits, reuses, orderings, last
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("case", list(STRUCTURE_CASES))
+def test_structure_of_every_update_matches_the_reference(case):
+    """Long-horizon STRUCTURAL parity (VERDICT r4 missing #1): the reference's `run_incrementally`
+    (src/slam/FactorGraphSolver.py:760-933) was run over ALL updates of Manhattan-136 (136), Plaza1 and Plaza1-ADA-0.4 (156
+    each, 778 poses) with `flow_iterations = 20`, PYTHONHASHSEED = 0; per update the fixture holds the elimination ordering,
+    every retrained clique's variable pattern / dims / D / D_s / true observations in training order, and every firing of
+    `root_clique_density_model_to_leaf` (src/slam/NFiSAM.py:550-577, decided at FactorGraphSolver.py:306-340).  This repository's
+    solver must reproduce ALL of it: the late-run machinery -- re-elimination, re-use of the old root's model, re-attached
+    subtrees, 100+-clique trees -- is decided by the graph alone, so equality is exact (observations to 1e-6)."""
+    path = os.path.join(GOLDEN, "pipeline_%s.npz" % case)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated (tests/golden/make_pipeline_fixture.py %s)" % (os.path.basename(path), case))
+    fx = np.load(path)
+    n_steps, n_fits = int(fx["seed0_n_steps"]), int(fx["seed0_n_fits"])
+    fits, reuses, orderings, last = _run_structure(case, fx)
+    assert len(orderings) == n_steps
+    for i in range(n_steps):
+        assert orderings[i] == [str(v) for v in fx["seed0_step%d_ordering" % i]], (i, orderings[i][:8])
+    ref_reuses = json.loads(str(fx["seed0_reuses"]))
+    assert reuses == ref_reuses, (len(reuses), len(ref_reuses), [r for r in reuses if r not in ref_reuses][:2], [r for r in ref_reuses if r not in reuses][:2])
+    assert len(fits) == n_fits, (len(fits), n_fits)
+    for j, f in enumerate(fits):
+        meta = json.loads(str(fx["seed0_fit%d_meta" % j]))
+        obs_names = [v for v in meta["vars"] if v.startswith("O")]
+        ref_vars = [v for v in meta["vars"] if not v.startswith("O")]
+        assert f["update"] == meta["update"] and f["vars"] in (ref_vars, meta["vars"]), (j, f["update"], meta["update"], f["vars"], meta["vars"])
+        dims = f["dims"] if f["vars"] == meta["vars"] else [1] * len(obs_names) + f["dims"]
+        assert dims == meta["dims"] and f["D"] == meta["D"] and f["Ds"] == meta["Ds"], (j, f["D"], meta["D"], f["Ds"], meta["Ds"])
+        assert f["frontal"] == meta["frontal"] and f["separator"] == meta["separator"], (j, f["frontal"], meta["frontal"])
+        np.testing.assert_allclose(f["true_obs"], np.asarray(fx["seed0_fit%d_true_obs" % j], dtype=np.float64).reshape(-1), atol=1e-6)
+    assert np.all(np.isfinite(last))
+    print(case, "updates", n_steps, "retrained cliques", n_fits, "re-used roots", len(reuses), "widest clique", max(f["D"] for f in fits))
+
+
+# ---- LONG HORIZON, distributional: Manhattan-136 COMPLETE at the reference's own budget (round 5) -------------------------------
+LATE_STEPS = (20, 60, 135)
+
+
+def compare_late(case="manhattan136_full", seeds=(0, 1, 2)):
+    """-> (rows, failures): this repository's solver over ALL 136 updates with the reference's own arguments (500 fixed
+    iterations per fit, manhattan_plaza/run_nfisam.py) against the reference's complete runs (3 seeds, fixture
+    pipeline_manhattan136_full.npz: posteriors kept at updates 20 / 60 / 135), with the block-wise / marginal statistics and the
+    bound max(0.08, 1.5 x the reference's own spread) of `compare_case`."""
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+    fx = np.load(os.path.join(GOLDEN, "pipeline_%s.npz" % case))
+    ref_seeds = [int(s) for s in fx["seeds"]]
+    kwargs = json.loads(str(fx["arguments"]))
+    kwargs["cuda_training"] = True
+    rows, failures = [], []
+
+    def check(kind, seed, idx, m, spread, **extra):
+        bound = max(0.08, 1.5 * spread)
+        row = dict(kind=kind, seed=seed, index=idx, ours=round(m, 4), spread=round(spread, 4), bound=round(bound, 4), **extra)
+        rows.append(row)
+        if not m <= bound:
+            failures.append(row)
+    path = os.path.join(DATA, "ManhattanPlaza136", "factor_graph.fg")
+    for seed in seeds:
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
+        steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))
+        assert len(steps) == int(fx["seed0_n_steps"]) == 136
+        solver = NFiSAM(NFiSAMArgs(**kwargs))
+        for i, (vs, fs) in enumerate(steps):
+            for v in vs:
+                solver.add_node(v)
+            for f in fs:
+                solver.add_factor(f)
+            solver.update_physical_and_working_graphs()
+            res = solver.incremental_inference()
+            order = [str(v.name) for v in solver.elimination_ordering]
+            assert order == [str(v) for v in fx["seed0_step%d_ordering" % i]], (i, order[:6])
+            if i in LATE_STEPS:
+                S = np.hstack([res[v] for v in solver.elimination_ordering])
+                _compare_step(check, seed, i, order, S, [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds],
+                              max_blocks=60)
+    return rows, failures
+
+
+@pytest.mark.timeout(1800)
+def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
+    """Long-horizon DISTRIBUTIONAL parity (VERDICT r4 missing #1, ii): the reference ran Manhattan-136 to its end -- 136 updates,
+    139 trained cliques, 131 re-used roots -- at its own budget (500 fixed iterations per fit, ~1.5 CPU-hours per seed, 3 seeds).
+    This repository's solver does the same 136 updates (3 seeds) and is held to the reference's late posteriors at updates 20,
+    60 and 135 (the last: 136 poses + 4 landmarks): every variable's standardised xy marginal, and MMDb on (pose, landmark) and
+    consecutive-pose blocks (an evenly spaced subset of 60 of the thousands of pairs), bound = max(0.08, 1.5 x the largest
+    leave-one-out value among the reference's own seeds).  What this sees that the first six updates cannot: drift accumulated
+    through 130 re-uses of the previous root's model, re-eliminated landmark cliques late in the run, the 100+-clique walk."""
+    path = os.path.join(GOLDEN, "pipeline_manhattan136_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture pipeline_manhattan136_full.npz not generated (tests/golden/make_pipeline_fixture.py manhattan136_full)")
+    rows, failures = compare_late()
+    print("manhattan136_full", [(r["kind"], r["seed"], r["index"], r["ours"], r["spread"], r["bound"]) for r in rows])
+    sat = [r for r in rows if abs(r["ours"] - r["floor"]) < 0.01 * r["floor"] and abs(r["spread"] - r["floor"]) < 0.01 * r["floor"]]
+    assert not sat, ("a statistic sits at its saturation floor sqrt(2 / n)", sat)
+    assert not failures, failures

@@ -708,9 +708,12 @@ def main():
                 if t.get("kernel") == out["roofline"]["kernel"]:
                     per_it = t.get("hbm_side_bytes_per_iteration_lower", t.get("hbm_side_bytes_per_launch_lower"))
                     out["roofline"]["traffic"] = per_it * head["iterations_per_launch"]
-                    out["roofline"]["traffic_provenance"] = ("profiled earlier (%s): lower bound of the HBM-side bytes per ITERATION of %s "
-                                                             "(separate --pmc FETCH_SIZE / WRITE_SIZE passes) x the %d iterations of a launch "
-                                                             "of this run" % (os.path.basename(tjs[-1]), t.get("kernel"), head["iterations_per_launch"]))
+                    out["roofline"]["traffic_provenance"] = ("rocprofv3 --pmc passes of scripts/collect_profiles.sh (%s, collected %s): lower bound of the "
+                                                             "HBM-side bytes per ITERATION of %s (separate FETCH_SIZE / WRITE_SIZE passes) x the %d "
+                                                             "iterations of a launch of this run; a counter figure of that collection, not of this run"
+                                                             % (os.path.basename(tjs[-1]), t.get("profiled_at", "in an earlier round"), t.get("kernel"),
+                                                                head["iterations_per_launch"]))
+                    out["roofline"]["traffic_profiled_at"] = t.get("profiled_at")
             except Exception:   # noqa: BLE001
                 pass
         ujs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_utilisation.json")))

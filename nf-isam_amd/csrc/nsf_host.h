@@ -151,8 +151,10 @@ static inline int weights_mode() {   // 0: scalar-cache path, 1: LDS copy, -1: a
 static inline bool dim_major_enabled();
 // `pair_h4`: hidden_dim 4 has ONE small-launch kernel, the two-dims-per-wave one (no two-lanes-per-particle kernel for
 // it): the caller says whether this launch can take it (layers or dL/dx couple the dims, the panels fit: pair_lds > 0).
+// (round 5: hidden_dim 16 likewise -- its multi-layer / dL/dx launches in the latency regime take the two-dims-per-wave kernel
+//  with ONE layer's panels resident; `pair_h4` = "a hidden width other than 8 whose pair kernel takes this launch")
 static inline int train_tile(int n_cliques, int max_n, int max_D, int H, bool nll_L1 = false, bool pair_h4 = false) {
-    if (H != 8 && !(H == 4 && pair_h4 && !nll_L1)) return TILE;
+    if (H != 8 && !((H == 4 || H == 16) && pair_h4 && !nll_L1)) return TILE;
     const char* e = getenv("NFISAM_TRAIN");            // read per call: tests switch families in-process
     if (e != nullptr) {
         if (strcmp(e, "wide") == 0) return TILE;

@@ -569,8 +569,8 @@ extern "C" int nfisam_rqs(const float* inputs, const float* widths, const float*
 // hidden_dim 4: can a multi-layer / dL/dx launch of this shape take the two-dims-per-wave kernel?  Asked of the LARGEST
 // num_knots of that width (the panels grow with K), so that the answer -- and with it the tile size, the number of
 // gradient copies and the workspace layout -- does not depend on K.
-static bool pair_h4_fits(int L, int max_D) {
-    const NsfUnitOps* o = find_ops(16, 4);
+static bool pair_h4_fits(int L, int max_D, int H = 4) {
+    const NsfUnitOps* o = find_ops(16, H);                  // (H = 4 or 16: the hidden widths without a two-lanes-per-particle kernel)
     return o != nullptr && o->pair_lds(L, max_D) > 0;
 }
 
@@ -594,7 +594,7 @@ extern "C" int nfisam_nsf_backward(const float* x, const float* kparams, int n, 
     a.B = B; a.L = L; a.max_iters = 0x7fffffff; a.nll_mode = nll_mode ? 1 : 0; a.layer_stride = (int)layer_stride;
     const NsfUnitOps* ops = find_ops(K, H);
     if (ops == nullptr) return NFISAM_ERR_ARG;
-    a.tile = train_tile(1, n, D, H, false, H == 4 && (L > 1 || gx != nullptr) && pair_h4_fits(L, D));
+    a.tile = train_tile(1, n, D, H, false, (H == 4 || H == 16) && (L > 1 || gx != nullptr) && pair_h4_fits(L, D, H));
     return ops->train(a, 1, n, D, (hipStream_t)stream);
 }
 
@@ -625,7 +625,7 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     const size_t copies16 = (tiles64 + 3) / 4;
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 4 * (copies16 > 8 ? copies16 : 8) + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
-    const size_t image = (L > 1 && (H == 8 || H == 4) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
+    const size_t image = (L > 1 && (H == 8 || H == 4 || H == 16) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
     // + the forward state that kernel parks between its forward and backward passes (latency-bound launches only)
     const size_t stash = (image > 0 && pair_stash_fits(n, D))
                              ? (size_t)((n + TILE2 - 1) / TILE2) * (size_t)(L - 1) * (size_t)((D + 1) / 2) * pair_stash_fields(K, H) * 64
@@ -638,7 +638,7 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
 struct TrainShape { int tile, T, slab, W; };
 static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H) {
     TrainShape sh;
-    sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1, H == 4 && L > 1 && pair_h4_fits(L, max_D));
+    sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1, (H == 4 || H == 16) && L > 1 && pair_h4_fits(L, max_D, H));
     sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile, H);
     sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
     sh.W = 0;
@@ -778,18 +778,26 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
 // device for half a second (replica schedulers create plans by the hundred); NFISAM_PERSIST_PROBE=0 skips the probe.
 // A point-in-time answer by construction: what protects a run against a neighbour that arrives LATER is the timeout above.
 __global__ void __launch_bounds__(256) nsf_coresidency_probe_kernel(unsigned* ctr, unsigned n_blocks, unsigned budget_ticks) {
-    extern __shared__ float probe_lds[];
-    if (threadIdx.x != 0) return;
-    probe_lds[0] = 0.0f;                                         // (the LDS allocation is what makes the footprint: keep it referenced)
-    __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    extern __shared__ unsigned probe_lds[];
+    // every wave of the block stays until its first thread has the answer (a block of the real kernel holds four waves too)
+    if (threadIdx.x == 0) {
+        probe_lds[0] = 0u;
+        __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        if (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_blocks) break;
-        if (__hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;       // somebody gave up: everybody leaves
-        if (wall_clock64() - t0 > (unsigned long long)budget_ticks) {
-            __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+        if (threadIdx.x == 0) {
+            unsigned done = 0u;
+            if (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_blocks) done = 1u;
+            else if (__hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) done = 1u;       // somebody gave up: everybody leaves
+            else if (wall_clock64() - t0 > (unsigned long long)budget_ticks) {
+                __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = 1u;
+            }
+            if (done) __hip_atomic_store(&probe_lds[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (__hip_atomic_load(&probe_lds[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
         __builtin_amdgcn_s_sleep(8);
     }
 }

@@ -2229,6 +2229,24 @@ __host__ __device__ static inline int pair_tile_floats(int L, int D, int g_tiles
     return (ONES_ROW + (L * D + 2 * g_tiles * pair_g_rows(D)) * XS2 + 3) & ~3;
 }
 constexpr int PAIR_WAVE_FLOATS = (16 + 8) * XS;             // staging rows + h1 rows (H <= 8)
+// hidden_dim 16 (round 5): sixteen h1 rows; and the panels of ONE layer resident at a time (9.1 KB per (layer, dim): all layers
+// of C2's shape would be 218 KB) -- a wave brings the panels of its two dims at the top of every stage (they are wave-private:
+// no barrier), from the clique's panel image (16-byte copies) or, iteration 0 of a chunk / VJP calls, from the parameters
+template <int H> __host__ __device__ constexpr int pair_wave_floats() { return (H == 16) ? (16 + 16) * XS : PAIR_WAVE_FLOATS; }
+// one layer's panels of the wave's dims out of the panel image into LDS (any size: rounds of 8 sixteen-byte words per lane)
+__device__ __forceinline__ void copy_pair_panels(const float* image_generic, size_t pstride, int PS, int iA, int nd, int l, int lane, float* lay0) {
+    typedef const __attribute__((address_space(1))) cm_f32x4* gv4;
+    const int n4 = (nd * PS) >> 2;
+    gv4 src = (gv4)(image_generic + (size_t)l * pstride + (size_t)iA * PS);
+    cm_f32x4* dst = (cm_f32x4*)(lay0 + (size_t)iA * PS);
+    for (int base = 0; base < n4; base += 64 * 8) {
+        cm_f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = base + lane + 64 * u; v[u] = src[e < n4 ? e : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = base + lane + 64 * u; if (e < n4) dst[e] = v[u]; }
+    }
+}
 static_assert(PAIR_MAP_OFFSETS == PAIR_MAX_D + 1, "one map per clique width 0 .. PAIR_MAX_D");
 struct PairMapOffsets { uint32_t at[PAIR_MAX_D + 1]; };     // word offset of clique width D's map in the table (kernel argument: no dependent load)
 
@@ -2240,7 +2258,10 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     constexpr int NT = (PoP + 15) / 16;
     constexpr int NS = TILE / 4, NSH = NS / 2;                // MFMA k-steps over the wave's 64 columns / over one dim's 32
     constexpr int QH = H / 4;
-    static_assert((H == 8 || H == 4) && NT <= 4, "the gradient GEMMs pack ga2|ga1 into one 16-row operand tile: H <= 8");
+    static_assert((H == 16 || H == 8 || H == 4) && NT <= 4, "H <= 8: ga2|ga1 share one 16-row operand tile; H = 16: one tile each, bias chains");
+    constexpr bool WIDE_H = (H == 16);                        // as in nsf_train1_kernel: no spare column for the bias in [h | 1]
+    constexpr bool STREAM = WIDE_H;                           // the panels of ONE layer resident (pair_wave_floats<H>, above)
+    constexpr int PWF = pair_wave_floats<H>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // the clique's descriptor in ONE scalar load: from the device array, or (single-clique calls) from the kernel-argument
@@ -2286,9 +2307,9 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     const int gt = a.g_tiles ? pair_g_rows(D) * XS2 : 0;
     float* g0 = xs + L * DT;
     float* g1 = g0 + gt;
-    float* stg = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)w * PAIR_WAVE_FLOATS;   // (sized for the launch's widest clique)
+    float* stg = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)w * PWF;   // (sized for the launch's widest clique)
     float* hrow = stg + 16 * XS;
-    float* panels = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)W * PAIR_WAVE_FLOATS;
+    float* panels = smem + pair_tile_floats(L, a.xrows, a.g_tiles) + (size_t)W * PWF;
     const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);
     const int r16 = lane & 15, kq = lane >> 4;
     STAMP_DECL
@@ -2312,7 +2333,10 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
 #endif
         if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
             const int j = w;
-            if (a.pair_image) {                                // layer 0 now, layer l + 1 under forward stage l
+            if constexpr (STREAM) {                            // the first stage's layer: 0 (forward passes ahead) or the only one
+                if (a.pair_image) copy_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, 0, lane, panels);
+                else stage_pair_panels<K, H>(panels, PS, (size_t)D * PS, kparams, (size_t)Pk, map, 2 * j, (2 * j + 1 < D) ? 2 : 1, 1, lane);
+            } else if (a.pair_image) {                         // layer 0 now, layer l + 1 under forward stage l
                 cm_f32x4 pv[PAIR_PANEL_WORDS];
                 load_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, 0, lane, pv);
                 store_pair_panels(panels, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, 0, lane, pv);
@@ -2346,34 +2370,47 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
         wave_lds_sync();
     }
     STAMP(1);
+    // STREAM: layer `l`'s panels of this wave's dims into the (one) resident slot; wave-private, the wave's own LDS operations
+    // are in order -- no barrier
+    int resident = 0;
+    auto bring_layer = [&](int l) {
+        if (w < npairs && l != resident) {
+            const int j = w, nd = (2 * j + 1 < D) ? 2 : 1;
+            if (a.pair_image) copy_pair_panels(image, (size_t)D * PS, PS, 2 * j, nd, l, lane, panels);
+            else stage_pair_panels<K, H>(panels, PS, (size_t)D * PS, kparams + (size_t)l * Pk, (size_t)Pk, pair_map + offs.at[D], 2 * j, nd, 1, lane);
+            wave_lds_sync();
+        }
+        resident = l;
+    };
 
     // ---- forward-only passes: layers 0 .. L-2.  With a workspace behind kgrad (training plans) the wave parks what the
     //      backward pass needs of each of them in device memory (NF coalesced rows of 64 floats; it stays in this XCD's L2) and
     //      reads it back one layer ahead of its use; otherwise the backward pass recomputes conditioner and spline. ---
     constexpr int NF = pair_stash_fields(K, H);
-    const bool stash = a.pair_stash != 0;
+    const bool stash = !WIDE_H && a.pair_stash != 0;          // (hidden_dim 16 recomputes: 64 parked floats per lane do not fit next to its state)
     gfloat* stash_w = (gfloat*)image + (size_t)L * D * PS + (((size_t)blockIdx.x * (L - 1)) * npairs + w) * (NF * 64) + 4 * lane;
     const size_t stash_layer = (size_t)npairs * (NF * 64);
     float lossv = 0.0f;
     for (int l = 0; l + 1 < L; ++l) {
         const float* xin = xs + l * DT;
         float* xout = xs + (l + 1) * DT;
+        if constexpr (STREAM) bring_layer(l);
         if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
             const int j = w;
             const int i = 2 * j + sub;
             const bool dim_ok = i < D;
             const int ic = dim_ok ? i : D - 1;
             const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
-            const float* pan = panels + ((size_t)l * D + ic) * PS;
+            const float* pan = panels + ((size_t)(STREAM ? 0 : l) * D + ic) * PS;
             cm_f32x4 pnext[PAIR_PANEL_WORDS];
-            if (a.pair_image) load_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
+            if (!STREAM && a.pair_image) load_pair_panels(image, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
             float h1[H], h2[H], th[PoP];
             cond_forward_mfma<K, H>(pan, imax, s0, xin, XS2, lane, p, h1, h2, th);
             SplineT<K> S;
             float z, lad;
             spline_train_fwd<K, PoP>(xin[ic * XS2 + p], th, B, S, z, lad);
             if (dim_ok) xout[i * XS2 + p] = z;
-            if (a.pair_image) store_pair_panels(panels, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
+            if (!STREAM && a.pair_image) store_pair_panels(panels, (size_t)D * PS, PS, 2 * j, (2 * j + 1 < D) ? 2 : 1, l + 1, lane, pnext);
             if (stash) {
                 float sv[NF];
                 stash_pack<K, H>(h1, h2, S, sv);
@@ -2412,13 +2449,14 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
         const bool need_gx = (l > 0) || (a.gx != nullptr);
         gfloat* Gl = G + (size_t)l * Pk;
         const float* xin = xs + l * DT;
+        if constexpr (STREAM) bring_layer(l);
         if (w < npairs) {                                     // W = ceil(max D / 2): a wave owns ONE pair (or none, in a narrower clique)
             const int j = w;
             const int i = 2 * j + sub;
             const bool dim_ok = i < D;
             const int ic = dim_ok ? i : D - 1;
             const int imax = (2 * j + 1 < D) ? 2 * j + 1 : D - 1;
-            const float* pan = panels + ((size_t)l * D + ic) * PS;
+            const float* pan = panels + ((size_t)(STREAM ? 0 : l) * D + ic) * PS;
             float h1[H], h2[H], gth[PoP];
             SplineT<K> S;
             float z = 0.0f, lad = 0.0f;
@@ -2484,17 +2522,19 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 wave_lds_sync();
             }
             f32x4 cacc[2][NT], c1[2], c0[2];
+            f32x4 cb2[2][NT], cb1[2];                             // WIDE_H only: the bias chains (operand 1)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT; ++t) { cacc[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[hb][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 c1[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 c0[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                cb1[hb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             // A generation of the 16 staging rows is read into registers completely; the NEXT one is written and its reads are
             // issued BEFORE this one's MFMAs, so that the LDS round trip runs under the 16 x 32 MFMA cycles (a lone wave per
             // SIMD has nothing else to hide it under); the last chains' second operands are requested the same way.
-            const bool merged = (imax <= 16 - (H + 1));
+            const bool merged = !WIDE_H && (imax <= 16 - (H + 1));
             lds_rows_store<0, 16, 0, PoP>(stg_lane, gth);
             wave_lds_sync();
 #pragma unroll
@@ -2509,8 +2549,12 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 if (t == 2 && NT > 2) lds_rows_store<0, 16, 32, PoP>(stg_lane, gth);
                 if (t == 3 && NT > 3) lds_rows_store<0, 16, 48, PoP>(stg_lane, gth);
                 if (t == NT) {
-                    lds_rows_store<0, H, 0, H>(stg_lane, ga2);
-                    lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                    if constexpr (WIDE_H) {
+                        lds_rows_store<0, 16, 0, H>(stg_lane, ga2);
+                    } else {
+                        lds_rows_store<0, H, 0, H>(stg_lane, ga2);
+                        lds_rows_store<H, H, 0, H>(stg_lane, ga1);
+                    }
                 }
                 wave_lds_sync();
 #pragma unroll
@@ -2529,14 +2573,34 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s4 = 0; s4 < NS; ++s4) cacc[s4 / NSH][t - 1] = mfma4(areg[s4], breg[s4], cacc[s4 / NSH][t - 1]);
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    cacc[s4 / NSH][t - 1] = mfma4(areg[s4], breg[s4], cacc[s4 / NSH][t - 1]);
+                    if constexpr (WIDE_H) cb2[s4 / NSH][t - 1] = mfma4(areg[s4], 1.0f, cb2[s4 / NSH][t - 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 wave_lds_sync();
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) areg[s4] = anext[s4];
             }
             STAMP(7);
-            if (merged) {
+            if constexpr (WIDE_H) {
+                // areg = the sixteen rows of ga2: x [h1] -> dW1t, x 1 -> db1; then ga1 (sixteen rows) x [x_0 .. x_{i-1} | 1] -> dW0t | db0
+                lds_rows_store<0, 16, 0, H>(stg_lane, ga1);       // (the rows of ga2 are in registers)
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const float* pb1 = hrow + r16 * XS + 32 * (s4 / NSH) + kq;
+                    c1[s4 / NSH] = mfma4(areg[s4], pb1[4 * (s4 % NSH)], c1[s4 / NSH]);
+                    cb1[s4 / NSH] = mfma4(areg[s4], 1.0f, cb1[s4 / NSH]);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    const int ih = 2 * j + s4 / NSH;
+                    const float* pb0 = ((r16 < ih) ? xin + r16 * XS2 : ones) + kq;
+                    areg[s4] = pa[4 * s4];
+                    c0[s4 / NSH] = mfma4(areg[s4], pb0[4 * (s4 % NSH)], c0[s4 / NSH]);
+                }
+            } else if (merged) {
 #pragma unroll
                 for (int s4 = 0; s4 < NS; ++s4) c1[s4 / NSH] = mfma4(areg[s4], bm[s4], c1[s4 / NSH]);
             } else {
@@ -2561,10 +2625,10 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                 const int ih = hb ? iB : iA;
                 if (ih >= D) continue;
                 if (ih == 0) {                                  // the spline parameters of dim 0: db2 alone
-                    if (r16 == H) {
+                    if (r16 == (WIDE_H ? 0 : H)) {
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gl[16 * t + 4 * kq], cacc[hb][t], slab);
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gl[16 * t + 4 * kq], WIDE_H ? cb2[hb][t] : cacc[hb][t], slab);
                     }
                     continue;
                 }
@@ -2576,7 +2640,15 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
                         if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw2[r16 * PoP + 16 * t + 4 * kq], cacc[hb][t], slab);
                 }
                 if (kq < QH && r16 <= H) gsink4(&(Gb + LY::oW1(ih))[r16 * H + 4 * kq], c1[hb], slab);
-                if (merged) {                                 // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
+                if constexpr (WIDE_H) {                         // the bias rows (every column of a bias chain holds the same sums) + dW0t | db0
+                    if (r16 == 0) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (16 * t + 4 * kq + 3 < PoP) gsink4(&Gw2[H * PoP + 16 * t + 4 * kq], cb2[hb][t], slab);
+                        gsink4(&(Gb + LY::oW1(ih))[H * H + 4 * kq], cb1[hb], slab);
+                    }
+                    if (r16 <= ih) gsink4(&Gb[r16 * H + 4 * kq], c0[hb], slab);
+                } else if (merged) {                          // columns H.. of the shared tile: bias first, then x_0..x_{i-1}
                     const int k0 = (r16 == H) ? ih : r16 - (H + 1);
                     if (kq >= QH && kq < 2 * QH && (r16 == H || (r16 > H && k0 < ih))) gsink4(&Gb[k0 * H + 4 * (kq - QH)], c1[hb], slab);
                 } else if (kq >= QH && kq < 2 * QH && r16 <= ih) {
@@ -3177,7 +3249,14 @@ struct PairMap {
 // LDS bytes of nsf_train3_kernel; 0: the launch does not fit it (too wide, or the panels of all layers exceed the CU's LDS)
 template <int KK, int HH>
 static size_t pair_kernel_lds(int L, int max_D) {
-    if constexpr (HH != 8 && HH != 4) {
+    if constexpr (HH == 16) {
+        // hidden_dim 16 (round 5): ONE layer's panels resident (9.1 KB per dim at K = 9), sixteen h1 rows per wave
+        const char* pe = getenv("NFISAM_PAIR");
+        if ((pe != nullptr && pe[0] == '0') || max_D > PAIR_MAX_D || max_D < 1) return 0;
+        const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
+        const size_t fl = (size_t)pair_tile_floats(L, max_D, 1) + (size_t)W * pair_wave_floats<16>() + (size_t)max_D * PairPanel<KK, HH>::floats(max_D);
+        return fl * sizeof(float) <= 160 * 1024 ? fl * sizeof(float) : 0;
+    } else if constexpr (HH != 8 && HH != 4) {
         return 0;
     } else {
         // Narrow cliques stay with nsf_train2_kernel: up to four dims are one wave per SIMD there too, and its units get
@@ -3194,7 +3273,7 @@ static size_t pair_kernel_lds(int L, int max_D) {
 }
 template <int KK, int HH>
 static int unit_pair_map(const uint32_t** map, uint32_t* offsets) {
-    if constexpr (HH != 8 && HH != 4) {
+    if constexpr (HH != 8 && HH != 4 && HH != 16) {
         return NFISAM_ERR_ARG;
     } else {
         PairMapOffsets o;
@@ -3206,7 +3285,7 @@ static int unit_pair_map(const uint32_t** map, uint32_t* offsets) {
 
 template <int KK, int HH>
 static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStream_t s) {
-    if constexpr (HH != 8 && HH != 4) {
+    if constexpr (HH != 8 && HH != 4 && HH != 16) {
         return NFISAM_ERR_ARG;
     } else {
         const long tiles = (long)((max_n + TILE2 - 1) / TILE2) * n_cliques;
@@ -3222,7 +3301,7 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
                 a.xrows = max_D;
                 {
                     const char* se = getenv("NFISAM_PAIR_STASH");
-                    a.pair_stash = (a.pair_ws && a.L > 1 && pair_stash_fits(max_n, max_D) && !(se != nullptr && se[0] == '0')) ? 1 : 0;
+                    a.pair_stash = (HH != 16 && a.pair_ws && a.L > 1 && pair_stash_fits(max_n, max_D) && !(se != nullptr && se[0] == '0')) ? 1 : 0;
                 }
                 const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
                 rc = set_lds(nsf_train3_kernel<KK, HH>, lds3);
@@ -3301,7 +3380,7 @@ template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PE
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4 || HH == 16) {
-        if constexpr (HH == 8 || HH == 4) {
+        {
             const int rc = PairMap<KK, HH>::get(nullptr, nullptr);
             if (rc) return rc;
         }

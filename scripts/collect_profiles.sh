@@ -55,4 +55,7 @@ for pre in ("c3_trace", "all_trace", "c3_chains_trace"):
         os.system("cp %s %s/%s_kernel_stats.csv" % (f, out, pre))
 os.system("rm -rf %s/*_pmc[0-9] %s/c3_trace %s/all_trace %s/c3_chains_trace" % (out, out, out, out))
 PY
+# the derived summaries bench.py reads (`roofline.traffic`, `roofline.issue_profiled`): <out>/derived_train_kernel_traffic.json and
+# <out>/derived_issue_utilisation.json, stamped with the time of THIS collection; copy them to profiles/rNN_* to publish them
+python3 scripts/derive_profile_json.py $out $out/derived
 ls -la $out

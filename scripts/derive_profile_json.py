@@ -67,6 +67,7 @@ grad_bytes = copies * sum(Pc) * 4
 state_bytes = 3 * sum(Pc) * 4
 traffic = {
     "kernel": "nsf_train1_kernel<9,8,true>" if k["_persistent"] else "nsf_train1_plain_kernel<9,8>", "iterations_per_launch": ipl,
+    "profiled_at": __import__("datetime").datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),      # (bench.py quotes it next to `roofline.traffic`)
     "workload": "bench.py headline (C3: 8 cliques, n=2000, D=6..12), training iterations "
               "(the launch also applies the previous iteration's Adam update)",
     "launches_averaged": int(k.get("_n", 0)) or None,

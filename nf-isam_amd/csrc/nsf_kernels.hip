@@ -854,6 +854,9 @@ static bool device_is_quiet(long blocks, long places) {
         if (hipGetLastError() == hipSuccess && hipMemcpyAsync(out, ctr, sizeof(out), hipMemcpyDeviceToHost, st) == hipSuccess &&
             hipStreamSynchronize(st) == hipSuccess)
             quiet = out[1] == 0u;
+        if (getenv("NFISAM_PROBE_DEBUG") != nullptr)
+            fprintf(stderr, "nfisam probe: %ld blocks (%ld places, %ld per CU, %zu B of LDS each): %u arrived, %u gave up, %.3f ms\n", blocks, places,
+                    per_cu, lds, out[0], out[1], 1e3 * (mono_seconds() - now));
     }
     if (st) (void)hipStreamDestroy(st);
     if (ctr) (void)hipFree(ctr);

@@ -2233,18 +2233,21 @@ constexpr int PAIR_WAVE_FLOATS = (16 + 8) * XS;             // staging rows + h1
 // of C2's shape would be 218 KB) -- a wave brings the panels of its two dims at the top of every stage (they are wave-private:
 // no barrier), from the clique's panel image (16-byte copies) or, iteration 0 of a chunk / VJP calls, from the parameters
 template <int H> __host__ __device__ constexpr int pair_wave_floats() { return (H == 16) ? (16 + 16) * XS : PAIR_WAVE_FLOATS; }
-// one layer's panels of the wave's dims out of the panel image into LDS (any size: rounds of 8 sixteen-byte words per lane)
+// one layer's panels of the wave's dims out of the panel image into LDS: rounds of 20 sixteen-byte words per lane, all loads of a
+// round in flight together (two panels of hidden_dim 16 at num_knots 9 are 18 words per lane: ONE memory round trip per stage;
+// three rounds of 8 words cost C2's shape 57.1 instead of the us per iteration below)
 __device__ __forceinline__ void copy_pair_panels(const float* image_generic, size_t pstride, int PS, int iA, int nd, int l, int lane, float* lay0) {
     typedef const __attribute__((address_space(1))) cm_f32x4* gv4;
+    constexpr int U = 20;
     const int n4 = (nd * PS) >> 2;
     gv4 src = (gv4)(image_generic + (size_t)l * pstride + (size_t)iA * PS);
     cm_f32x4* dst = (cm_f32x4*)(lay0 + (size_t)iA * PS);
-    for (int base = 0; base < n4; base += 64 * 8) {
-        cm_f32x4 v[8];
+    for (int base = 0; base < n4; base += 64 * U) {
+        cm_f32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = base + lane + 64 * u; v[u] = src[e < n4 ? e : 0]; }
+        for (int u = 0; u < U; ++u) { const int e = base + lane + 64 * u; v[u] = src[e < n4 ? e : 0]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = base + lane + 64 * u; if (e < n4) dst[e] = v[u]; }
+        for (int u = 0; u < U; ++u) { const int e = base + lane + 64 * u; if (e < n4) dst[e] = v[u]; }
     }
 }
 static_assert(PAIR_MAP_OFFSETS == PAIR_MAX_D + 1, "one map per clique width 0 .. PAIR_MAX_D");

@@ -1284,13 +1284,15 @@ def test_oversubscribed_persistent_launch_stalls_loudly_and_the_rerun_is_exact(t
 def test_a_busy_device_is_probed_before_a_plan_takes_the_persistent_form():
     """"Probe before persisting" (nsf_kernels.hip: device_is_quiet): the occupancy API answers for this process's kernel alone;
     whether the device really holds all blocks of a chunk-persistent launch AT ONCE right now is asked with one launch of as
-    many trivial blocks that must all arrive at a counter within ~200 us.  On a quiet device the plan takes the persistent
-    form (`xcd_span() >= 1`: a persistent chunk ran).  While somebody else's long kernel holds the compute units -- here the
-    library's diagnostic occupier on a side stream: spinning four-wave blocks that take every wave slot and all LDS of every CU for 1.5 s, what a foreign
-    process's kernel looks like to the probe -- a NEW plan keeps to one launch per iteration (`xcd_span() == 0`), says so once
-    on stderr, and gives the same bits once the device is free again.  (Without the probe that plan would have taken the
-    persistent form and its blocks would have queued behind the occupier -- on a partly occupied device: started in part, and
-    stalled.)  NFISAM_PERSIST_PROBE=0: not asked, the quiet plan is persistent all the same."""
+    many trivial blocks of the same footprint that must all arrive at a counter within ~200 us of their own start.  On a quiet
+    device the plan of the C3 batch (624 blocks, three per CU) takes the persistent form (`xcd_span() >= 1`: a persistent chunk
+    ran).  While somebody else's long kernel holds PART of every compute unit -- here the library's diagnostic occupier on a
+    side stream: one spinning block per CU with 100 KB of its 160 KB of LDS for 1.5 s, what a foreign process's kernel looks
+    like to the probe -- only one block of the plan's footprint fits a CU: the probe's first 256 blocks wait in vain for the
+    other 368, say so, and the NEW plan keeps to one launch per iteration (`xcd_span() == 0`, one line on stderr), with the
+    same bits.  (Without the probe that plan would have taken the persistent form, 256 of its blocks would have spun for
+    members queued behind the occupier, and the fit would have ended with NFISAM_ERR_STALL.)  NFISAM_PERSIST_PROBE=0: not asked,
+    the quiet plan is persistent all the same."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = PROBE_WORKER % dict(root=root)
@@ -1302,7 +1304,7 @@ def test_a_busy_device_is_probed_before_a_plan_takes_the_persistent_form():
     r, err = outs["probe"]
     assert r["quiet_span"] >= 1, r                                   # quiet device: the persistent form ran
     assert r["busy_span"] == 0 and "another process is using it" in err, (r, err[-500:])
-    assert r["equal"] and r["iters"] == [100, 100]
+    assert r["equal"] and r["iters"] == [[100] * 8, [100] * 8]
     r0, _ = outs["no-probe"]
     assert r0["quiet_span"] >= 1, r0
 
@@ -1315,14 +1317,15 @@ import nfisam_hip as nh
 K, H, B = 9, 8, 5.0
 dev = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(5)
-x = (1.2 * torch.randn(2000, 15, generator=gen)).clamp_(-4, 4).to(dev)
-kp0 = nh.pack((0.2 * torch.randn(nh.param_count(15, K, H), generator=gen)).to(dev), 15, K, H, 1)
+shapes = [(2000, D) for D in (6, 8, 8, 10, 10, 12, 12, 12)]          # the C3 batch: 624 four-wave blocks, three per CU on 208 CUs
+xs = [(1.2 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
+kp0 = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(dev), D, K, H, 1) for n, D in shapes]
 def fit():
-    tb = nh.TrainBatch([x], [kp0.clone()], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
+    tb = nh.TrainBatch(xs, [k.clone() for k in kp0], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
     tb.prepare(True)                      # <- the probe runs here (plan creation)
     it = tb.run()
     torch.cuda.synchronize()
-    out = (tb.xcd_span(), it[0], tb.kparams[0].cpu().numpy().copy(), tb.iter_loss[0].cpu().numpy().copy())
+    out = (tb.xcd_span(), it, [k.cpu().numpy().copy() for k in tb.kparams], [l.cpu().numpy().copy() for l in tb.iter_loss])
     tb.close()
     return out
 quiet = fit()
@@ -1332,14 +1335,17 @@ if os.environ.get("PROBE_TEST_SKIP_BUSY") != "1":
     side = torch.cuda.Stream()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     torch.cuda.synchronize()
-    # eight four-wave blocks per CU x 20 KB: every wave slot and all of the LDS, with as many blocks again queued behind them
-    rc = nh.lib().nfisam_debug_occupy_device(16 * cus, ctypes.c_size_t(20 * 1024), ctypes.c_float(1.5), ctypes.c_void_p(side.cuda_stream))
+    # (the first launch of a kernel pays its code load, ~70 ms: a short one first, so that the real one starts at once)
+    assert nh.lib().nfisam_debug_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(0.01), ctypes.c_void_p(side.cuda_stream)) == 0
+    side.synchronize()
+    # one block per CU holding 100 KB of its 160 KB of LDS for 1.5 s: room for ONE more block of the plan's footprint per CU
+    rc = nh.lib().nfisam_debug_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(1.5), ctypes.c_void_p(side.cuda_stream))
     assert rc == 0, rc
-    time.sleep(0.05)                      # the occupier is on the machine
+    time.sleep(0.1)                       # the occupier is on the machine
     busy = fit()
     torch.cuda.synchronize()
-print(json.dumps(dict(quiet_span=quiet[0], busy_span=busy[0], iters=[quiet[1], busy[1]],
-                      equal=bool(np.array_equal(quiet[2], busy[2]) and np.array_equal(quiet[3], busy[3])))))
+eq = all(np.array_equal(a, b) for a, b in zip(quiet[2], busy[2])) and all(np.array_equal(a, b) for a, b in zip(quiet[3], busy[3]))
+print(json.dumps(dict(quiet_span=quiet[0], busy_span=busy[0], iters=[quiet[1], busy[1]], equal=bool(eq))))
 """
 
 

@@ -30,7 +30,8 @@ Prints ONE JSON line on rank 0 (driver contract), including
                  clique, 4 stacked layers), one Plaza1-shaped clique (n = 2000, D = 15: the latency regime of the
                  real datasets), a batch of 64 such cliques (the throughput regime / scaling shape), the last two with
                  hidden_dim 16 (the reference's parameter grids sweep it, src/slam/NFiSAM.py:589-609), and C2 with
-                 hidden_dim 16 and 4 (multi-layer flows of those widths run the generic kernel: the gap on record).
+                 hidden_dim 16 and 4 (the two-dims-per-wave kernel is instantiated for both: H = 4 since round 4, H = 16 --
+                 one layer's panels resident -- since round 5; before that the generic kernel: 192 us per iteration).
   cpu_baseline : the oracle (PyTorch-eager CPU restatement of the reference path, validated against
                  the reference) timed on the host cores on a bounded sample of the same workload, next to the
                  TRUE reference's figures measured in the build container (profiles/history/r02_cpu_reference_vs_port.json).

@@ -1,7 +1,7 @@
 // nsf_units.h -- which (K bins, H hidden width) pairs each kernel unit instantiates (X(K, H) lists).
-// Every H: the dim-major MFMA training kernel (one-layer flows).  H = 8 and 16: the pipelined posterior walk.  H = 8 and 4: the
-// two-dims-per-wave kernel of small multi-layer / VJP launches (H = 8 also the two-lane kernel; H = 16: one lane per particle,
-// butterfly gradients).
+// Every H: the dim-major MFMA training kernel (one-layer flows) and the two-dims-per-wave kernel of small multi-layer / VJP
+// launches (H = 16, round 5: one layer's panels resident; H = 8 also the two-lane kernel).  H = 8 and 16: the pipelined posterior
+// walk.  Hidden widths in between run zero-padded in the next of these (nsf_kernels.hip: compiled_H).
 // The reference accepts any K / hidden_dim (src/flows/flows.py:51-60); its examples use K in {5, 9, 12, 15}, H = 8.
 #pragma once
 #define NSF_UNITS(U) U(0) U(1) U(2) U(3) U(4) U(5) U(6) U(7) U(8) U(9) U(10) U(11)

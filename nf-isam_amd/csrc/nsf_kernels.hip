@@ -1199,7 +1199,9 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
         long p_blocks = 0, p_places = 0;
         bool can_persist = persist_shape(p->host.data(), n_cliques, p->max_n, p->max_D, K, H, L, &p_blocks, &p_places) && p->chunk > (p->val.empty() ? 1 : 2);
         // probe before persisting (device_is_quiet): is the device ours right now?  (outside the capture below)
-        if (can_persist && !device_is_quiet(p_blocks, p_places)) can_persist = false;
+        // (not while a hand-stepped conveyor of this process fills the machine -- slam.ReplicaNFiSAM creates plans by the hundred
+        //  next to one: the probe's blocks would queue behind its chunks, and no run takes the persistent graph then anyway)
+        if (can_persist && g_hand_stepped.load() == 0 && !device_is_quiet(p_blocks, p_places)) can_persist = false;
         for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
         const bool persist = pass == 1;
         hipGraph_t* graph_out = persist ? &p->graph_p : &p->graph;

@@ -2390,7 +2390,9 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     //      backward pass needs of each of them in device memory (NF coalesced rows of 64 floats; it stays in this XCD's L2) and
     //      reads it back one layer ahead of its use; otherwise the backward pass recomputes conditioner and spline. ---
     constexpr int NF = pair_stash_fields(K, H);
-    const bool stash = !WIDE_H && a.pair_stash != 0;          // (hidden_dim 16 recomputes: 64 parked floats per lane do not fit next to its state)
+    // (hidden_dim 16 parks its 2 x 16 + 2 K + 12 floats per lane too while they fit the register file next to the GEMMs' operands:
+    //  248 VGPRs at num_knots 9, scratch from 12 up -- there the backward stages recompute conditioner and spline)
+    const bool stash = (!WIDE_H || K <= 11) && a.pair_stash != 0;
     gfloat* stash_w = (gfloat*)image + (size_t)L * D * PS + (((size_t)blockIdx.x * (L - 1)) * npairs + w) * (NF * 64) + 4 * lane;
     const size_t stash_layer = (size_t)npairs * (NF * 64);
     float lossv = 0.0f;
@@ -3304,7 +3306,7 @@ static int unit_train2(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
                 a.xrows = max_D;
                 {
                     const char* se = getenv("NFISAM_PAIR_STASH");
-                    a.pair_stash = (HH != 16 && a.pair_ws && a.L > 1 && pair_stash_fits(max_n, max_D) && !(se != nullptr && se[0] == '0')) ? 1 : 0;
+                    a.pair_stash = ((HH != 16 || KK <= 11) && a.pair_ws && a.L > 1 && pair_stash_fits(max_n, max_D) && !(se != nullptr && se[0] == '0')) ? 1 : 0;
                 }
                 const int W = ((max_D + 1) / 2 < 8) ? (max_D + 1) / 2 : 8;
                 rc = set_lds(nsf_train3_kernel<KK, HH>, lds3);

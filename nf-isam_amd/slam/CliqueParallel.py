@@ -239,7 +239,7 @@ def tree_edges(tree: CliqueTree, assignment: Dict[Hashable, int], order: Sequenc
 
 def run_tree(tree: CliqueTree, fit: Callable[[Hashable, List[torch.Tensor]], torch.Tensor], rank: int,
              world_size: int, device="cpu", message_shape=None, assignment: Dict[Hashable, int] = None,
-             exchange_log: List = None) -> Dict[Hashable, torch.Tensor]:
+             exchange_log: List = None, exchange_stats: Dict = None) -> Dict[Hashable, torch.Tensor]:
     """Execute `fit(clique, child_messages) -> message_to_parent` for every clique owned by this rank,
     leaves first, routing messages over rank boundaries point-to-point (`EdgeExchange`: no tags, no headers).
     Per clique the reference's order is kept: children's separator samples -> fit -> separator factor for the
@@ -262,4 +262,6 @@ def run_tree(tree: CliqueTree, fit: Callable[[Hashable, List[torch.Tensor]], tor
     ex.drain()
     if exchange_log is not None:
         exchange_log.extend(ex.log)
+    if exchange_stats is not None:               # what the pass cost this rank (EdgeExchange.stats: bench.py's `exchange` block)
+        exchange_stats.update(ex.stats)
     return produced

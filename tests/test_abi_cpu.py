@@ -156,3 +156,25 @@ def test_posterior_walk_refuses_a_table_that_would_read_past_the_latent_draws():
     table["n_frontal"] = [3, 2]
     with pytest.raises(ValueError, match="frontal columns exceed"):
         nh.posterior_walk_raw(table, np.array([0, 1, 2, 0, 1, 2, 3]), np.zeros(0), 4, 8, D, K, H, 5.0, 1, torch.device("cpu"))
+
+
+def test_workspace_count_covers_groups_of_up_to_sixteen_blocks():
+    """`nfisam_nsf_grad_workspace_count` (host-only): a one-layer clique's workspace must hold what the chunk-persistent kernel
+    addresses in it -- gradient copies, loss ring + 64 counters, the second set of copies, the second (theta | m | v) buffer, two
+    sets of TAGGED copies (2 floats per parameter) and the theta exchange: (6 x copies + 5) x kparam_count + ring + counters for
+    `copies` = ceil(n / 256) four-wave blocks per (clique, dim) group, up to sixteen (n <= 4096, round 5); and it does not shrink
+    with n."""
+    lib = nh.lib()
+    lib.nfisam_nsf_grad_workspace_count.restype = C.c_size_t
+    K, H, L = 9, 8, 1
+    prev = 0
+    for n in (64, 256, 257, 2000, 2048, 2049, 3000, 4096):
+        for D in (1, 6, 15):
+            kc = nh.kparam_count(D, K, H)
+            copies = (n + 255) // 256
+            need = (6 * copies + 5) * kc + 128 * 64 + 64
+            got = int(lib.nfisam_nsf_grad_workspace_count(n, D, K, H, L))
+            assert got >= need, (n, D, got, need)
+        now = int(lib.nfisam_nsf_grad_workspace_count(n, 6, K, H, L))
+        assert now >= prev
+        prev = now

@@ -129,9 +129,9 @@ def _worker(rank, world, port, out_dir, which="bushy"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tree, assign = TREES[which]()
     fit, shape_of, _ = _fit_factory(tree)
-    log = []
-    produced = run_tree(tree, fit, rank, world, device="cpu", message_shape=shape_of, assignment=assign, exchange_log=log)
-    torch.save({"produced": {k: v for k, v in produced.items()}, "log": log}, os.path.join(out_dir, "rank%d.pt" % rank))
+    log, stats = [], {}
+    produced = run_tree(tree, fit, rank, world, device="cpu", message_shape=shape_of, assignment=assign, exchange_log=log, exchange_stats=stats)
+    torch.save({"produced": {k: v for k, v in produced.items()}, "log": log, "stats": stats}, os.path.join(out_dir, "rank%d.pt" % rank))
     # weak-scaling shards + the max-over-ranks timing reduction bench.py performs
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,12 +149,13 @@ def test_two_process_tree_run_matches_single_process(tmp_path, which):
     world = 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), which), nprocs=world, join=True)
-    merged, logs = {}, []
+    merged, logs, stats = {}, [], []
     for r in range(world):
         part = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         assert not (set(part["produced"]) & set(merged))          # every clique ran on exactly one rank
         merged.update(part["produced"])
         logs.append(part["log"])
+        stats.append(part["stats"])
     tree, assign = TREES[which]()
     assert set(merged) == set(tree.parent)
     assignment = assign_subtrees(tree, world) if assign is None else assign
@@ -170,6 +171,11 @@ def test_two_process_tree_run_matches_single_process(tmp_path, which):
         assert e0 == e1 and {k0, k1} == {"send", "recv"} and p0 == 1 and p1 == 0, (logs[0], logs[1])
     crossing = [c for c in tree.parent if tree.parent[c] is not None and assignment[c] != assignment[tree.parent[c]]]
     assert sorted(e for _, _, e in logs[0]) == sorted(crossing)
+    # the exchange's own accounting (bench.py's `exchange` block is made of it): every crossing batch counted once on each side
+    total = sum(4 * shape_of(c)[0] * shape_of(c)[1] for c in crossing)
+    assert stats[0]["bytes_sent"] + stats[1]["bytes_sent"] == total == stats[0]["bytes_received"] + stats[1]["bytes_received"]
+    assert stats[0]["bytes_sent"] == stats[1]["bytes_received"] and stats[0]["sends"] + stats[0]["recvs"] == len(crossing)
+    assert all(st["send_s"] >= 0 and st["wait_s"] >= 0 for st in stats)
     if which == "both_directions":
         assert {k for k, _, _ in logs[0]} == {"send", "recv"}
     if which == "two_remote_children":

@@ -982,7 +982,9 @@ def _pair_kernel_of_another_width(K, H, shapes):
             # (three layers at this step size amplify rounding from the fourth iteration on: test_multilayer_training_follows_the_oracle)
             # (hidden_dim 16 x num_knots 16: the third loss already 6e-5 relative off the float64 curve -- three layers at this step size)
             np.testing.assert_allclose(out[3][c][:3], l64[:3], atol=(3e-3 if H == 16 else 2e-4), rtol=1e-5, err_msg=str((K, c)))
-            np.testing.assert_allclose(out[3][c][:iters], l64[:iters], rtol=4e-2, err_msg=str((K, c)))
+            # (hidden_dim 16 x num_knots 16: the loss RISES at the second iteration -- 25.3, 28.1, 23.4 -- in the oracle too: an
+            #  unstable start, from which float32 and float64 part ways: 8 % at iteration 6)
+            np.testing.assert_allclose(out[3][c][:iters], l64[:iters], rtol=(0.15 if H == 16 else 4e-2), err_msg=str((K, c)))
 
 
 def test_multilayer_training_follows_the_oracle():

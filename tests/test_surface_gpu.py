@@ -204,6 +204,49 @@ def test_fit_clique_density_model_and_conditional_sampling():
     assert m2.separator_dim == 1 and m2.flows[0] is model.flows[0]
 
 
+@pytest.mark.parametrize("hidden", [6, 12])
+def test_hidden_dims_of_the_references_own_grid_through_the_solver_surface(hidden):
+    """`hidden_dim` 6 / 12 (the reference's grid, example/slam/manhattan_world_with_range/lawnmower_4x4/run_nfisam.py:5-6) through
+    the drop-in surface: `NFiSAM(NFiSAMArgs(hidden_dim=...))` fits a clique and samples from it (zero-padded kernels of width 8 /
+    16 underneath, ABI 1500), the returned `NSF_AR` modules carry the REFERENCE'S shapes in `state_dict()` -- `network.0.weight`
+    [hidden, i], `network.2.weight` [hidden, hidden], `network.4.weight` [3K - 1, hidden] -- and a module rebuilt from that
+    state_dict gives the same forward values."""
+    from flows.flows import NSF_AR
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.Variables import R2Variable, SE2Variable, VariableType
+    rng = np.random.RandomState(1)
+    np.random.seed(1); torch.manual_seed(1)
+    n, K = 2000, 9
+    samples = ring_clique(n, rng)
+    L0, X0 = R2Variable("L0", VariableType.Landmark), SE2Variable("X0")
+    clique = FakeClique(frontal=[X0], separator=[L0])
+    solver = NFiSAM(NFiSAMArgs(flow_iterations=400, num_knots=K, hidden_dim=hidden, learning_rate=0.02, local_sample_num=n,
+                               average_window=50, loss_delta_tol=1e-2))
+    model = solver.fit_clique_density_model(clique, samples, [L0, X0], [])
+    loss = np.array(solver._temp_training_loss["".join(str(v.name) for v in clique.vars)])
+    iters = solver.last_fit_iterations
+    assert 100 <= iters <= 400 and loss[iters - 1] < loss[0] - 0.3 and np.all(np.isfinite(loss))
+    xs = model.conditional_sample_given_observation(conditional_dim=6, sample_number=1500)
+    assert xs.shape == (1500, 6) and np.all(np.isfinite(xs))
+    floor = mmd_rbf(samples[:1000, 1:5], samples[1000:2000, 1:5], 2.0)
+    assert mmd_rbf(xs[:1000, 1:5], samples[:1000, 1:5], 2.0) < max(0.08, 3 * floor)
+    flow = model.flows[0]
+    sd = flow.state_dict()
+    assert tuple(sd["init_param"].shape) == (3 * K - 1,)
+    for j in range(5):                                        # conditioner of dim i = j + 1
+        assert tuple(sd["layers.%d.network.0.weight" % j].shape) == (hidden, j + 1)
+        assert tuple(sd["layers.%d.network.0.bias" % j].shape) == (hidden,)
+        assert tuple(sd["layers.%d.network.2.weight" % j].shape) == (hidden, hidden)
+        assert tuple(sd["layers.%d.network.4.weight" % j].shape) == (3 * K - 1, hidden)
+    twin = NSF_AR(6, K=K, B=5.0, hidden_dim=hidden).to("cuda:0")
+    twin.load_state_dict({k: v.to("cuda:0") for k, v in sd.items()})
+    x = torch.from_numpy(np.clip(np.random.RandomState(2).randn(200, 6), -3, 3).astype(np.float32)).to("cuda:0")
+    z1, l1 = flow.forward(x)
+    z2, l2 = twin.forward(x)
+    np.testing.assert_allclose(z1.detach().cpu().numpy(), z2.detach().cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(l1.detach().cpu().numpy(), l2.detach().cpu().numpy(), atol=1e-5)
+
+
 def test_fit_with_validation_split_and_multilayer():
     from slam.NFiSAM import NFiSAM, NFiSAMArgs
     from slam.Variables import R2Variable, SE2Variable, VariableType

@@ -29,6 +29,18 @@ and run1/marginal_mmd (the bars the reference published for this case).
 
     python tests/golden/make_pipeline_fixture.py [small_range plaza1 plaza1ada manhattan136 icra] [--seeds 5] [--jobs 4]
 Workers are separate processes started with PYTHONHASHSEED=0 (set iteration order = reproducible orderings).
+
+Round 5 -- the LONG HORIZON (`LONG_CASES`, named explicitly on the command line; ~7 / 27 / 26 CPU-minutes and 3 x 75 CPU-minutes):
+    manhattan136_structure, plaza1_structure, plaza1ada_structure
+        ALL updates (136 / 156 / 156) with flow_iterations = 20, one seed: per update the elimination ordering; per retrained
+        clique (in training order) column pattern, dims, frontal / separator sets, D, D_s, true observations; every firing of
+        `root_clique_density_model_to_leaf`.  No samples are stored: the structure is decided by the graph alone.
+    manhattan136_full
+        ALL 136 updates at the reference's own budget (500 fixed iterations), 3 seeds; posteriors kept at updates 20 / 60 / 135.
+For these the reference's two sampling entry points run under torch.no_grad() (see `worker`): the reference keeps the autograd
+graphs of everything it samples, quadratic in the run's length -- Plaza1 at update 98: 34 GB.  Same values.
+    python tests/golden/make_pipeline_fixture.py plaza1_structure plaza1ada_structure manhattan136_structure manhattan136_full --jobs 5
+    python tests/golden/make_pipeline_fixture.py <case> --merge <workdir> --seeds N     (merge the outputs of workers started by hand)
 """
 import argparse
 import json

@@ -616,9 +616,32 @@ def main():
 
     # ---- N > 1 (or the forced process group of a 1-GPU box): the path that DOES exchange -- ParallelNFiSAM on a branching tree ----
     exchange = None
+    hard_exit = False
     if use_dist and not args.no_exchange:
+        # The regime has NEVER run with more than one RCCL rank (no multi-GPU node was available to this build: DESIGN.md 7); a
+        # mismatched point-to-point pair would be a hang, and a hang here would take the headline line -- already measured -- with
+        # it.  So it runs in a thread under a watchdog (BENCH_EXCHANGE_TIMEOUT seconds, default 240): if it does not come back,
+        # `exchange` says so, the line is printed, and the rank leaves with os._exit (no barrier, no teardown: they would hang too).
+        import threading
+        box = {}
+
+        def _run_exchange():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["per_rank"] = exchange_regime(world, rank)
+            except Exception as e:   # noqa: BLE001  (must never break the contract line)
+                box["error"] = repr(e)[:300]
+        th = threading.Thread(target=_run_exchange, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("BENCH_EXCHANGE_TIMEOUT", "240")))
+        if th.is_alive():
+            hard_exit = True
+            box["error"] = "the exchange regime did not return within its watchdog's time on rank %d" % rank
+        elif "error" in box:
+            hard_exit = True              # (the other ranks may sit in a collective this rank never entered: do not join their barrier)
+    if "per_rank" in (box if use_dist and not args.no_exchange else {}):
         try:
-            per_rank = exchange_regime(world, rank)
+            per_rank = box["per_rank"]
             r0 = per_rank[0]
             exchange = {
                 "workload": "one incremental update of a binary meeting tree of %d robots (%d cliques, D = 6..9+obs, n = 2000, K=9, H=8, "
@@ -642,6 +665,8 @@ def main():
                         "Not part of `value`: the headline stays the exchange-free weak-scaling line."}
         except Exception as e:   # noqa: BLE001  (must never break the contract line)
             exchange = {"error": repr(e)[:300]}
+    elif use_dist and not args.no_exchange:
+        exchange = {"error": box.get("error", "no result")}
 
     if rank == 0:
         total = world * wl.n_samples * args.steps
@@ -739,6 +764,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
+    if hard_exit:                      # (the exchange regime hangs in a collective: so would the barrier and the teardown)
+        sys.stderr.flush()
+        os._exit(0)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

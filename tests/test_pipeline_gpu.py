@@ -398,11 +398,13 @@ def test_structure_of_every_update_matches_the_reference(case):
 LATE_STEPS = (20, 60, 135)
 
 
-def compare_late(case="manhattan136_full", seeds=(0, 1, 2)):
+def compare_late(case="manhattan136_full", seeds=(0, 1, 2), rmse_seeds=(0, 1, 2, 3, 4, 5)):
     """-> (rows, failures): this repository's solver over ALL 136 updates with the reference's own arguments (500 fixed
-    iterations per fit, manhattan_plaza/run_nfisam.py) against the reference's complete runs (3 seeds, fixture
+    iterations per fit, manhattan_plaza/run_nfisam.py) against the reference's complete runs (fixture
     pipeline_manhattan136_full.npz: posteriors kept at updates 20 / 60 / 135), with the block-wise / marginal statistics and the
-    bound max(0.08, 1.5 x the reference's own spread) of `compare_case`."""
+    bound max(0.08, 1.5 x the reference's own spread) of `compare_case` for `seeds`, and -- over `rmse_seeds` (a run takes ~3 s) -- the
+    RMSE of the posterior-mean trajectory against the .fg ground truth: MEDIAN over our seeds <= 1.5 x the worst reference seed
+    + 0.25 m (single runs scatter widely on this graph, ours and the reference's alike: 59 ambiguous associations)."""
     from slam.NFiSAM import NFiSAM, NFiSAMArgs
     from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
     fx = np.load(os.path.join(GOLDEN, "pipeline_%s.npz" % case))
@@ -418,7 +420,8 @@ def compare_late(case="manhattan136_full", seeds=(0, 1, 2)):
         if not m <= bound:
             failures.append(row)
     path = os.path.join(DATA, "ManhattanPlaza136", "factor_graph.fg")
-    for seed in seeds:
+    rm_ours, rm_ref = {i: [] for i in LATE_STEPS}, {}
+    for seed in sorted(set(seeds) | set(rmse_seeds)):
         random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
         nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
         steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))
@@ -435,8 +438,29 @@ def compare_late(case="manhattan136_full", seeds=(0, 1, 2)):
             assert order == [str(v) for v in fx["seed0_step%d_ordering" % i]], (i, order[:6])
             if i in LATE_STEPS:
                 S = np.hstack([res[v] for v in solver.elimination_ordering])
-                _compare_step(check, seed, i, order, S, [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds],
-                              max_blocks=60)
+                ref_raw = [fx["seed%d_step%d_samples" % (s, i)].astype(np.float64) for s in ref_seeds]
+                if seed in seeds:
+                    _compare_step(check, seed, i, order, S, ref_raw, max_blocks=60)
+                off, cols = 0, {}
+                for v in solver.elimination_ordering:
+                    cols[str(v.name)] = (off, v)
+                    off += v.dim
+                poses = [n for n in order if n.startswith("X")]
+                tr = np.array([truth[cols[n][1]][:2] for n in poses])
+
+                def rmse(A):
+                    mean = np.array([A[:, cols[n][0]:cols[n][0] + 2].mean(0) for n in poses])
+                    return float(np.sqrt(((mean - tr) ** 2).sum(1).mean()))
+                if seed in rmse_seeds:
+                    rm_ours[i].append(rmse(S))
+                rm_ref[i] = [rmse(r) for r in ref_raw]
+    for i in LATE_STEPS:
+        row = dict(kind="trajectory-rmse", seed=-1, index=i, ours=round(float(np.median(rm_ours[i])), 3), ours_per_seed=[round(v, 3) for v in rm_ours[i]],
+                   reference_per_seed=[round(v, 3) for v in rm_ref[i]], bound=round(1.5 * max(rm_ref[i]) + 0.25, 3), floor=0.0,
+                   spread=round(max(rm_ref[i]) - min(rm_ref[i]), 3))
+        rows.append(row)
+        if not row["ours"] <= row["bound"]:
+            failures.append(row)
     return rows, failures
 
 
@@ -449,7 +473,10 @@ def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
     consecutive-pose blocks (an evenly spaced subset of 60 of the thousands of pairs), bound = max(0.08, 1.5 x the largest
     leave-one-out value among the reference's own seeds).  What this sees that the first six updates cannot: drift accumulated
     through 130 re-uses of the previous root's model, re-eliminated landmark cliques late in the run, the 100+-clique walk.
-    How sharp it is, is the REFERENCE'S doing: its own three seeds sit 0.50 / 0.83 / 1.03 apart (largest leave-one-out block MMDb
+    Next to them an ACCURACY row per checkpoint: RMSE of the posterior-mean trajectory against the .fg ground truth, median over
+    six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (measured, 12 seeds here / 3 of the reference:
+    medians 4.0 / 5.1 / 6.8 m against 5.4 / 5.3 / 5.9 m; single runs 1.9-12.1 m against 2.6-6.6 m -- scripts/exp/late_rmse.py).
+    How sharp the distributional rows are, is the REFERENCE'S doing: its own three seeds sit 0.50 / 0.83 / 1.03 apart (largest leave-one-out block MMDb
     at updates 20 / 60 / 135; sqrt 2 = unrelated), so the bound at update 135 is 1.27-1.55 -- a collapse or a displaced trajectory
     fails, a subtle late bias does not; measured here: 0.42-0.54 / 0.60-1.03 / 0.95-1.19, at the reference's own level
     (profiles/r05_pipeline_parity_vs_reference.json).  The sharp test of the late-run machinery is the structural one above."""
@@ -458,6 +485,7 @@ def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
         pytest.skip("fixture pipeline_manhattan136_full.npz not generated (tests/golden/make_pipeline_fixture.py manhattan136_full)")
     rows, failures = compare_late()
     print("manhattan136_full", [(r["kind"], r["seed"], r["index"], r["ours"], r["spread"], r["bound"]) for r in rows])
-    sat = [r for r in rows if abs(r["ours"] - r["floor"]) < 0.01 * r["floor"] and abs(r["spread"] - r["floor"]) < 0.01 * r["floor"]]
+    print([r for r in rows if r["kind"] == "trajectory-rmse"])
+    sat = [r for r in rows if r["kind"] != "trajectory-rmse" and abs(r["ours"] - r["floor"]) < 0.01 * r["floor"] and abs(r["spread"] - r["floor"]) < 0.01 * r["floor"]]
     assert not sat, ("a statistic sits at its saturation floor sqrt(2 / n)", sat)
     assert not failures, failures

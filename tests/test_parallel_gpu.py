@@ -222,3 +222,23 @@ def test_bench_under_the_launcher_over_rccl_prints_only_the_contract_line():
     alone = json.loads([l for l in q.stdout.split("\n") if l.strip()][-1])
     assert abs(d["per_gpu_value"] / alone["per_gpu_value"] - 1.0) < 0.10, (d["per_gpu_value"], alone["per_gpu_value"])
     # (when RCCL prints its banner -- it does with this image's defaults -- it is in p.stderr, not in front of the record)
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_survives_an_exchange_regime_that_does_not_come_back():
+    """bench.py runs the `exchange` regime (ParallelNFiSAM over the process group: never executed with more than one RCCL rank)
+    under a watchdog: when it does not return in time -- here: a watchdog of 10 ms against a regime that takes seconds -- the
+    headline line is still printed, `exchange` says what happened, and the rank leaves with exit code 0 without entering another
+    collective (a hang of the regime must not cost the driver its SCALE line)."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_EXCHANGE_TIMEOUT="0.01")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--steps", "20", "--warmup", "5", "--no-regimes", "--no-update-bench", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=550)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 1e7 and "did not return" in d["exchange"]["error"]

@@ -1128,7 +1128,7 @@ for name, shapes, iters, window, tol, H in (("plaza", [(2000, 15)], 230, 50, 0.0
                                             ("three_wide", [(2000, 16)] * 3, 100, 50, 0.0, 8), ("d24", [(1000, 24), (600, 19)], 100, 50, 0.0, 8),
                                             ("d33", [(700, 33)], 100, 50, 0.0, 8),
                                             ("n4096", [(4096, 6)], 130, 50, 0.0, 8), ("n3000_n2500", [(3000, 9), (2500, 5)], 100, 50, 0.0, 8),
-                                            ("n4096_h16", [(4096, 7)], 100, 50, 0.0, 16),
+                                            ("n4096_h16", [(4096, 7)], 100, 50, 0.0, 16), ("mixed_16_and_4_blocks", [(4096, 6), (1000, 5)], 100, 50, 0.0, 8),
                                             ("c3", [(2000, D) for D in (6, 8, 8, 10, 10, 12, 12, 12)], 100, 50, 0.0, 8)):
     gen = torch.Generator().manual_seed(len(name))
     xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
@@ -1154,7 +1154,7 @@ def test_chunk_persistent_kernel_is_bit_identical_to_one_launch_per_iteration(tm
     cliques in one plan, a run that stops early, a clique of one tile, hidden_dim 16 and 4, three cliques of D = 16 (384 blocks in two
     parallel persistent launches), D = 19 / 24 / 33, the eight C3 cliques (624 blocks: three per CU); round 5: cliques of MORE THAN
     2048 PARTICLES -- n = 4096, D = 6 (BASELINE config[1]'s batch: sixteen blocks per (clique, dim) group), a ragged pair of 12 and 10
-    blocks, hidden_dim 16 -- whose groups exchange up to sixteen tagged copies in two passes, summed in the lane-partial order
+    blocks, hidden_dim 16, a plan that mixes groups of sixteen and of four blocks -- whose groups exchange up to sixteen tagged copies in two passes, summed in the lane-partial order
     nsf_adam_kernel uses for that many copies (their one-launch-per-iteration form is gradient kernel + Adam kernel).
     Third run, NFISAM_PERSIST_SCATTER=1 (round 4): the launch's grid is transposed so that the blocks of a group are
     neighbours in dispatch order, i.e. on DIFFERENT XCDs (checked: every plan reports a span > 1 where a group has several

@@ -467,18 +467,19 @@ def compare_late(case="manhattan136_full", seeds=(0, 1, 2), rmse_seeds=(0, 1, 2,
 @pytest.mark.timeout(1800)
 def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
     """Long-horizon DISTRIBUTIONAL parity (VERDICT r4 missing #1, ii): the reference ran Manhattan-136 to its end -- 136 updates,
-    139 trained cliques, 131 re-used roots -- at its own budget (500 fixed iterations per fit, ~1.5 CPU-hours per seed, 3 seeds).
+    139 trained cliques, 131 re-used roots -- at its own budget (500 fixed iterations per fit, 65-75 CPU-minutes per seed, 6 seeds).
     This repository's solver does the same 136 updates (3 seeds) and is held to the reference's late posteriors at updates 20,
     60 and 135 (the last: 136 poses + 4 landmarks): every variable's standardised xy marginal, and MMDb on (pose, landmark) and
     consecutive-pose blocks (an evenly spaced subset of 60 of the thousands of pairs), bound = max(0.08, 1.5 x the largest
     leave-one-out value among the reference's own seeds).  What this sees that the first six updates cannot: drift accumulated
     through 130 re-uses of the previous root's model, re-eliminated landmark cliques late in the run, the 100+-clique walk.
     Next to them an ACCURACY row per checkpoint: RMSE of the posterior-mean trajectory against the .fg ground truth, median over
-    six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (measured, 12 seeds here / 3 of the reference:
-    medians 4.0 / 5.1 / 6.8 m against 5.4 / 5.3 / 5.9 m; single runs 1.9-12.1 m against 2.6-6.6 m -- scripts/exp/late_rmse.py).
-    How sharp the distributional rows are, is the REFERENCE'S doing: its own three seeds sit 0.50 / 0.83 / 1.03 apart (largest leave-one-out block MMDb
-    at updates 20 / 60 / 135; sqrt 2 = unrelated), so the bound at update 135 is 1.27-1.55 -- a collapse or a displaced trajectory
-    fails, a subtle late bias does not; measured here: 0.42-0.54 / 0.60-1.03 / 0.95-1.19, at the reference's own level
+    six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (measured, 12 seeds here / 6 of the reference:
+    medians 4.0 / 5.1 / 6.8 m against 4.6 / 4.2 / 4.2 m; single runs 1.9-12.1 m against 2.2-6.6 m; one-sided rank-sum p = 0.59 /
+    0.11 / 0.04: an open finding about the upper tail of our late runs, DESIGN.md 5 -- scripts/exp/late_rmse.py).
+    How sharp the distributional rows are, is the REFERENCE'S doing: its own six seeds sit 0.60 / 0.88 / 1.04 apart (largest leave-one-out block MMDb
+    at updates 20 / 60 / 135; sqrt 2 = unrelated), so the bound at update 135 is 1.30-1.56 -- a collapse or a displaced trajectory
+    fails, a subtle late bias does not; measured here: 0.42-0.53 / 0.64-1.05 / 0.95-1.23, at the reference's own level
     (profiles/r05_pipeline_parity_vs_reference.json).  The sharp test of the late-run machinery is the structural one above."""
     path = os.path.join(GOLDEN, "pipeline_manhattan136_full.npz")
     if not os.path.exists(path):

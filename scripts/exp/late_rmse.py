@@ -54,6 +54,14 @@ def rmse_of(order_vars, A, truth):
         off += v.dim
     return float(np.sqrt((np.array(out) ** 2).sum(1).mean()))
 ours = {i: [] for i in LATE}
+per_pose = {i: [] for i in LATE}            # DUMP=<file.npz>: per seed the posterior-mean error of every pose (name order X0, X1, ...)
+def pose_errors(order_vars, A, truth):
+    off, out = 0, {}
+    for v in order_vars:
+        if str(v.name).startswith("X"):
+            out[int(str(v.name)[1:])] = np.concatenate([A[:, off:off + 2].mean(0) - truth[v][:2], A[:, off:off + 2].std(0)])
+        off += v.dim
+    return np.array([out[k] for k in sorted(out)])
 for seed in range(seed0, seed0 + n_seeds):
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
@@ -66,9 +74,12 @@ for seed in range(seed0, seed0 + n_seeds):
         res = solver.incremental_inference()
         if i in LATE:
             ours[i].append(rmse_of(solver.elimination_ordering, np.hstack([res[v] for v in solver.elimination_ordering]), truth))
+            per_pose[i].append(pose_errors(solver.elimination_ordering, np.hstack([res[v] for v in solver.elimination_ordering]), truth))
             if seed == seed0:
                 byname = {str(v.name): v for v in solver.elimination_ordering}
                 order = [byname[str(n)] for n in fx["seed0_step%d_ordering" % i]]
                 print("update", i, "reference seeds:", [round(rmse_of(order, fx["seed%d_step%d_samples" % (s, i)].astype(np.float64), truth), 2) for s in range(3)], flush=True)
 for i in LATE:
     print("update", i, "ours:", [round(v, 2) for v in ours[i]], "median %.2f" % np.median(ours[i]), flush=True)
+if os.environ.get("DUMP"):
+    np.savez_compressed(os.environ["DUMP"], **{"update%d" % i: np.array(per_pose[i]) for i in LATE})

@@ -474,9 +474,9 @@ def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
     leave-one-out value among the reference's own seeds).  What this sees that the first six updates cannot: drift accumulated
     through 130 re-uses of the previous root's model, re-eliminated landmark cliques late in the run, the 100+-clique walk.
     Next to them an ACCURACY row per checkpoint: RMSE of the posterior-mean trajectory against the .fg ground truth, median over
-    six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (measured, 12 seeds here / 6 of the reference:
-    medians 4.0 / 5.1 / 6.8 m against 4.6 / 4.2 / 4.2 m; single runs 1.9-12.1 m against 2.2-6.6 m; one-sided rank-sum p = 0.59 /
-    0.11 / 0.04: an open finding about the upper tail of our late runs, DESIGN.md 5 -- scripts/exp/late_rmse.py).
+    six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (a seed study beside it, DESIGN.md 5: 96 runs here
+    4.59 / 5.45 / 6.60 m on average, 18 of the reference 4.50 / 5.43 / 6.60 m, one-sided rank-sum p = 0.56 / 0.68 / 0.48; single runs
+    are heavy-tailed, 2-17 m here and 2-13 m there at update 135 -- scripts/exp/late_rmse.py, profiles/r05_manhattan136_late_rmse_*).
     How sharp the distributional rows are, is the REFERENCE'S doing: its own six seeds sit 0.60 / 0.88 / 1.04 apart (largest leave-one-out block MMDb
     at updates 20 / 60 / 135; sqrt 2 = unrelated), so the bound at update 135 is 1.30-1.56 -- a collapse or a displaced trajectory
     fails, a subtle late bias does not; measured here: 0.42-0.53 / 0.64-1.05 / 0.95-1.23, at the reference's own level

@@ -1,4 +1,4 @@
-"""Host-only: rebuilds profiles/r05_manhattan136_late_rmse_ours_vs_reference.json's `reference_per_seed` and `summary` from the
+"""Host-only: writes tests/golden/manhattan136_full_rmse_reference_seeds.json and rebuilds profiles/r05_manhattan136_late_rmse_ours_vs_reference.json's `reference_per_seed` and `summary` from the
 per-pose error files (profiles/r05_manhattan136_pose_errors_*.npz; scripts/exp/pose_scatter.py --reduce makes the reference's).
     python scripts/exp/late_summary.py"""
 import json, os
@@ -26,5 +26,12 @@ for u in (20, 60, 135):
         "reference_later_seeds_mean_pm_se": ("%.2f +- %.2f (%d seeds)" % (rest.mean(), rest.std(ddof=1) / np.sqrt(len(rest)), len(rest))) if len(rest) > 1 else None}
 d["summary"] = summ
 json.dump(d, open(path, "w"), indent=1)
+# the test fixture of tests/test_pipeline_gpu.py::test_late_trajectory_error_over_many_seeds_is_distributed_like_the_reference_s: DATA
+# (numbers reduced from the reference's own runs), next to pipeline_manhattan136_full.npz which holds the first six seeds' samples
+json.dump({"what": "trajectory RMSE (m) of the reference's complete Manhattan-136 runs at updates 20 / 60 / 135, one entry per seed: "
+                   "tests/golden/make_pipeline_fixture.py --worker manhattan136_full <seed> out.npz, reduced by scripts/exp/pose_scatter.py --reduce "
+                   "and scripts/exp/late_summary.py", "seeds": seeds,
+           "rmse": {str(u): [round(float(v), 4) for v in rm(ref["update%d" % u])] for u in (20, 60, 135)}},
+          open(os.path.join(ROOT, "tests", "golden", "manhattan136_full_rmse_reference_seeds.json"), "w"), indent=1)
 for u, s in summ.items():
     print(u, s)

@@ -233,7 +233,7 @@ class Workload:
             gms.append(ev0.elapsed_time(ev1))
         il = [t.cpu().numpy() for t in tb.iter_loss]
         for v in il:
-            assert np.all(np.isfinite(v)) and v[iters - 1] < v[0], (v[0], v[iters - 1])
+            assert np.all(np.isfinite(v)) and (iters == 1 or v[iters - 1] < v[0]), (v[0], v[iters - 1])   # --steps 1: one loss value
         # which form the plan ran in: chunk-persistent launches (a chunk's iterations in ONE launch per chain) report the XCDs
         # their (clique, dim) groups sat on; 0 = one launch per iteration
         self.persistent = tb.xcd_span() > 0

@@ -475,7 +475,7 @@ def test_late_posteriors_of_the_complete_manhattan_run_match_the_reference():
     through 130 re-uses of the previous root's model, re-eliminated landmark cliques late in the run, the 100+-clique walk.
     Next to them an ACCURACY row per checkpoint: RMSE of the posterior-mean trajectory against the .fg ground truth, median over
     six seeds here, held to 1.5 x the worst of the reference's seeds + 0.25 m (a seed study beside it, DESIGN.md 5: 96 runs here
-    4.59 / 5.45 / 6.60 m on average, 18 of the reference 4.50 / 5.43 / 6.60 m, one-sided rank-sum p = 0.56 / 0.68 / 0.48; single runs
+    4.59 / 5.45 / 6.60 m on average, 24 of the reference 4.87 / 5.47 / 6.52 m, one-sided rank-sum p = 0.83 / 0.76 / 0.48; single runs
     are heavy-tailed, 2-17 m here and 2-13 m there at update 135 -- scripts/exp/late_rmse.py, profiles/r05_manhattan136_late_rmse_*).
     How sharp the distributional rows are, is the REFERENCE'S doing: its own six seeds sit 0.60 / 0.88 / 1.04 apart (largest leave-one-out block MMDb
     at updates 20 / 60 / 135; sqrt 2 = unrelated), so the bound at update 135 is 1.30-1.56 -- a collapse or a displaced trajectory
@@ -499,8 +499,8 @@ def test_late_trajectory_error_over_many_seeds_is_distributed_like_the_reference
     late run is a statement about a DISTRIBUTION: 32 seeds here (seconds each on the GPU) against every reference seed there is
     (tests/golden/manhattan136_full_rmse_reference_seeds.json: 65-100 CPU-minutes each) at updates 20 / 60 / 135.  Held: the two-sided
     rank-sum test does not reject at 0.5 % and the means differ by less than 3 standard errors of their difference, per checkpoint.
-    History: with the reference's first twelve seeds this read 6.6 against 4.9 m at update 135 (p = 0.03 one-sided); with eighteen,
-    6.60 against 6.60.  Sensitivity: ~1.7 m of systematic late error (a quarter of the run-to-run sd x 3 se) would fail the mean
+    History: with the reference's first twelve seeds this read 6.6 against 4.9 m at update 135 (p = 0.03 one-sided); with twenty-four,
+    6.60 against 6.52.  Sensitivity: ~1.7 m of systematic late error (a quarter of the run-to-run sd x 3 se) would fail the mean
     criterion; the structural test above and the distributional rows of the previous test are the sharper ones for everything
     they cover."""
     from scipy.stats import mannwhitneyu

@@ -49,6 +49,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 
@@ -96,6 +97,10 @@ LONG_CASES = {
     "plaza1ada_structure": ("plaza1ada", None, dict(flow_iterations=20), None, 1),
     "manhattan136_structure": ("manhattan136", None, dict(flow_iterations=20), None, 1),
     "manhattan136_full": ("manhattan136", None, dict(), (20, 60, 135), 3),
+    # round 6: Plaza1 -- the graph BASELINE's north_star names -- through update 30 (155 poses) at the reference's own budget
+    # (2000 iterations + window rule, plaza_dataset/run_nfisam.py:5-21), posteriors kept at updates 10 / 20 / 30.  The number of
+    # seeds (6) was fixed before any run was looked at.
+    "plaza1_late": ("plaza1", 31, dict(), (10, 20, 30), 6),
 }
 for _name, (_base, _upd, _over, _keep, _seeds) in LONG_CASES.items():
     _b = CASES[_base]
@@ -163,12 +168,28 @@ def write_stubs(root):
                 f.write(STUB + (GAUSSIAN if d == os.path.join("TransportMaps", "Distributions") else ""))
 
 
+def provenance(started):
+    """What a reference run depended on besides its seed (round 6: recorded per seed, VERDICT r5 weak #1b)."""
+    import platform
+    import torch
+    try:
+        commit = subprocess.check_output(["git", "-C", HERE, "rev-parse", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", HERE, "status", "--porcelain", "--", __file__], text=True).strip())
+    except Exception:
+        commit, dirty = "unknown", True
+    return dict(generator_commit=commit, generator_modified=dirty, PYTHONHASHSEED=os.environ.get("PYTHONHASHSEED", "unset"),
+                REF_THREADS=int(os.environ.get("REF_THREADS", "2")), torch_threads=torch.get_num_threads(),
+                host=platform.node(), cpus=os.cpu_count(), python=platform.python_version(), torch=torch.__version__,
+                numpy=np.__version__, started_unix=round(started), seconds=round(time.time() - started))
+
+
 def worker(case, seed, out_path):
     """One reference run (own process, PYTHONHASHSEED=0)."""
     import random
     ref_dir, graph_file, step, updates, kwargs, n_post, n_batch, _ = CASES[case]
     keep_steps = LONG_CASES[case][3] if case in LONG_CASES else "all"
     tmp = tempfile.mkdtemp(prefix="nfisam_ref_")
+    started = time.time()
     try:
         write_stubs(os.path.join(tmp, "stubs"))
         sys.path.insert(0, os.path.join(tmp, "stubs"))
@@ -260,6 +281,7 @@ def worker(case, seed, out_path):
             if n_batch:
                 out["fit%d_batch" % j] = f["batch"]
         out["timing"] = np.array([float(t) for t in open(os.path.join(run_dir, "step_timing")).read().split()])
+        out["provenance"] = np.array(json.dumps(provenance(started)))
         np.savez_compressed(out_path, **out)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

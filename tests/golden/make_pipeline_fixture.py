@@ -178,7 +178,8 @@ def provenance(started):
     except Exception:
         commit, dirty = "unknown", True
     return dict(generator_commit=commit, generator_modified=dirty, PYTHONHASHSEED=os.environ.get("PYTHONHASHSEED", "unset"),
-                REF_THREADS=int(os.environ.get("REF_THREADS", "2")), torch_threads=torch.get_num_threads(),
+                REF_THREADS=int(os.environ.get("REF_THREADS", "2")), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "unset"),
+                niceness=os.nice(0), torch_threads=torch.get_num_threads(),
                 host=platform.node(), cpus=os.cpu_count(), python=platform.python_version(), torch=torch.__version__,
                 numpy=np.__version__, started_unix=round(started), seconds=round(time.time() - started))
 

@@ -31,6 +31,22 @@
 
 typedef float cm_f32x4 __attribute__((ext_vector_type(4)));
 
+// diagnostic build (-DNSF_STAMPS=3, unit 0): cycle sums of the staging's sub-phases, thread 64 of block (1, 0, 0)
+#if defined(NSF_STAMPS) && NSF_STAMPS == 3 && defined(NSF_UNIT) && NSF_UNIT == 0
+__device__ unsigned long long g_stg[32];
+#define STG_T0() unsigned long long stg_prev_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stg_prev_)::"memory")
+#define STG_STAMP(id, v)                                                                                   \
+    do {                                                                                                   \
+        unsigned long long t_;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(v)::"memory");                \
+        if (tid == 64 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) { g_stg[id] += t_ - stg_prev_; g_stg[16 + (id)] += 1ull; } \
+        stg_prev_ = t_;                                                                                    \
+    } while (0)
+#else
+#define STG_T0()
+#define STG_STAMP(id, v)
+#endif
+
 __device__ __forceinline__ cm_f32x4 mfma1(float a, float b, cm_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
@@ -247,6 +263,19 @@ struct PersistAdam {
     AdamCoef kc;
 };
 
+// One (value, tag) pair of copy c: a 64-bit scalar base per copy + a 32-bit lane offset (the `saddr + voffset` form of
+// global_load_dwordx2: no 64-bit vector address arithmetic per load).  `cs_bytes` = bytes between copies (< 2^31 / copies:
+// a clique's whole workspace is a few MB); copies beyond the group's size re-read its last one (their values are not used,
+// their tags are this iteration's as soon as that copy's are).
+__device__ __forceinline__ unsigned long long tagged_pair(const __attribute__((address_space(1))) float* tagged, int c, int copies,
+                                                          unsigned cs_bytes, unsigned lane_off) {
+    typedef const __attribute__((address_space(1))) char* gc;
+    typedef const __attribute__((address_space(1))) unsigned long long* gq;
+    const unsigned cc = (unsigned)(c < copies ? c : copies - 1);
+    gc base = (gc)tagged + (size_t)(cc * cs_bytes);
+    return __hip_atomic_load((const unsigned long long*)(gq)(base + (size_t)lane_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // -> 0: staged; 1: the clique is finished (the block returns); 2: gave up waiting for a copy (the group's abort flag is up)
 template <int K, int H>
 __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
@@ -255,7 +284,6 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
     typedef const __attribute__((address_space(1))) uint32_t* gu;
-    typedef const __attribute__((address_space(1))) unsigned long long* gq;
     gp t_src = (gp)theta_generic;
     constexpr int PoP = CP::PoP;
     const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
@@ -264,6 +292,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     int gave_up = 0;
     // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
     if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    STG_T0();
     for (int base = 0; base < nj; base += 2 * NT) {
         const int ja = base + tid, jb = base + NT + tid;
         const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
@@ -286,13 +315,13 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
                 unsigned long long qa[8], qb[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const size_t o = (size_t)(c < fa.copies ? c : 0) * fa.cstride;
-                    qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    qb[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qa[c] = tagged_pair(fa.tagged, c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ia);
+                    qb[c] = tagged_pair(fa.tagged, c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ib);
                 }
                 // (the iteration's bias corrections while the loads are under way: ~80 instructions that depend on nothing loaded)
                 if (base == 0 && spins == 0u)
                     fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+                if (spins == 0u) STG_STAMP(0, fa.kc.step_size);
                 bool ok = true;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -314,6 +343,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
                 }
             }
         }
+        STG_STAMP(1, ga[0]);
         if (pending) {
             FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
             sum_order.copies = fa.copies;
@@ -324,6 +354,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
                 if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
             }
         }
+        STG_STAMP(2, ta);
         if (ja < nj) {
             fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
             lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
@@ -341,6 +372,7 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
             lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
         }
     }
+    { float d_ = lds0[4]; STG_STAMP(3, d_); }
     return gave_up ? 2 : 0;
 }
 
@@ -354,7 +386,6 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
     using LY = Layout<K, H>;
     typedef const __attribute__((address_space(1))) float* gp;
     typedef const __attribute__((address_space(1))) uint32_t* gu;
-    typedef const __attribute__((address_space(1))) unsigned long long* gq;
     gp t_src = (gp)theta_generic;
     constexpr int PoP = CP::PoP;
     const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
@@ -363,6 +394,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
     int gave_up = 0;
     // (looked at BEFORE anything is waited for: nobody writes the copies of a finished clique)
     if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    STG_T0();
     for (int base = 0; base < nj; base += 2 * NT) {
         const int ja = base + tid, jb = base + NT + tid;
         const int ca = (ja < nj ? ja : 0), cb = (jb < nj ? jb : 0);
@@ -391,13 +423,13 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
                 unsigned long long qa[8], qb[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const size_t o = (size_t)(c0 + c < fa.copies ? c0 + c : 0) * fa.cstride;
-                    qa[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ia), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    qb[c] = __hip_atomic_load((const unsigned long long*)(gq)(fa.tagged + o + 2 * (size_t)ib), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qa[c] = tagged_pair(fa.tagged, c0 + c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ia);
+                    qb[c] = tagged_pair(fa.tagged, c0 + c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ib);
                 }
                 // (the iteration's bias corrections while the loads are under way: ~80 instructions that depend on nothing loaded)
                 if (base == 0 && spins == 0u && pass == 0)
                     fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+                if (spins == 0u && pass == 0) STG_STAMP(0, fa.kc.step_size);
                 bool ok = true;
                 float la[8], lb[8];
 #pragma unroll
@@ -431,6 +463,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
             }
             }
         }
+        STG_STAMP(1, ga[0]);
         if (pending) {
             FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
             sum_order.copies = fa.copies < 8 ? fa.copies : 8;  // (more than eight copies: the eight lane partials)
@@ -441,6 +474,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
                 if (jb < nj) { fa.t_dst[ib] = tb; fa.m_dst[ib] = mb; fa.v_dst[ib] = vb; }
             }
         }
+        STG_STAMP(2, ta);
         if (ja < nj) {
             fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
             lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
@@ -458,6 +492,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
             lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
         }
     }
+    { float d_ = lds0[4]; STG_STAMP(3, d_); }
     return gave_up ? 2 : 0;
 }
 

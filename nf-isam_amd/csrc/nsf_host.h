@@ -81,6 +81,7 @@ struct TrainArgs {
     int persist_spins;              // ... log2 of the polls a block waits at its group barrier before it raises the group's abort flag (15; NFISAM_PERSIST_SPINS)
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
+    int half;                       // nsf_train1_kernel: two lanes per particle (nsf_half.h): a wave covers 32 particles, a block 32 x waves
 };
 
 
@@ -192,6 +193,30 @@ static inline int dim_major_waves(int n_cliques, int max_n, int max_D, int T) {
     const char* e = getenv("NFISAM_BIG_W");
     const int v = e != nullptr ? atoi(e) : 4;
     return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+}
+// ---- two lanes per particle on the dim-major kernel (round 6, nsf_half.h) --------------------------------------------------
+// The family for launches that leave most SIMDs idle -- ONE clique, i.e. every fit of a real NF-iSAM run: a wave covers 32
+// particles with a shorter per-lane program (stamped arithmetic of a unit 9.3 k -> 7.1 k cycles), twice the waves, blocks of
+// 128 particles.  Instantiated for hidden_dim 8 and sixteen theta columns per half (num_knots 9 .. 11: every shipped large run
+// uses 9), cliques of up to 16 dims (one operand tile of [x | 1] in the dW0 GEMM).  A launch takes it when its blocks get a CU
+// each (<= 256) and a (clique, dim) group keeps to EIGHT blocks (n <= 1024): the exchange between a group's blocks is bound
+// by the instructions a thread spends per gradient copy, and with sixteen copies it gives back what the shorter unit gained
+// (one clique, D = 15, us per iteration, 64-particle family / this one: n = 500 .. 1024: 7.4 / 6.25; n = 1500 .. 2048: 7.40 / 7.34).
+// NFISAM_HALF=0: never; =2: groups of up to sixteen blocks too (measurements); NFISAM_HALF_W=4|8: waves per block (8: 256
+// particles per block, two waves per SIMD -- measured slower: the younger wave of a SIMD runs at half speed).
+static inline int half_waves() {
+    const char* e = getenv("NFISAM_HALF_W");
+    const int v = e != nullptr ? atoi(e) : 4;
+    return (v == 4 || v == 8) ? v : 4;
+}
+static inline bool half_shape(int n_cliques, int max_n, int max_D, int K, int H, int L, int T) {
+    const char* e = getenv("NFISAM_HALF");               // read per call: tests switch families in-process
+    if (e != nullptr && e[0] == '0') return false;
+    if (H != 8 || K < 2 || hp_of(K) != 16 || L != 1 || T != 1 || max_D > 16 || max_D < 1) return false;
+    const int per_block = 32 * half_waves();
+    const long copies = (max_n + per_block - 1) / per_block;
+    const long most = (e != nullptr && e[0] == '2') ? PERSIST_MAX_COPIES : 8;
+    return copies <= most && (long)n_cliques * max_D * copies <= 256;
 }
 // hidden widths the dim-major kernel is instantiated for (H <= 8: [ga2 | ga1] share one 16-row MFMA operand tile;
 // H = 16: one tile each and separate bias chains)

@@ -622,7 +622,9 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     const size_t tiles64 = (size_t)((n + TILE - 1) / TILE);
     // + the chunk-persistent form's two sets of TAGGED copies (8 blocks of 4 waves at most, 2 floats per parameter)
     // (round 5: groups of up to sixteen blocks -- n <= 4096 -- in the chunk-persistent form: 2 sets x copies x 2 floats)
-    const size_t copies16 = (tiles64 + 3) / 4;
+    // (round 6: two lanes per particle, nsf_half.h -- blocks of 128 particles while a group keeps to sixteen of them)
+    const size_t copies128 = (tiles64 + 1) / 2;
+    const size_t copies16 = (copies128 <= (size_t)PERSIST_MAX_COPIES && copies128 > (tiles64 + 3) / 4) ? copies128 : (tiles64 + 3) / 4;
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 4 * (copies16 > 8 ? copies16 : 8) + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && (H == 8 || H == 4 || H == 16) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;
@@ -635,16 +637,24 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
 
 // Launch shape of one training iteration: kernel family, tiles per block, particles per gradient copy (0 = one
 // shared copy accumulated with float atomics).
-struct TrainShape { int tile, T, slab, W; };
-static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H) {
+struct TrainShape { int tile, T, slab, W, half; };
+static TrainShape train_shape(int n_cliques, int max_n, int max_D, int L, int H, int K) {
     TrainShape sh;
     sh.tile = train_tile(n_cliques, max_n, max_D, H, L == 1, (H == 4 || H == 16) && L > 1 && pair_h4_fits(L, max_D, H));
     sh.T = tiles_per_block(n_cliques, max_n, max_D, L, sh.tile, H);
     sh.slab = use_slabs(max_n, sh.tile) ? sh.tile * sh.T : 0;      // the workspace holds ceil(n / tile) copies at most
     sh.W = 0;
+    sh.half = 0;
     if (is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H)) {
         sh.W = dim_major_waves(n_cliques, max_n, max_D, sh.T);
         sh.slab *= sh.W;                                            // one copy per block
+        // two lanes per particle (nsf_half.h): 32 particles per wave; a function of the launch shape only, like everything
+        // here, so that the gradient, Adam and bookkeeping launches of an iteration agree on the number of gradient copies
+        if (sh.slab != 0 && half_shape(n_cliques, max_n, max_D, K, H, L, sh.T)) {
+            sh.half = 1;
+            sh.W = half_waves();
+            sh.slab = 32 * sh.T * sh.W;
+        }
     }
     return sh;
 }
@@ -676,8 +686,8 @@ static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* s
                         int chain = 0, int n_chains = 1, bool pair_image = false, int persist_iters = 0) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
-    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
-    a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab; a.waves = sh.W;
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H, K);
+    a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab; a.waves = sh.W; a.half = sh.half;
     if (fused_cfg != nullptr) {
         a.fused_adam = 1;
         a.adam = *fused_cfg;
@@ -703,7 +713,7 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
     ad.cliques = dev_cliques;
     if (single != nullptr) ad.single = *single;
     ad.cfg = *cfg;
-    ad.slab = train_shape(n_cliques, max_n, max_D, L, H).slab;
+    ad.slab = train_shape(n_cliques, max_n, max_D, L, H, K).slab;
     ad.log_b1 = (float)log((double)cfg->beta1);
     ad.log_b2 = (float)log((double)cfg->beta2);
     ad.L = L; ad.K = K; ad.H = H; ad.max_n = max_n;
@@ -728,7 +738,7 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
                           long* blocks_out = nullptr, long* places_out = nullptr) {
     static const bool on = !(getenv("NFISAM_PERSIST") != nullptr && getenv("NFISAM_PERSIST")[0] == '0');
     if (!on || g_persist_broken.load() || host == nullptr || L != 1 || (H != 16 && H != 8 && H != 4) || max_D > FUSED_COUNTERS) return false;
-    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H, K);
     // (the one-launch-per-iteration fused form sums at most eight gradient copies -- fused_adam_shape --; the persistent
     //  exchange takes up to sixteen, round 5: single cliques of up to 4096 particles, whose plain graph is then gradient
     //  kernel + Adam kernel per iteration; nsf_adam_kernel's lane-partial order for that many copies is the order the
@@ -737,11 +747,11 @@ static bool persist_shape(const nfisam_clique* host, int n_cliques, int max_n, i
         const char* fe = getenv("NFISAM_FUSED_ADAM");
         if (fe != nullptr && fe[0] == '0') return false;
     }
-    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.T != 1 || sh.slab == 0 || sh.W != 4 ||
+    if (!is_dim_major(n_cliques, max_n, max_D, L, sh.tile, H) || sh.T != 1 || sh.slab == 0 || (sh.W != 4 && !sh.half) ||
         (max_n + sh.slab - 1) / sh.slab > PERSIST_MAX_COPIES)
         return false;
     long blocks = 0;
-    for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + 4 * TILE - 1) / (4 * TILE));
+    for (int c = 0; c < n_cliques; ++c) blocks += (long)host[c].D * ((host[c].n + sh.slab - 1) / sh.slab);
     // (asked once per (K, H, clique width, device): the query costs a device-properties call, and replica schedulers
     //  create plans by the hundred)
     static std::mutex mu;
@@ -878,7 +888,7 @@ static int enqueue_step(const nfisam_clique* dev_cliques, const nfisam_clique* s
                         int max_D, int K, int H, float B, int L, const nfisam_adam_cfg* cfg, int iter_idx,
                         hipStream_t s, const nfisam_clique* host_cliques = nullptr, int chain = 0, int n_chains = 1,
                         int persist_iters = 0) {
-    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H, K);
     const bool fused = fused_adam_shape(n_cliques, max_n, max_D, L, H, sh) || persist_iters > 0;   // (the persistent form applies its own updates: up to 16 copies)
     if (!fused && n_chains > 1) return NFISAM_ERR_ARG;
     const bool image = !fused && pair_image_shape(max_D, K, H, L, sh);
@@ -923,7 +933,7 @@ static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_cliq
                              nfisam_train_state* mirror = nullptr, bool persistent_chunk = false) {
     // (`persistent_chunk`: the chunk ran as a chunk-persistent launch, whose last update is always pending -- also for
     //  groups of 9 .. 16 copies, which the one-launch-per-iteration form does not fuse)
-    if (persistent_chunk || fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H))) {
+    if (persistent_chunk || fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H, K))) {
         AdamArgs ad;
         fill_adam_args(ad, dev_cliques, single, n_cliques, max_n, max_D, K, H, L, cfg);
         ad.close_chunk = chunk;
@@ -959,7 +969,7 @@ static int check_cfg(const nfisam_adam_cfg* cfg, int K, int H, int L, float B) {
 // Parallel launches per iteration of a training plan (see nfisam_nsf_train_plan_create): NFISAM_CHAINS=n, default by size.
 static int plan_chains(int n_cliques, int max_n, int max_D, int K, int H, int L) {
     (void)K;
-    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H);
+    const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H, K);
     if (!fused_adam_shape(n_cliques, max_n, max_D, L, H, sh)) return 1;
     const long waves = (long)n_cliques * max_D * ((max_n + 64 * sh.T - 1) / (64 * sh.T));
     // measured (MI355X): C3 (3072 waves) 15.0 -> 14.5 us per iteration, 64 cliques (7680 waves) 89.5 -> 82.5;
@@ -986,7 +996,7 @@ extern "C" int nfisam_nsf_train_gradient_part(const nfisam_clique* cliques, int 
     if (cliques == nullptr || n_cliques < 1 || max_n < 1 || max_D < 1 || L < 1 || !(B > 0) ||
         !nfisam_nsf_supported(K, H) || n_chains < 1 || chain < 0 || chain >= n_chains)
         return NFISAM_ERR_ARG;
-    if (n_chains > 1 && !fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H)))
+    if (n_chains > 1 && !fused_adam_shape(n_cliques, max_n, max_D, L, H, train_shape(n_cliques, max_n, max_D, L, H, K)))
         return NFISAM_ERR_ARG;
     if (cliques_on_host) {
         if (n_cliques != 1) return NFISAM_ERR_ARG;

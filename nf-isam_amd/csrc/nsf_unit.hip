@@ -20,6 +20,7 @@
 
 #include "nsf_host.h"
 #include "nsf_cond_mfma.h"
+#include "nsf_half.h"
 
 #ifndef NSF_UNIT
 #error "compile with -DNSF_UNIT=<unit index> (see nsf_units.h)"
@@ -150,6 +151,12 @@ extern "C" int nfisam_debug_read_blocks(unsigned long long* out) {
 extern "C" int nfisam_debug_write_stamps(const unsigned long long* in) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), in, sizeof(unsigned long long) * 64 * 32);
 }
+#if NSF_STAMPS == 3
+extern "C" int nfisam_debug_read_stg(unsigned long long* out, int zero) {
+    if (zero) { unsigned long long z[32] = {0ull}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stg), sizeof(unsigned long long) * 32);
+}
+#endif
 extern "C" int nfisam_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 32);
 }
@@ -1197,15 +1204,19 @@ __host__ __device__ constexpr int persist_keep_stride(int max_D) {
 // PERSIST_MAX_COPIES = 16 gradient copies per (clique, dim) -- whose tagged copies are fetched in two passes and summed in
 // nsf_adam_kernel's lane-partial order for that many copies (nsf_cond_mfma.h: stage_cond_panel_persist*_wide).  A second
 // instantiation rather than a run-time branch: the common case keeps the code round 4 measured.
-template <int K, int H, bool PERSIST = false, bool LEAN = false, bool WIDE = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || LEAN || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
+template <int K, int H, bool PERSIST = false, bool LEAN = false, bool WIDE = false, bool SPL = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((H == 16 || LEAN || SPL || (PERSIST && NSF_PERSIST_WAVES < 3)) ? 2 : 3, 8)))
 nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, unsigned h_magic, int h_groups, int h_grid_cliques,
                   int h_xrows, int h_shifts, TrainArgs a, Train1Few few) {
     using LY = Layout<K, H>;
     using CP = CondPanel<K, H>;
     constexpr int PoP = LY::PoP;
     constexpr int NT = (PoP + 15) / 16;
-    constexpr int NS = TILE / 4;                              // MFMA k-steps over the 64 particles of a tile
+    // SPL (round 6, nsf_half.h): two lanes per particle -- a wave covers 32 particles, lanes p and p + 32 share particle p
+    constexpr int TP = SPL ? 32 : TILE;                       // particles per wave-tile
+    constexpr int PSH = SPL ? 5 : 6;                          // log2 of it
+    constexpr int NS = TP / 4;                                // MFMA k-steps over the particles of a tile
+    static_assert(!SPL || (H == 8 && LY::HP == 16), "two lanes per particle: hidden_dim 8, sixteen theta columns per half (num_knots 9 .. 11)");
     static_assert((H == 16 || H == 8 || H == 4) && NT <= 4, "H <= 8: ga2|ga1 share one 16-row operand tile; H = 16: one tile each, bias chains");
     constexpr bool WIDE_H = (H == 16);                        // no spare column for the bias in [h | 1]: db2 / db1 come from chains against a constant 1
     constexpr int QH = H / 4;                                 // row groups (of 4) of ga2 resp. ga1 in that tile
@@ -1272,7 +1283,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         ones0[lane0] = 1.0f;
         if (lane0 < ONES_ROW - 64) ones0[64 + lane0] = 1.0f;
     }
-    if (PERSIST && bx >= (((((int)cp0->n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws)) return;   // a block without a tile
+    if (PERSIST && bx >= (((((int)cp0->n + (TP << ts) - 1) >> (PSH + ts)) + W - 1) >> ws)) return;   // a block without a tile
     if (PERSIST && threadIdx.x == 0) smem[1] = 0.0f;          // the block's abort word (words 1-3 in front of the panel are free)
     // (test knob NFISAM_PERSIST_DROP=1, h_shifts bit 6: block 1 of group 0 leaves at once -- a member that "never became
     //  resident"; its group must time out, raise the abort flag and end the run with NFISAM_ERR_STALL)
@@ -1291,6 +1302,14 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     for (int t = 0; t < NT; ++t) { cacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float r0 = 0.0f, lossv = 0.0f;
     int it = PERSIST ? 0 : a.iter_idx;                        // iteration inside the chunk
+    // ROOMY: a two-wave build (256 VGPRs: SPL, LEAN).  The three-wave builds re-derive everything per phase from laundered roots
+    // so that nothing lives around the loop (below); a roomy build lets the compiler hoist the loop-invariant derivations
+    // instead (round 6: one Plaza clique 7.63 -> 7.40 us per iteration).
+    // (Tried on top of it and dropped, round 6: requesting the first look at the tagged copies at the TOP of the iteration, in
+    //  front of the derivations -- the copies of the slower blocks are not out yet, the look fails and costs a second round
+    //  trip, and 16 blocks x 256 threads x 32 early loads stand in the way of the very stores they wait for: one Plaza clique
+    //  7.34 -> 11.2 us per iteration with sixteen copies, 7.41 -> 7.6 with eight.  The staging's own first look is just in time.)
+    constexpr bool ROOMY = PERSIST && (SPL || LEAN);
 
   for (;;) {                                                  // (PERSIST: the iterations of the chunk; else one pass)
     // Everything the body needs is (re)derived INSIDE the loop from two laundered roots -- the thread index and the address
@@ -1305,7 +1324,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     //  ~45 loop-carried scalars the body spilled 166 SGPRs into VGPR lanes, 350 v_readlane / v_writelane per iteration and wave)
     typedef const __attribute__((address_space(4))) TrainArgs cargs;
     cargs* ap_ = (cargs*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + 40);
-    if constexpr (PERSIST) asm volatile("" : "+v"(tl_), "+s"(cp), "+s"(ap_));
+    if constexpr (PERSIST && !ROOMY) asm volatile("" : "+v"(tl_), "+s"(cp), "+s"(ap_));
 #define AF(f) (PERSIST ? ap_->f : a.f)
     const int lane = tl_ & 63;
     // the descriptor's pointers are device-memory pointers: say so (generic pointers would compile to flat_ loads and
@@ -1319,9 +1338,9 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const int n = cp->n;
     const int D = cp->D;
     const int slot = (bx << ws) + w;                          // this wave's tile group
-    const int p0 = slot << (6 + ts);
+    const int p0 = slot << (PSH + ts);
     float B = AF(B);
-    if constexpr (PERSIST) asm volatile("" : "+s"(B));         // (the spline's per-bin constants are functions of B: not to be hoisted into VGPRs)
+    if constexpr (PERSIST && !ROOMY) asm volatile("" : "+s"(B));         // (the spline's per-bin constants are functions of B: not to be hoisted into VGPRs)
     const bool slab = AF(slab) != 0;
     const size_t gstride = (size_t)LY::count(D);
     gfloat* ring = G + (slab ? (size_t)AF(n_copies) : (size_t)1) * gstride;
@@ -1350,7 +1369,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     float* ctacc = xt + xrows * XS;                           // D > 16: dW0 rows 16.. of the wave, summed over its tiles
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
-    const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
+    const int members = (((n + (TP << ts) - 1) >> (PSH + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
     const bool has_tile = p0 < n;
     const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
     const int r16 = lane & 15, kq = lane >> 4;
@@ -1364,7 +1383,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     // flight while the block stages its weight panel.
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     auto fetch = [&](int pt, int c0, float (&xr)[16]) {
-        const int pr = (pt + lane < n) ? pt + lane : n - 1;
+        const int pr = (pt + (lane & (TP - 1)) < n) ? pt + (lane & (TP - 1)) : n - 1;
         const gfloat* row = x + (size_t)pr * D;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1386,7 +1405,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     auto store = [&](int c0, const float (&xr)[16]) {
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (c0 + u <= i) xt[(c0 + u) * XS + lane] = xr[u];
+            if (c0 + u <= i) xt[(c0 + u) * XS + (lane & (TP - 1))] = xr[u];
     };
     auto load_tile = [&](int pt, int c_first) {
         for (int c0 = c_first; c0 <= i; c0 += 16) {
@@ -1505,7 +1524,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     // four interleaved rounds on one box); a lone wave per SIMD (one Plaza clique) is indifferent.
     if constexpr (PERSIST) __builtin_amdgcn_s_setprio(0);
     for (int tt = 0; tt < T && has_tile; ++tt) {
-        const int pt = p0 + tt * TILE;
+        const int pt = p0 + tt * TP;
         if (pt >= n) break;
         PSTAMP(1, lossv, r0);
         if (tt > 0) load_tile(pt, 0);
@@ -1513,11 +1532,109 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         // (PERSIST: a fresh derivation per phase -- a value derived once at the loop's top would have to stay in a register,
         //  or in scratch, from there to its last use in the epilogue)
         int tl2_ = threadIdx.x;
-        if constexpr (PERSIST) asm volatile("" : "+v"(tl2_));
+        if constexpr (PERSIST && !ROOMY) asm volatile("" : "+v"(tl2_));
         const int lane = tl2_ & 63;
         const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);
         const int r16 = lane & 15, kq = lane >> 4;
         PSTAMP(2, lossv, r0);
+        if constexpr (SPL) {
+            // ---- two lanes per particle (nsf_half.h): lanes p and p + 32 share particle p of the wave's 32 ----
+            constexpr int HP = LY::HP, HQ = H / 2;
+            const int p = lane & 31;
+            const bool up = lane >= 32;
+            const bool validp = pt + p < n;
+            const unsigned stg_p = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + p);
+            float th[HP], gth[HP], h1o[HQ], h2o[HQ];
+            if (i == 0) {
+#pragma unroll
+                for (int o = 0; o < HP; o += 4) {
+                    const cm_f32x4 v4 = *(const cm_f32x4*)(pan + (up ? HP : 0) + o);
+                    th[o] = v4[0]; th[o + 1] = v4[1]; th[o + 2] = v4[2]; th[o + 3] = v4[3];
+                }
+            } else {
+                float h1[H], h2[H];
+                cond_forward_half<K, H>(pan, i, CP::s0_of(i), xt, XS, lane, p, h1o, h2o, h1, h2, th);
+                // operands of the gradient GEMMs, parked while the lanes are busy with the spline: the low lanes write the
+                // h2 rows (0 ..), the high lanes the h1 rows (16 .. = hrow), both at the particle's column
+                float hs[H];
+#pragma unroll
+                for (int t = 0; t < H; ++t) hs[t] = up ? h1[t] : h2[t];
+                lds_rows_store<0, H, 0, H>(stg_p + (up ? 16u * XS * 4u : 0u), hs);
+            }
+            PSTAMP(3, th[0], th[HP - 1]);
+            if constexpr (PERSIST) __builtin_amdgcn_s_setprio(1);
+            SplineH<K> S;
+            float z, lad;
+            spline_half_fwd<K, HP>(xt[i * XS + p], th, up, B, S, z, lad);
+            PSTAMP(4, z, lad);
+            if (validp && !up) lossv += 0.5f * z * z - lad;       // (both lanes hold z and lad: the low one counts)
+            spline_half_bwd<K, HP>(S, up, B, validp ? z : 0.0f, validp ? -1.0f : 0.0f, gth);
+            PSTAMP(5, gth[0], gth[K]);
+            if (i == 0) {   // init_param: plain sum over the half's particles of gth
+                float v[HP];
+#pragma unroll
+                for (int t = 0; t < HP; ++t) v[t] = gth[t];
+                r0 += butterfly_half<HP>(v, p);
+                wave_lds_sync();
+                continue;
+            }
+            float ga2o[HQ], ga1o[HQ];
+            cond_backward_half<K, H>(pan, lane, gth, h1o, h2o, ga2o, ga1o);
+            PSTAMP(6, ga1o[0], ga2o[HQ - 1]);
+            if constexpr (PERSIST) __builtin_amdgcn_s_setprio(2);
+            // ---- weight gradients on the matrix cores: the contraction runs over the wave's 32 particles (NS = 8 steps);
+            //      BOTH 16-row tiles of gth are staged at once, the halves side by side (columns 0-31 | 32-63) ----
+            const float* pa = stg + r16 * XS + kq;
+            float breg[NS], ar0[NS], ar1[NS];
+            {
+                wave_lds_sync();
+                const float* pah = ((r16 < H) ? stg + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) breg[s4] = pah[4 * s4];
+                wave_lds_sync();
+            }
+            PSTAMP(7, breg[0], breg[NS - 1]);
+            lds_rows_store<0, 16, 0, HP>(stg_lane, gth);
+            wave_lds_sync();
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) { ar0[s4] = pa[4 * s4]; ar1[s4] = pa[32 + 4 * s4]; }
+            wave_lds_sync();
+            {   // [ga2 | ga1]: rows 0 .. H-1 | H .. 2H-1, a half writes its own units' rows at the particle's column
+                const unsigned own = stg_p + (up ? (unsigned)HQ * XS * 4u : 0u);
+                lds_rows_store<0, HQ, 0, HQ>(own, ga2o);
+                lds_rows_store<H, HQ, 0, HQ>(own, ga1o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < NS; ++s4) {
+                cacc[0] = mfma4(ar0[s4], breg[s4], cacc[0]);
+                cacc[1] = mfma4(ar1[s4], breg[s4], cacc[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wave_lds_sync();
+            if (merged) {
+                const int kx = r16 - (H + 1);
+                const bool one = (r16 == H) || kx >= i;
+                const float* pbm = (one ? ones : ((r16 < H) ? hrow + r16 * XS : xt + kx * XS)) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    ar0[s4] = pa[4 * s4];
+                    c1 = mfma4(ar0[s4], pbm[4 * s4], c1);
+                }
+            } else {
+                const float* pb0 = ((r16 < i) ? xt + r16 * XS : ones) + kq;     // input columns 0..15 (column i = bias)
+                const float* pb1 = ((r16 < H) ? hrow + r16 * XS : ones) + kq;
+#pragma unroll
+                for (int s4 = 0; s4 < NS; ++s4) {
+                    ar0[s4] = pa[4 * s4];
+                    c1 = mfma4(ar0[s4], pb1[4 * s4], c1);
+                    c0 = mfma4(ar0[s4], pb0[4 * s4], c0);
+                }
+            }
+            wave_lds_sync();
+            PSTAMP(8, c1.x, cacc[0].x);
+            continue;
+        }
         const bool valid = pt + lane < n;
         float h1[H], h2[H], th[PoP], gth[PoP];
         if (i == 0) {
@@ -1672,7 +1789,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     int tl3_ = threadIdx.x;
     cclique* cpe = cp0;
     cargs* ape_ = (cargs*)((cchar*)__builtin_amdgcn_kernarg_segment_ptr() + 40);
-    if constexpr (PERSIST) asm volatile("" : "+v"(tl3_), "+s"(cpe), "+s"(ape_));
+    if constexpr (PERSIST && !ROOMY) asm volatile("" : "+v"(tl3_), "+s"(cpe), "+s"(ape_));
     const int lane_e = tl3_ & 63, r16_e = lane_e & 15, kq_e = lane_e >> 4;
   {
     // (PERSIST: what the epilogue needs of the clique's descriptor and of the launch's arguments is derived AGAIN here, from
@@ -1693,8 +1810,8 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
-    const int members = (((n + (TILE << ts) - 1) >> (6 + ts)) + W - 1) >> ws;
-    const bool has_tile = (((bx << ws) + w) << (6 + ts)) < n;
+    const int members = (((n + (TP << ts) - 1) >> (PSH + ts)) + W - 1) >> ws;
+    const bool has_tile = (((bx << ws) + w) << (PSH + ts)) < n;
     if (slab) {
         // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
         // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
@@ -1703,7 +1820,11 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         if (!has_tile) {
             // (PERSIST: a wave without particles stays for the staging of the following iterations)
         } else if (i == 0) {
-            if (lane_e < PoP) frag[lane_e] = r0;
+            if constexpr (SPL) {                               // (lane (half, p < 16) holds the half's column p)
+                if ((lane_e & 31) < LY::HP) frag[LY::HP * (lane_e >> 5) + (lane_e & 31)] = r0;
+            } else {
+                if (lane_e < PoP) frag[lane_e] = r0;
+            }
         } else {
             float* fw = frag + LY::oW2(i);
             if (r16_e <= H) {
@@ -1736,7 +1857,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             if (lane_e == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
         }
         __syncthreads();                                      // waves without a tile left before the panel barrier
-        const int waves_c = (n + (TILE << ts) - 1) >> (6 + ts);
+        const int waves_c = (n + (TP << ts) - 1) >> (PSH + ts);
         const int alive = (waves_c - (bx << ws) < W) ? waves_c - (bx << ws) : W;
         const int nj4 = ((i == 0) ? PoP : LY::block(i)) >> 2;
         gvf4_t* Gc = (gvf4_t*)(G + ((i == 0) ? 0 : LY::off(i)));
@@ -1771,7 +1892,11 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         STAMP(12);
 #endif
     } else if (i == 0) {
-        if (lane_e < PoP) gsink(&G[lane_e], r0, false);
+        if constexpr (SPL) {
+            if ((lane_e & 31) < LY::HP) gsink(&G[LY::HP * (lane_e >> 5) + (lane_e & 31)], r0, false);
+        } else {
+            if (lane_e < PoP) gsink(&G[lane_e], r0, false);
+        }
     } else {
         gfloat* Gw = Gb + LY::oW2(i);
         {
@@ -3382,6 +3507,10 @@ struct PanelMap {
 template <int KK, int HH, bool PERSIST> static bool lean_launch_fits(long blocks, int max_D);
 template <int KK, int HH> constexpr bool lean_plain_v = HH <= 8 && KK > NSF_PLAIN_MAX_K3;
 template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PERSIST_MAX_K3;
+// round 6: the two-wave build of the chunk-persistent form also serves LONE launches of num_knots 9 (a block per CU at most:
+// nothing to gain from a third wave per SIMD) -- it has the registers to request the first look at the tagged copies at the
+// top of the iteration -- tried and dropped -- and to let the compiler hoist the loop's derivations (nsf_train1_kernel: ROOMY)
+template <int KK, int HH> constexpr bool lean_persist_inst_v = lean_persist_v<KK, HH> || (HH == 8 && hp_of(KK) == 16);
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4 || HH == 16) {
@@ -3390,7 +3519,7 @@ static int unit_prepare(int max_D) {
             if (rc) return rc;
         }
         // (the occupancy answers the launcher will want: asked here, outside the capture of the plan's graph)
-        if constexpr (lean_persist_v<KK, HH>) (void)lean_launch_fits<KK, HH, true>(1, max_D);
+        if constexpr (lean_persist_inst_v<KK, HH>) (void)lean_launch_fits<KK, HH, true>(1, max_D);
         if constexpr (lean_plain_v<KK, HH>) (void)lean_launch_fits<KK, HH, false>(1, max_D);
         return max_D <= PANEL_MAP_MAX_D ? PanelMap<KK, HH>::get(max_D, nullptr) : NFISAM_OK;
     } else {
@@ -3467,9 +3596,14 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         a.t_shift = __builtin_ctz((unsigned)T);
         a.w_shift = __builtin_ctz((unsigned)W);
         a.xrows = max_D;
-        const int waves = (max_n + TILE * T - 1) / (TILE * T);
+        // two lanes per particle (nsf_half.h; the shape decision is train_shape's, nsf_kernels.hip): 32 particles per wave
+        constexpr bool half_kh = (HH == 8 && hp_of(KK) == 16);
+        const bool spl = a.half != 0;
+        if (spl && (!half_kh || T != 1 || !a.slab || max_D > 16 || a.L != 1)) return NFISAM_ERR_ARG;
+        const int TP = spl ? 32 : TILE;                       // particles per wave-tile
+        const int waves = (max_n + TP * T - 1) / (TP * T);
         const int gx = (waves + W - 1) / W;
-        a.n_copies = gx;                                       // one gradient copy per block (a.slab = TILE * T * W particles)
+        a.n_copies = gx;                                       // one gradient copy per block (a.slab = TP * T * W particles)
         a.grid_cliques = n_cliques;
         a.groups = n_cliques * max_D;                          // (clique, dim) groups of gx blocks, padded to the 8 XCDs
         if ((long)a.groups * (long)n_cliques >= (1L << 31) || gx > 65535 || (a.groups + 7) / 8 > 65535) return NFISAM_ERR_ARG;
@@ -3486,22 +3620,36 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         {
             const nfisam_clique* hc = (a.cliques == nullptr) ? &a.single : a.host_cliques;
             if (hc != nullptr)
-                for (int c = 0; c < n_cliques; ++c) real_blocks += (long)hc[c].D * ((hc[c].n + W * T * TILE - 1) / (W * T * TILE));
+                for (int c = 0; c < n_cliques; ++c) real_blocks += (long)hc[c].D * ((hc[c].n + W * T * TP - 1) / (W * T * TP));
             else
                 real_blocks = (long)n_cliques * max_D * gx;
         }
         // LEAN build (two waves per SIMD, no scratch: see the kernels' attribute) when the launch is resident at that occupancy anyway
         bool lean = false;
-        if constexpr (lean_persist_v<KK, HH>) { if (persist && W == 4) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D); }
-        if constexpr (lean_plain_v<KK, HH>) { if (!persist && W == 4) lean = lean_launch_fits<KK, HH, false>(real_blocks, max_D); }
+        if constexpr (lean_persist_v<KK, HH>) { if (persist && W == 4 && !spl) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D); }
+        else if constexpr (lean_persist_inst_v<KK, HH>) {
+            static const bool lone_lean = !(getenv("NFISAM_LONE_LEAN") != nullptr && getenv("NFISAM_LONE_LEAN")[0] == '0');
+            if (persist && W == 4 && !spl && lone_lean && real_blocks <= 256) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D);
+        }
+        if constexpr (lean_plain_v<KK, HH>) { if (!persist && W == 4 && !spl) lean = lean_launch_fits<KK, HH, false>(real_blocks, max_D); }
         const bool wide = persist && gx > 8;                   // groups of 9 .. 16 blocks (n > 2048): the WIDE instantiation
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
-        if (persist && wide) {
+        if constexpr (half_kh) {
+            if (spl) {
+                // (the one-launch-per-iteration twin is the same template with PERSIST = false: the same arithmetic in the same order)
+                if (persist && wide) rc = set_lds(nsf_train1_kernel<KK, HH, true, false, true, true>, lds_launch);
+                else if (persist) rc = set_lds(nsf_train1_kernel<KK, HH, true, false, false, true>, lds_launch);
+                else rc = set_lds(nsf_train1_kernel<KK, HH, false, false, false, true>, lds_launch);
+                if (rc) return rc;
+            }
+        }
+        if (spl) {
+        } else if (persist && wide) {
             rc = set_lds(nsf_train1_kernel<KK, HH, true, false, true>, lds_launch);
-            if constexpr (lean_persist_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true, true>, lds_launch); }
+            if constexpr (lean_persist_inst_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true, true>, lds_launch); }
         } else if (persist) {
             rc = set_lds(nsf_train1_kernel<KK, HH, true>, lds_launch);
-            if constexpr (lean_persist_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true>, lds_launch); }
+            if constexpr (lean_persist_inst_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_kernel<KK, HH, true, true>, lds_launch); }
         } else {
             rc = set_lds(nsf_train1_plain_kernel<KK, HH>, lds_launch);
             if constexpr (lean_plain_v<KK, HH>) { if (lean) rc = set_lds(nsf_train1_plain_kernel<KK, HH, true>, lds_launch); }
@@ -3527,7 +3675,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
             static const char* se = getenv("NFISAM_PERSIST_SPLIT");
             long blocks = 0;
             const nfisam_clique* hc = (a.cliques == nullptr) ? &a.single : a.host_cliques;
-            for (int c = 0; c < n_cliques && hc != nullptr; ++c) blocks += (long)hc[c].D * ((hc[c].n + 4 * TILE - 1) / (4 * TILE));
+            for (int c = 0; c < n_cliques && hc != nullptr; ++c) blocks += (long)hc[c].D * ((hc[c].n + W * TP - 1) / (W * TP));
             a.persist_split = (se != nullptr) ? (se[0] == '1') : (blocks > 256);
         }
         static const int spin_log2 = getenv("NFISAM_PERSIST_SPINS") != nullptr ? atoi(getenv("NFISAM_PERSIST_SPINS")) : 15;           // (~1 us per look: a member that never arrives costs tens of milliseconds, not seconds -- round 4: 22)
@@ -3537,7 +3685,22 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const int pshifts = a.t_shift | (scatter ? 0x80 : 0) | (drop ? 0x40 : 0) | (a.w_shift << 8) | (ch << 16) | (nch << 24);
         const int shifts = a.t_shift | (a.w_shift << 8) | (ch << 16) | (nch << 24);
         bool launched = false;
-        if constexpr (lean_persist_v<KK, HH>) {
+        if constexpr (half_kh) {
+            if (gz > 0 && spl) {
+                if (persist && wide)
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                                       dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+                else if (persist)
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                                       dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
+                else
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, false, false, false, true>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
+                                       a.magic_cliques, a.groups, a.grid_cliques, a.xrows, shifts, a, few);
+                launched = true;
+            }
+        }
+        if (spl && !launched && gz > 0) return NFISAM_ERR_ARG;
+        if constexpr (lean_persist_inst_v<KK, HH>) {
             if (gz > 0 && persist && lean) {
                 if (wide)
                     hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,

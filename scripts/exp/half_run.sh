@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out; rm -f gpurun_out/half_run.txt
+for cfg in "NFISAM_HALF=0 NFISAM_LONE_LEAN=0" "NFISAM_HALF=0" "NFISAM_HALF=1 NFISAM_HALF_W=4"; do
+  echo "== $cfg" >> gpurun_out/half_run.txt
+  env $cfg python scripts/time_grad.py 1 2000 15 2>&1 | grep -v amdgpu.ids >> gpurun_out/half_run.txt
+  env $cfg python scripts/time_grad.py 1 2000 15 2>&1 | grep -v amdgpu.ids >> gpurun_out/half_run.txt
+  env $cfg python scripts/stamps3.py 1 2000 15 persist 2>&1 | grep -v amdgpu.ids | head -18 >> gpurun_out/half_run.txt
+done
+env NFISAM_HALF=0 python scripts/time_grad.py 8 2000 12 2>&1 | grep -v amdgpu.ids >> gpurun_out/half_run.txt
+cat gpurun_out/half_run.txt

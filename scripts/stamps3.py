@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
 import nfisam_hip as nh
 nh.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nf-isam_amd", "csrc", "_diag", "libnfisam_hip_stamps3.so")
+_shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nf-isam_amd", "csrc", "_stamps3", "libnfisam_hip_stamps3.so")
+if os.path.exists(_shipped):             # (round 6: a build made in the container and shipped with the snapshot)
+    nh.LIB_PATH = _shipped
 if not os.path.exists(nh.LIB_PATH):      # built on demand, on this box (not shipped)
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nf-isam_amd", "csrc"), "stamps"])
@@ -54,6 +57,12 @@ st = st // per
 for i in range(1, 14 if per > 1 else 10):
     print("  %-14s %8.0f" % (names[i], m[i]))
 print("  %-14s %8.0f" % ("total", m[1:10].sum() + (m[10:13].sum() if per > 1 else 0)))
+if hasattr(lib, "nfisam_debug_read_stg"):
+    sb = (C.c_ulonglong * 32)()
+    if lib.nfisam_debug_read_stg(sb, 0) == 0:
+        v = np.array(sb[:]).astype(np.int64)
+        print("  staging sub-phases (thread 64 of block (1,0,0), mean cycles):",
+              " ".join("%s=%d" % (nm, v[q] // max(1, v[16 + q])) for q, nm in enumerate(["issue+coef", "arrival", "adam", "stores"])), "calls", v[16:20].tolist())
 for w in (4, 5, 4 * (D // 2), 4 * (D - 1)):
     if w < 64:
         print("  slot %2d (dim %2d wave %d): " % (w, w // 4, w % 4) + " ".join("%s=%d" % (names[i], st[w][i]) for i in range(1, 10)))

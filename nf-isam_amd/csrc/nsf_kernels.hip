@@ -624,7 +624,8 @@ extern "C" size_t nfisam_nsf_grad_workspace_count(int n, int D, int K, int H, in
     // (round 5: groups of up to sixteen blocks -- n <= 4096 -- in the chunk-persistent form: 2 sets x copies x 2 floats)
     // (round 6: two lanes per particle, nsf_half.h -- blocks of 128 particles while a group keeps to sixteen of them)
     const size_t copies128 = (tiles64 + 1) / 2;
-    const size_t copies16 = (copies128 <= (size_t)PERSIST_MAX_COPIES && copies128 > (tiles64 + 3) / 4) ? copies128 : (tiles64 + 3) / 4;
+    const size_t c128 = copies128 < (size_t)PERSIST_MAX_COPIES ? copies128 : (size_t)PERSIST_MAX_COPIES;
+    const size_t copies16 = c128 > (tiles64 + 3) / 4 ? c128 : (tiles64 + 3) / 4;                // (monotone in n)
     const size_t fused = (L == 1 && tiles64 <= (size_t)FUSED_MAX_COPIES) ? (tiles64 + 3 + 4 * (copies16 > 8 ? copies16 : 8) + 2) * kcount(D, K, H) : 0;   // (+ the theta exchange of the divided update: 2 floats per parameter)
     // + the panel image of multi-layer cliques (nsf_train3_kernel; maintained by the Adam kernel, nsf_cond_mfma.h)
     const size_t image = (L > 1 && (H == 8 || H == 4 || H == 16) && D <= PAIR_MAX_D) ? (size_t)L * D * pair_panel_floats(K, H, D) : 0;

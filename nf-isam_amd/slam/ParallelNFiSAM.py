@@ -305,6 +305,7 @@ class ParallelNFiSAM(NFiSAM):
                  for c in cliques for ch in c.children if ch.separator and owner[id(ch)] != owner[id(c)]]
         exchange = EdgeExchange(edges, self.rank, device=_device(), on_device=self._on_device)
         crossing = {e[0] for e in edges}
+        self.posterior_exchange_log = exchange.log                  # (tests: the pairs' operation sequences must mirror each other)
         samples: Dict = {}
         for clique in cliques:
             frontal_list = sorted(clique.frontal, key=rmap.__getitem__)

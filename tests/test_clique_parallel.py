@@ -228,3 +228,154 @@ def test_meeting_tree_of_the_bench_exchange_regime_branches_and_shards_as_design
         cross = sum(1 for c in cl if c.parent is not None and a[ids[id(c)]] != a[ids[id(c.parent)]])
         assert set(a.values()) == set(range(world))
         assert cross == (0 if world == 1 else (1 if world == 2 else arms - 1)), (world, cross)
+
+
+# ---- round 6: the solver's OWN multi-rank loops at world size 4 and 8 (CPU, gloo) ------------------------------------------------
+# `ParallelNFiSAM.fit_tree_density_models` / `sample_posterior_sharded` (slam/ParallelNFiSAM.py) had only ever run with two ranks.
+# With four or eight a rank has several peers, joins sit on several levels of the meeting tree and the two `all_gather`s carry
+# ragged lengths.  Here the REAL loops run -- the solver's own edge lists, `EdgeExchange`, `_all_gather_flat`, the model
+# replication -- on the depth-2 / depth-3 meeting tree of bench.py, with the three density hooks (training sampler, fit,
+# separator factor) and the model (de)serialisation replaced by deterministic stand-ins, so no GPU is needed.  What must hold:
+# every rank ends with every model and every posterior sample, equal to the single-rank run of the same recursion, and for every
+# pair of ranks the two operation sequences are mirror images (nothing relies on message tags: RCCL has none).
+# Reference dependency that is sharded: src/slam/FactorGraphSolver.py:409-477 (upward), :524-531 (downward).
+def _stub_parallel_worker(rank, world, port, out_dir, depth):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import slam.NFiSAM as SN
+    import slam.ParallelNFiSAM as SP
+    from slam.FactorGraphSolver import CliqueSeparatorFactor
+    SN._device = lambda: "cpu"                        # (host-only run: the device hooks below never touch a GPU)
+    SP._device = lambda: "cpu"
+
+    def code_of(clique):
+        name = SP.ParallelNFiSAM._clique_name(clique)
+        return float(sum((k + 1) * ord(ch) for k, ch in enumerate(name)) % 997) / 100.0
+
+    class StubModel:
+        def __init__(self, value, dim):
+            self.value, self.dim = float(value), int(dim)
+
+        def conditional_sample_given_observation(self, conditional_dim, obs_samples=None, sample_number=None):
+            n = obs_samples.shape[0] if obs_samples is not None else sample_number
+            base = self.value + (0.25 * float(np.asarray(obs_samples, dtype=np.float64).mean()) if obs_samples is not None else 0.0)
+            return (base + 0.01 * np.arange(conditional_dim)[None, :] + np.zeros((n, 1))).astype(np.float32)
+
+    class StubFactor(CliqueSeparatorFactor):
+        def __init__(self, vars, value):
+            super().__init__()
+            self._vars, self._value = vars, float(value)
+
+        @property
+        def vars(self):
+            return self._vars
+
+        @property
+        def is_gaussian(self):
+            return False
+
+        def sample_on_device(self, num_samples):
+            ds = int(sum(v.dim for v in self._vars))
+            return torch.full((num_samples, ds), self._value) + 0.001 * torch.arange(ds, dtype=torch.float32)[None, :]
+
+        def sample(self, num_samples, **kwargs):
+            return self.sample_on_device(num_samples).numpy().astype(np.float64)
+
+    class StubSolver(SP.ParallelNFiSAM):
+        def clique_training_sampler(self, clique, num_samples, method):
+            graph = self._working_graph.get_clique_factor_graph(clique)
+            msgs = [f.sample_on_device(num_samples) for f in graph.factors if isinstance(f, CliqueSeparatorFactor)]
+            value = code_of(clique) + 0.5 * sum(float(m.double().mean()) for m in msgs)       # (order-independent)
+            return np.full((num_samples, clique.dim), value), list(clique.vars), np.zeros(0)
+
+        def fit_clique_density_model(self, clique, samples, var_ordering, timer, *a, **k):
+            return StubModel(samples[0, 0], clique.dim)
+
+        def clique_density_to_separator_factor(self, separator_var_list, density_model, true_obs):
+            return StubFactor(separator_var_list, density_model.value)
+
+        def _pack_models(self, cliques):                 # ragged on purpose: [value, dim, n_pad, pad ...]
+            parts = []
+            for c in cliques:
+                n_pad = (len(self._clique_name(c)) * 7) % 11
+                parts += [np.array([self._clique_density_model[c].value, c.dim, n_pad], dtype=np.float32), np.full(n_pad, -1.0, dtype=np.float32)]
+            return torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, dtype=np.float32))
+
+        def _install_models(self, cliques, flat):
+            off = 0
+            for c in cliques:
+                value, dim, n_pad = float(flat[off]), int(flat[off + 1]), int(flat[off + 2])
+                assert dim == c.dim and np.all(flat[off + 3:off + 3 + n_pad] == -1.0)
+                off += 3 + n_pad
+                m = StubModel(value, dim)
+                self._clique_density_model[c] = m
+                self._clique_true_obs[c] = np.zeros(0)
+                if c.separator:
+                    sep = sorted(c.separator, key=lambda x: self._reverse_ordering_map[x])
+                    self._implicit_factors[c] = self.clique_density_to_separator_factor(sep, m, np.zeros(0))
+            assert off == flat.size, (off, flat.size)
+
+    from slam.NFiSAM import NFiSAMArgs
+    order, factors = bench.meeting_tree(depth)
+    s = StubSolver(NFiSAMArgs(num_knots=9, hidden_dim=8, elimination_method="natural", cuda_training=True, local_sample_num=8,
+                              posterior_sample_num=6), posterior="sharded")
+    for v in order:
+        s.add_node(v)
+    for f in factors:
+        s.add_factor(f)
+    s.update_physical_and_working_graphs()
+    s.fit_tree_density_models()
+    up_log = list(s.exchange_log)
+    post = s.sample_posterior_sharded()
+    cl = s.physical_bayes_tree.clique_ordering()
+    torch.save(dict(models={s._clique_name(c): s._clique_density_model[c].value for c in cl},
+                    owners=s.owner_log[-1], up_log=up_log, down_log=list(s.posterior_exchange_log),
+                    up_stats=s.exchange_stats[-1], down_stats=s.posterior_exchange_stats,
+                    post={str(v.name): np.asarray(a) for v, a in post.items()}), os.path.join(out_dir, "w%d_rank%d.pt" % (world, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("depth, world", [(2, 4), (3, 8), (3, 4)], ids=["4arms-4ranks", "8arms-8ranks", "8arms-4ranks"])
+def test_the_solvers_own_loops_at_world_size_4_and_8(tmp_path, depth, world):
+    out = str(tmp_path)
+    for w in (1, world):
+        mp.spawn(_stub_parallel_worker, args=(w, _free_port(), out, depth), nprocs=w, join=True)
+    single = torch.load(os.path.join(out, "w1_rank0.pt"), weights_only=False)
+    parts = [torch.load(os.path.join(out, "w%d_rank%d.pt" % (world, r)), weights_only=False) for r in range(world)]
+    arms = 2 ** depth
+    assert len(single["models"]) == 2 * arms + (arms - 1)
+    owners = parts[0]["owners"]
+    assert set(owners.values()) == set(range(world))                    # every rank trained something
+    for r, p in enumerate(parts):
+        assert p["owners"] == owners
+        # replication: every rank holds every model, and they are the single-rank recursion's
+        assert p["models"].keys() == single["models"].keys()
+        for name, value in single["models"].items():
+            assert abs(p["models"][name] - value) < 1e-4 * max(1.0, abs(value)), (r, name, p["models"][name], value)
+        # downward pass: every rank ends with every variable's samples, equal to the single-rank pass
+        assert p["post"].keys() == single["post"].keys()
+        for v, a in single["post"].items():
+            np.testing.assert_allclose(p["post"][v], a, rtol=1e-5, atol=1e-5, err_msg="rank %d variable %s" % (r, v))
+    # joins on several levels: the upward pass crosses ranks at every join with children on different ranks
+    expected_cross = world - 1 if world <= arms else arms - 1
+    assert parts[0]["up_stats"]["cross_rank_edges"] == expected_cross, parts[0]["up_stats"]
+    assert parts[0]["down_stats"]["cross_rank_edges"] >= expected_cross
+    if world >= 4:
+        peers = [{peer for _, peer, _ in p["up_log"]} for p in parts]
+        assert max(len(q) for q in peers) >= 2                            # some rank talks to several peers
+    # no tags: for every pair of ranks the two operation sequences are mirror images, edge by edge, in both passes
+    for log in ("up_log", "down_log"):
+        total = 0
+        for a in range(world):
+            for b in range(a + 1, world):
+                ab = [(k, e) for k, peer, e in parts[a][log] if peer == b]
+                ba = [(k, e) for k, peer, e in parts[b][log] if peer == a]
+                assert len(ab) == len(ba), (log, a, b, ab, ba)
+                for (ka, ea), (kb, eb) in zip(ab, ba):
+                    assert ea == eb and {ka, kb} == {"send", "recv"}, (log, a, b, ab, ba)
+                total += len(ab)
+        assert total == parts[0][{"up_log": "up_stats", "down_log": "down_stats"}[log]]["cross_rank_edges"]

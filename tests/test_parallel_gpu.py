@@ -242,3 +242,87 @@ def test_bench_line_survives_an_exchange_regime_that_does_not_come_back():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 1e7 and "did not return" in d["exchange"]["error"]
+
+
+# ---- round 6: FOUR ranks (the one GPU shared over gloo), the real fit, the depth-2 meeting tree of bench.py -------------------------
+WORKER4 = r'''
+import json, os, random, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "nf-isam_amd")); sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+import bench
+from slam.NFiSAM import NFiSAM, NFiSAMArgs
+
+mode, out = sys.argv[1], sys.argv[2]
+rank = int(os.environ.get("RANK", "0"))
+if mode != "single":                      # (every rank is spawned before anything touches the GPU: the parent never initialises it)
+    dist.init_process_group("gloo", rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+random.seed(5); np.random.seed(5 + rank); torch.manual_seed(5 + rank)
+order, factors = bench.meeting_tree(2)
+args = NFiSAMArgs(num_knots=9, flow_iterations=600, local_sample_num=2000, learning_rate=.02, hidden_dim=8,
+                  cuda_training=True, elimination_method="natural", training_set_frac=1.0, loss_delta_tol=.01,
+                  posterior_sample_num=800)
+if mode == "single":
+    solver = NFiSAM(args)
+else:
+    from slam.ParallelNFiSAM import ParallelNFiSAM
+    solver = ParallelNFiSAM(args, posterior=mode)
+for v in order:
+    solver.add_node(v)
+for f in factors:
+    solver.add_factor(f)
+solver.update_physical_and_working_graphs()
+res = solver.incremental_inference()
+tree = solver.physical_bayes_tree
+info = dict(n_cliques=len(tree.clique_ordering()), max_children=max(len(c.children) for c in tree.clique_ordering()),
+            owners=solver.owner_log[-1] if hasattr(solver, "owner_log") else None,
+            up=solver.exchange_stats[-1] if hasattr(solver, "exchange_stats") else None,
+            down=getattr(solver, "posterior_exchange_stats", None),
+            trained_here=sorted(solver._temp_training_loss.keys()))
+np.savez(out, info=json.dumps(info), **{str(v.name): res[v] for v in order})
+if mode != "single":
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(1200)
+def test_four_rank_solver_matches_single_process(tmp_path):
+    """`ParallelNFiSAM` at world size FOUR with the real clique fit (VERDICT r5 next #2): four robots meet pairwise, the pairs'
+    survivors meet again -- 11 cliques, three joins on two levels, every rank trains one arm, three child -> parent separator
+    batches cross ranks upward and at least three parent -> child batches downward (`posterior="sharded"`), a rank talks to
+    more than one peer and the replication all_gathers carry ragged lengths.  The box has one GPU: the four ranks share it
+    over gloo (what stays unexecuted is the RCCL transport itself).  Compared with the single-process `NFiSAM` run by MMD."""
+    def run(mode, world):
+        script = tmp_path / "worker4.py"
+        script.write_text(WORKER4 % dict(root=ROOT))
+        port = _free_port()
+        procs, outs = [], []
+        for r in range(world):
+            out = str(tmp_path / ("%s_rank%d.npz" % (mode, r)))
+            outs.append(out)
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = [p.communicate(timeout=1000)[0].decode() for p in procs]
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-3000:]
+        return [dict(np.load(o)) for o in outs]
+    single = run("single", 1)[0]
+    ranks = run("sharded", 4)
+    info = [json.loads(str(r["info"])) for r in ranks]
+    assert info[0]["n_cliques"] == 11 and info[0]["max_children"] == 2, info[0]
+    owners = info[0]["owners"]
+    assert all(i["owners"] == owners for i in info) and set(owners.values()) == {0, 1, 2, 3}, owners
+    assert info[0]["up"]["cross_rank_edges"] == 3 and info[0]["down"]["cross_rank_edges"] >= 3, (info[0]["up"], info[0]["down"])
+    assert sum(i["up"]["cliques_trained_here"] for i in info) == 11 and min(i["up"]["cliques_trained_here"] for i in info) >= 2
+    names = [k for k in single if k != "info"]
+    for v in names:
+        for r in range(1, 4):                                       # every rank ends with the same samples of every variable
+            np.testing.assert_allclose(ranks[0][v], ranks[r][v], atol=1e-5)
+        assert ranks[0][v].shape == single[v].shape and np.all(np.isfinite(ranks[0][v]))
+    for v in names:
+        a, b = ranks[0][v][:, :2], single[v][:, :2]
+        scale = max(1.0, float(b.std(0).max()))
+        m = _mmd(a / scale, b / scale, np.sqrt(2.0))
+        assert m < 0.16, (v, m)
+        assert np.linalg.norm(a.mean(0) - b.mean(0)) < 0.5 + 0.25 * scale, (v, a.mean(0), b.mean(0))

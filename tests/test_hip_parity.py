@@ -934,7 +934,12 @@ def test_multilayer_hidden_dim_16_on_the_two_dims_per_wave_kernel(K):
     stage's layer at the top of every stage, from the clique's panel image or -- iteration 0 of a chunk, VJP calls -- from
     the parameters.  Same checks as hidden_dim 4 (below): against the generic kernel, the float64 oracle, image on / off.
     (C2's shape with hidden_dim 16: `regimes.C2_..._H16` of the bench line.)"""
-    _pair_kernel_of_another_width(K, 16, [(300, 5), (257, 8), (64, 1), (200, 2), (129, 6)])
+    # (round 6: the widest clique the kernel takes at this hidden width goes first -- one layer's panels of ALL the clique's dims
+    #  must fit the CU's LDS next to the tiles, and the launch-shape rule asks that of num_knots 16 whatever K is (`pair_h4_fits`,
+    #  csrc/nsf_kernels.hip: a function of the launch shape only): D <= 9.  Wider cliques, PAIR_MAX_D = 16 included, train on the
+    #  generic kernel.  So the last wave of an odd clique, five waves and a dW0 row beyond 8 meet the oracle too, not only D <= 8.)
+    widest = 9
+    _pair_kernel_of_another_width(K, 16, [(120, widest), (300, 5), (257, 8), (64, 1), (200, 2), (129, 6)])
 
 
 def _pair_kernel_of_another_width(K, H, shapes):
@@ -945,30 +950,47 @@ def _pair_kernel_of_another_width(K, H, shapes):
     dL/dx of single calls (`nfisam_nsf_backward`), and a six-iteration loss curve; panel image on / off bit for bit.
     (C2's shape with hidden_dim 4: 60.3 -> 29.2 us per iteration, `regimes.C2_..._H04` of the bench line.)"""
     B, L = 5.0, 3                                       # (a small launch; hidden_dim 4: D = 11 x 3 layers -- the panels of num_knots 16 still fit)
+    # Bars (round 6, VERDICT r5 weak #1d): SURVEY 8(c)'s -- 1e-4 x scale between kernels, 2e-5 x L absolute + 2e-3 relative against
+    # the float64 oracle, 4e-2 on the loss curve -- for EVERY (K, H), plus what float32 itself costs on the problem at hand: three
+    # times the distance of the float32 ORACLE from the float64 one (its 99.9 % quantile), as test_multilayer_training_follows_the_oracle
+    # does.  Round 5 had loosened the constants 10-30 x for all of hidden_dim 16 because of (K, H) = (16, 16); what is wild is not a
+    # (K, H) but single PROBLEMS: three stacked layers can put a particle within rounding of a knot of a later layer, and then every
+    # float32 evaluation differs -- scripts/exp/h16_diag2.py, K = 9, H = 16, n = 300, D = 5, seed 901: float32 oracle 7.1e-3 x max|g|
+    # off float64 (589 of 9318 entries beyond 1e-4), generic kernel 2.9e-3, this kernel 4.0e-4; seeds 900 / 902: all three 1e-5.
     with _Env(NFISAM_TRAIN="wide"):
         _, wide, _ = _train_layers(shapes, L, 1, 1, False, K=K, H=H)
     _, pair, probs = _train_layers(shapes, L, 1, 1, False, K=K, H=H)
+    g64s, owns = [], []
+    for c, (n, D) in enumerate(shapes):
+        blob, x = probs[c]
+        lossc, gradc, _, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+        _, g32, _, _ = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float32, want_gx=True)
+        g64s.append((lossc, gradc, gxc))
+        owns.append(float(np.quantile(np.abs(np.asarray(g32, dtype=np.float64) - gradc), 0.999)))      # float32's own distance from float64
     for c in range(len(shapes)):
         assert not np.array_equal(wide[1][c], pair[1][c])       # two kernels (rounding differs somewhere)
         scale = np.abs(wide[1][c]).max()
-        # (hidden_dim 16 x num_knots 16 x three layers: BOTH kernels sit 1e-4 .. 1e-3 x max|g| off the float64 oracle -- the
-        #  generic one further, scripts/exp/h16_diag.py -- so the bar between them is that rounding level, not 1e-4)
-        np.testing.assert_allclose(pair[1][c], wide[1][c], atol=(3e-3 if H == 16 else 1e-4) * scale, rtol=2e-3, err_msg=str((K, c)))
+        own_m = 0.1 * owns[c]                                   # (the first Adam moment is 0.1 x gradient)
+        d = np.abs(pair[1][c] - wide[1][c])
+        excess = d - 2e-3 * np.abs(wide[1][c]) - 1e-4 * scale - 6.0 * own_m
+        print("K %d H %d clique %d (n %d, D %d): kernel vs kernel %.2e x max|m| (float32 oracle's own distance from float64: %.2e x), over the bar %d of %d"
+              % (K, H, c, shapes[c][0], shapes[c][1], d.max() / scale, own_m / scale, int((excess > 0).sum()), excess.size))
+        assert (excess > 0).mean() < 3e-4 and excess.max() < 2e-3 * scale, (K, c, int((excess > 0).sum()), float(excess.max() / scale))
         np.testing.assert_allclose(pair[3][c][:1], wide[3][c][:1], rtol=2e-5)
     for c, (n, D) in enumerate(shapes[:3]):
         blob, x = probs[c]
-        lossc, gradc, _, gxc = CO.nll_grad(x, blob, K, H, B, L, dtype=np.float64, want_gx=True)
+        lossc, gradc, gxc = g64s[c]
         kg, gx, loss = nh.backward(dev(x), kpack(blob, D, K, H, L), K, H, B, L, nll_mode=True, want_gx=True)
         assert abs(loss.item() / n + 0.5 * D * np.log(2 * np.pi) - lossc) < 3e-4 * L, (K, c)
         # (three layers in fp32 against fp64: a particle next to a knot may pick the other bin -- a handful of the ~17 k entries
         #  may sit up to 1 % off; measured at hidden_dim 16: 1 entry, 0.75 %)
         gk, sc = nh.unpack(kg, D, K, H, L).cpu().numpy() / n, max(1.0, float(np.abs(gradc).max()))
-        # (hidden_dim 16 x three layers: the fp32 kernels -- this one and the generic one alike -- sit ~1e-4 x max|g| off the float64
-        #  oracle at num_knots 16, scripts/exp/h16_diag.py: the absolute part of the bar is that level there)
-        excess = np.abs(gk - gradc) - 2e-3 * np.abs(gradc) - (2e-4 if H == 16 else 2e-5) * L * sc
+        excess = np.abs(gk - gradc) - 2e-3 * np.abs(gradc) - 2e-5 * L * sc - 3.0 * owns[c]
+        print("K %d H %d clique %d (D %d): gradient vs float64 oracle: max |err| %.2e x max|g| (float32 oracle's own q99.9: %.2e x), over the bar %d of %d"
+              % (K, H, c, D, np.abs(gk - gradc).max() / sc, owns[c] / sc, int((excess > 0).sum()), excess.size))
         assert (excess > 0).mean() < 3e-4 and excess.max() < 2e-3 * sc, (K, c, (excess > 0).sum(), excess.max())
         ex = np.abs(gx.cpu().numpy() / n - gxc)            # (a particle next to a knot may pick the other bin in fp32: dL/dx jumps there)
-        assert np.quantile(ex, 0.98) < 2e-3 * np.abs(gxc).max() + 2e-5 * L and ex.max() < 0.05 * max(1.0, np.abs(gxc).max()), (K, c)
+        assert np.quantile(ex, 0.98) < 2e-3 * np.abs(gxc).max() + 2e-5 * L + 3.0 * owns[c] and ex.max() < 0.05 * max(1.0, np.abs(gxc).max()), (K, c)
     iters = 6
     with _Env(NFISAM_PAIR_IMAGE="0"):
         _, ref, _ = _train_layers(shapes, L, iters, 50, True, K=K, H=H, lr=0.02, early_stop=False)
@@ -980,12 +1002,17 @@ def _pair_kernel_of_another_width(K, H, shapes):
         if c < 2:
             blob, x = probs[c]
             _, l64, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.02, max_iters=iters, early_stop=False, dtype=np.float64)
-            # (three layers at this step size amplify rounding from the fourth iteration on: test_multilayer_training_follows_the_oracle)
-            # (hidden_dim 16 x num_knots 16: the third loss already 6e-5 relative off the float64 curve -- three layers at this step size)
-            np.testing.assert_allclose(out[3][c][:3], l64[:3], atol=(3e-3 if H == 16 else 2e-4), rtol=1e-5, err_msg=str((K, c)))
-            # (hidden_dim 16 x num_knots 16: the loss RISES at the second iteration -- 25.3, 28.1, 23.4 -- in the oracle too: an
-            #  unstable start, from which float32 and float64 part ways: 8 % at iteration 6)
-            np.testing.assert_allclose(out[3][c][:iters], l64[:iters], rtol=(0.15 if H == 16 else 4e-2), err_msg=str((K, c)))
+            _, l32, _, _, _ = CO.train(x, blob, K, H, B, L, lr=0.02, max_iters=iters, early_stop=False, dtype=np.float32)
+            got, l64 = out[3][c][:iters].astype(np.float64), np.asarray(l64, dtype=np.float64)[:iters]
+            own = np.abs(np.asarray(l32, dtype=np.float64)[:iters] - l64)
+            print("K %d H %d clique %d: loss curve vs float64 oracle, relative: %s   (float32 oracle's own: %s)"
+                  % (K, H, c, " ".join("%.1e" % v for v in np.abs(got / l64 - 1.0)), " ".join("%.1e" % v for v in own / np.abs(l64))))
+            # the first three iterations to 2e-4 absolute, the curve to 4e-2 relative (three layers at this step size amplify rounding
+            # from the fourth iteration on: test_multilayer_training_follows_the_oracle), each + 3 x the float32 oracle's own distance
+            # ((K, H) = (16, 16): the loss RISES at the second iteration -- 25.3, 28.1, 23.4 -- in the oracle too, an unstable start
+            #  from which float32 and float64 part ways: 8 % at iteration 6 for the oracle itself)
+            assert np.all(np.abs(got[:3] - l64[:3]) <= 2e-4 + 1e-5 * np.abs(l64[:3]) + 3.0 * own[:3]), (K, c, got, l64, own)
+            assert np.all(np.abs(got - l64) <= 4e-2 * np.abs(l64) + 3.0 * own), (K, c, got, l64, own)
 
 
 def test_multilayer_training_follows_the_oracle():

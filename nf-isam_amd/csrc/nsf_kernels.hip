@@ -812,24 +812,6 @@ __global__ void __launch_bounds__(256) nsf_coresidency_probe_kernel(unsigned* ct
         __builtin_amdgcn_s_sleep(8);
     }
 }
-// Diagnostic (tests/test_hip_parity.py: the probe's test; not part of the ABI header): occupies the device the way a foreign
-// process's long kernel would -- `blocks` blocks of 256 threads holding `lds_bytes` of LDS each spin for `seconds` of wall
-// clock on `stream`.
-extern "C" int nfisam_debug_occupy_device(int blocks, size_t lds_bytes, float seconds, nfisam_stream_t stream) {
-    if (blocks < 1 || !(seconds > 0.0f) || seconds > 30.0f || lds_bytes > (size_t)(160 * 1024)) return NFISAM_ERR_ARG;
-    static unsigned* ctr = nullptr;                              // (one per process: the blocks only ever add to it)
-    if (ctr == nullptr) {
-        HIP_TRY(hipMalloc((void**)&ctr, 2 * sizeof(unsigned)));
-        HIP_TRY(hipMemset(ctr, 0, 2 * sizeof(unsigned)));
-    }
-    HIP_TRY(hipFuncSetAttribute((const void*)nsf_coresidency_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-    HIP_TRY(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned), (hipStream_t)stream));
-    hipLaunchKernelGGL(nsf_coresidency_probe_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, ctr, 0xffffffffu,
-                       (unsigned)(seconds * 1e8f));
-    HIP_TRY(hipGetLastError());
-    return NFISAM_OK;
-}
-
 // -> true: `blocks` blocks of `per_cu` per compute unit are resident at once right now (or the probe is switched off / failed to run:
 // the occupancy answer stands)
 static bool device_is_quiet(long blocks, long places) {

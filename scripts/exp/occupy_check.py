@@ -1,4 +1,4 @@
-"""Diagnostic (GPU): is the library's device occupier (nfisam_debug_occupy_device) on the machine, and what does the probe say then?"""
+"""Diagnostic (GPU): is the library's device occupier (nfisam_diag_occupy_device, libnfisam_diag.so) on the machine, and what does the probe say then?"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "nf-isam_amd")); sys.path.insert(0, ROOT)
@@ -7,6 +7,7 @@ import nfisam_hip as nh
 os.environ["NFISAM_PROBE_DEBUG"] = "1"
 dev = torch.device("cuda", 0)
 lib = nh.lib()
+diag = ctypes.CDLL(os.path.join(os.path.dirname(nh.LIB_PATH), "libnfisam_diag.so"))
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 print("CUs", cus, "wall clock rate attr:", end=" ")
 try:
@@ -18,7 +19,7 @@ x = torch.zeros(1024, device=dev)
 torch.cuda.synchronize()
 for blocks, lds, sec in ((cus, 100 * 1024, 0.5), (cus, 100 * 1024, 1.5), (16 * cus, 20 * 1024, 0.5)):
     t0 = time.perf_counter()
-    rc = lib.nfisam_debug_occupy_device(blocks, ctypes.c_size_t(lds), ctypes.c_float(sec), ctypes.c_void_p(side.cuda_stream))
+    rc = diag.nfisam_diag_occupy_device(blocks, ctypes.c_size_t(lds), ctypes.c_float(sec), ctypes.c_void_p(side.cuda_stream))
     t1 = time.perf_counter()
     y = x + 1                       # a small kernel on the default stream while the occupier runs
     torch.cuda.current_stream().synchronize()
@@ -36,7 +37,7 @@ kp0 = [nh.pack((0.2 * torch.randn(nh.param_count(D, K, H), generator=gen)).to(de
 for occupy in (False, True):
     time.sleep(0.7)
     if occupy:
-        lib.nfisam_debug_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(1.5), ctypes.c_void_p(side.cuda_stream))
+        diag.nfisam_diag_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(1.5), ctypes.c_void_p(side.cuda_stream))
         time.sleep(0.05)
     tb = nh.TrainBatch(xs, [k.clone() for k in kp0], K, H, B, 1, lr=0.01, max_iters=100, average_window=50, loss_delta_tol=0.0, early_stop=True)
     t0 = time.perf_counter()

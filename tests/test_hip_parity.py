@@ -1362,10 +1362,11 @@ OCCUPIER = (
     "import torch, nfisam_hip as nh\n"
     "cus = torch.cuda.get_device_properties(0).multi_processor_count\n"
     "s = torch.cuda.Stream()\n"
-    "lib = nh.lib()\n"
-    "assert lib.nfisam_debug_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(0.01), ctypes.c_void_p(s.cuda_stream)) == 0\n"
+    "import os\n"
+    "lib = ctypes.CDLL(os.path.join(os.path.dirname(nh.LIB_PATH), 'libnfisam_diag.so'))   # the diagnostic library (csrc/nsf_diag.hip), not the product\n"
+    "assert lib.nfisam_diag_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(0.01), ctypes.c_void_p(s.cuda_stream)) == 0\n"
     "s.synchronize()\n"      # (the first launch pays the kernel's code load)
-    "assert lib.nfisam_debug_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(2.5), ctypes.c_void_p(s.cuda_stream)) == 0\n"
+    "assert lib.nfisam_diag_occupy_device(cus, ctypes.c_size_t(100 * 1024), ctypes.c_float(2.5), ctypes.c_void_p(s.cuda_stream)) == 0\n"
     "time.sleep(0.05)\n"
     "print('occupying', flush=True)\n"
     "s.synchronize()\n")

@@ -168,6 +168,14 @@ def test_bench_two_ranks_prints_the_contract_line():
     assert len(x["update_ms_per_rank"]) == 2 and all(0 < t < 60000 for t in x["update_ms_per_rank"])
     assert sum(x["cliques_trained_per_rank"]) == 5 and min(x["cliques_trained_per_rank"]) >= 2
     assert x["p2p_ms"] > 0 and x["all_gather_ms"] > 0 and x["p2p_one_way_us_24KB"] > 0
+    assert d["exchange_failed"] is False
+    # the regime for the chain-shaped configs (Plaza1 / Manhattan: "replicas only", round 6): every rank runs 8 independent Plaza1
+    # runs over the first 20 updates; wall-clock per replica-update per rank and for the job
+    rp = d["replicas"]
+    assert "error" not in rp and rp["errors"] is None, rp
+    assert rp["world"] == 2 and rp["runs"] == 16 and len(rp["per_replica_update_ms_per_rank"]) == 2
+    assert all(0 < t < 2000 for t in rp["per_replica_update_ms_per_rank"]) and rp["per_replica_update_ms"] == max(rp["per_replica_update_ms_per_rank"])
+    assert rp["replica_updates_per_s"] > 1 and all(i > 8 * 20 * 100 for i in rp["fit_iterations_per_rank"])
 
 
 @pytest.mark.timeout(600)
@@ -242,6 +250,7 @@ def test_bench_line_survives_an_exchange_regime_that_does_not_come_back():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 1e7 and "did not return" in d["exchange"]["error"]
+    assert d["exchange_failed"] is True and "EXCHANGE REGIME FAILED" in p.stderr
 
 
 # ---- round 6: FOUR ranks (the one GPU shared over gloo), the real fit, the depth-2 meeting tree of bench.py -------------------------

@@ -174,7 +174,7 @@ def test_bench_two_ranks_prints_the_contract_line():
     rp = d["replicas"]
     assert "error" not in rp and rp["errors"] is None, rp
     assert rp["world"] == 2 and rp["runs"] == 16 and len(rp["per_replica_update_ms_per_rank"]) == 2
-    assert all(0 < t < 2000 for t in rp["per_replica_update_ms_per_rank"]) and rp["per_replica_update_ms"] == max(rp["per_replica_update_ms_per_rank"])
+    assert all(0 < t < 2000 for t in rp["per_replica_update_ms_per_rank"]) and abs(rp["per_replica_update_ms"] - max(rp["per_replica_update_ms_per_rank"])) < 1e-3
     assert rp["replica_updates_per_s"] > 1 and all(i > 8 * 20 * 100 for i in rp["fit_iterations_per_rank"])
 
 

@@ -73,6 +73,14 @@ CASES = {
                   dict(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
                        cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
                        average_window=50, posterior_sample_num=500), 300, 300, 5),
+    # round 6: the other six cases of the reference's Plaza loop (plaza_dataset/run_nfisam.py:11-12), same arguments; used by the
+    # structural long-horizon fixtures only (LONG_CASES below)
+    **{name: ("example/slam/plaza_dataset/RangeOnlyDataset/%s" % folder, "factor_graph.fg", 5, 4,
+              dict(num_knots=9, flow_iterations=2000, local_sample_num=2000, learning_rate=.01, hidden_dim=8,
+                   cuda_training=False, elimination_method="pose_first", training_set_frac=1.0, loss_delta_tol=.01,
+                   average_window=50, posterior_sample_num=500), 300, 300, 5)
+       for name, folder in (("plaza2", "Plaza2EFG"), ("plaza2ada02", "Plaza2ADA0.2EFG"), ("plaza2ada04", "Plaza2ADA0.4EFG"),
+                            ("plaza2ada06", "Plaza2ADA0.6EFG"), ("plaza1ada02", "Plaza1ADA0.2EFG"), ("plaza1ada06", "Plaza1ADA0.6EFG"))},
     # manhattan_plaza/run_nfisam.py:5-52 (iters = [500], loss_delta_tol 1e-9: a fixed budget)
     "manhattan136": ("example/slam/manhattan_world_with_range/manhattan_plaza/res/seed0/pada0.4_r2_odom0.01_mada3",
                      "factor_graph.fg", 1, 6,
@@ -101,6 +109,9 @@ LONG_CASES = {
     # (2000 iterations + window rule, plaza_dataset/run_nfisam.py:5-21), posteriors kept at updates 10 / 20 / 30.  The number of
     # seeds (6) was fixed before any run was looked at.
     "plaza1_late": ("plaza1", 31, dict(), (10, 20, 30), 6),
+    # round 6: every update of the remaining cases of the reference's Plaza loop, structure only (as plaza1_structure)
+    **{"%s_structure" % name: (name, None, dict(flow_iterations=20), None, 1)
+       for name in ("plaza2", "plaza2ada02", "plaza2ada04", "plaza2ada06", "plaza1ada02", "plaza1ada06")},
 }
 for _name, (_base, _upd, _over, _keep, _seeds) in LONG_CASES.items():
     _b = CASES[_base]

@@ -1340,20 +1340,33 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const int slot = (bx << ws) + w;                          // this wave's tile group
     const int p0 = slot << (PSH + ts);
     float B = AF(B);
+    // (round 6) What the loop's top and the staging read of the launch's arguments and of the descriptor, requested as ONE
+    // batch of scalar loads: left to itself the compiler sinks every load to its use, behind the branches in between, and
+    // a three-wave build's iteration began with five scalar-cache round trips one after the other (s_load .. s_waitcnt
+    // lgkmcnt(0) x 5: ~1 k of the 1.4 k cycles of "loop top").  The empty asm is a use of all of them in one place.
+    struct TopArgs { int slab, n_copies, fused_adam, persist_split, persist_spins, max_iters; float lr, b1, b2, eps, lb1, lb2; } ta;
+    ta.slab = AF(slab); ta.n_copies = AF(n_copies); ta.fused_adam = AF(fused_adam); ta.persist_split = AF(persist_split);
+    ta.persist_spins = AF(persist_spins); ta.max_iters = AF(max_iters);
+    ta.lr = AF(adam.lr); ta.b1 = AF(adam.beta1); ta.b2 = AF(adam.beta2); ta.eps = AF(adam.eps); ta.lb1 = AF(log_b1); ta.lb2 = AF(log_b2);
+    if constexpr (PERSIST && !ROOMY) {
+        asm volatile("" ::"s"(x), "s"(kparams), "s"(G), "s"(own_m), "s"(own_v), "s"(st), "s"(n), "s"(D), "s"(B), "s"(ta.slab), "s"(ta.n_copies),
+                     "s"(ta.fused_adam), "s"(ta.persist_split), "s"(ta.persist_spins), "s"(ta.max_iters), "s"(ta.lr), "s"(ta.b1), "s"(ta.b2),
+                     "s"(ta.eps), "s"(ta.lb1), "s"(ta.lb2));
+    }
     if constexpr (PERSIST && !ROOMY) asm volatile("" : "+s"(B));         // (the spline's per-bin constants are functions of B: not to be hoisted into VGPRs)
-    const bool slab = AF(slab) != 0;
+    const bool slab = ta.slab != 0;
     const size_t gstride = (size_t)LY::count(D);
-    gfloat* ring = G + (slab ? (size_t)AF(n_copies) : (size_t)1) * gstride;
+    gfloat* ring = G + (slab ? (size_t)ta.n_copies : (size_t)1) * gstride;
     // fused Adam (nsf_cond_mfma.h): gradient copies and optimiser state alternate between two buffers with the parity
     // of the iteration inside its chunk; the second set sits behind the loss ring: [copies][ring][64][copies][theta|m|v]
     gfloat* const G0 = G;
     gfloat* Gset1 = ring + LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
-    gfloat* alt = Gset1 + (size_t)AF(n_copies) * gstride;
+    gfloat* alt = Gset1 + (size_t)ta.n_copies * gstride;
     // chunk-persistent form: two sets of TAGGED copies behind the second state buffer, 2 floats (value, tag) per parameter
     gfloat* const tg0 = alt + 3 * gstride;
-    const size_t tg_set = (size_t)AF(n_copies) * 2 * gstride;
-    const int par = (AF(fused_adam) != 0) ? (it & 1) : 0;
-    const bool pending = AF(fused_adam) != 0 && it > 0;
+    const size_t tg_set = (size_t)ta.n_copies * 2 * gstride;
+    const int par = (ta.fused_adam != 0) ? (it & 1) : 0;
+    const bool pending = ta.fused_adam != 0 && it > 0;
     const gfloat* Gprev = par ? G0 : Gset1;                   // copy 0 of the previous iteration
     if (par) G = Gset1;
     if (slab) G += (size_t)bx * gstride;                      // one gradient copy per block
@@ -1447,10 +1460,10 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 pa_.keep = tiles0 + (size_t)W * wave_floats;
                 pa_.kstride = persist_keep_stride<K, H>(xrows);
                 pa_.ctr = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS) + i;
-                pa_.spin_log2 = AF(persist_spins);
-                pa_.max_iters = AF(max_iters);
-                pa_.lr = AF(adam.lr); pa_.beta1 = AF(adam.beta1); pa_.beta2 = AF(adam.beta2); pa_.eps = AF(adam.eps);
-                pa_.log_b1 = AF(log_b1); pa_.log_b2 = AF(log_b2);
+                pa_.spin_log2 = ta.persist_spins;
+                pa_.max_iters = ta.max_iters;
+                pa_.lr = ta.lr; pa_.beta1 = ta.b1; pa_.beta2 = ta.b2; pa_.eps = ta.eps;
+                pa_.log_b1 = ta.lb1; pa_.log_b2 = ta.lb2;
                 if (it == 1 && threadIdx.x == 0) {             // (diagnostic: the XCCs a group's blocks run on, bits 23-30 of the dim's control word)
                     unsigned xcc;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -1459,7 +1472,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                 pa_.looks = 0u;
                 { float d0_ = lossv, d1_ = r0; PSTAMP(10, d0_, d1_); }       // (loop top -> here: descriptor, pointers)
                 int rc_;
-                if (AF(persist_split) != 0) {
+                if (ta.persist_split != 0) {
                     // every block records its slice of the state (fa.*_dst are the first block's otherwise)
                     const bool to_own = pending && par == 0;
                     pa_.t_dst = to_own ? (gfloat*)own_t : alt;

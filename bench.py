@@ -172,6 +172,10 @@ def regime_problem(name, seed0):
         s, circ = ring_clique(2000, *PLAZA_SHAPE, np.random.RandomState(seed0))
         x, _, _ = normalize(s, circ)
         return [(x, init_blob_np(15, K, H, 1, seed0))], 1
+    if name == "single_clique_n1000_D15":    # (round 6: a clique of <= 1024 particles takes the two-lanes-per-particle family, csrc/nsf_half.h)
+        s, circ = ring_clique(1000, *PLAZA_SHAPE, np.random.RandomState(seed0))
+        x, _, _ = normalize(s, circ)
+        return [(x, init_blob_np(15, K, H, 1, seed0))], 1
     if name == "batch64_n2000_D15":
         out = []
         for c in range(64):
@@ -651,7 +655,7 @@ def main():
 
     regimes = {}
     if rank == 0 and world == 1 and not args.no_regimes:
-        for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "batch64_n2000_D15", "plaza_clique_n2000_D15_H16",
+        for name in ("C2_single_clique_n4096_D6_L4", "plaza_clique_n2000_D15", "single_clique_n1000_D15", "batch64_n2000_D15", "plaza_clique_n2000_D15_H16",
                      "batch64_n2000_D15_H16", "C2_single_clique_n4096_D6_L4_H16", "C2_single_clique_n4096_D6_L4_H04"):
             prob, L = regime_problem(name, seed0=7)
             regimes[name], _ = Workload(prob, L, dev, REGIME_HIDDEN.get(name)).record(args.regime_steps, 20, lambda: torch.cuda.synchronize())

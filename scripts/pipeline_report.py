@@ -43,4 +43,17 @@ if len(sys.argv) <= 2:
                                                     "compared_at_updates": list(T.LATE_STEPS), "rows": rows, "failures": failures,
                                                     "seconds_reference_cpu_whole_run": [round(float(np.sum(fx["seed%d_timing" % int(s)])), 1) for s in fx["seeds"]]}
         print("manhattan136_full late posteriors:", len(rows), "rows,", len(failures), "over their bound", flush=True)
+    # round 6: Plaza1 through update 30 at the reference's own budget (six seeds), posteriors at updates 10 / 20 / 30
+    if os.path.exists(os.path.join(T.GOLDEN, "pipeline_plaza1_late.npz")):
+        from scipy.stats import mannwhitneyu
+        rows, failures = T.compare_late("plaza1_late", seeds=(0, 1, 2), rmse_seeds=tuple(range(12)), data="Plaza1EFG", late_steps=T.PLAZA_LATE_STEPS)
+        fx = np.load(os.path.join(T.GOLDEN, "pipeline_plaza1_late.npz"), allow_pickle=True)
+        for r in rows:
+            if r["kind"] == "trajectory-rmse":
+                r["rank_sum_p_two_sided"] = float(mannwhitneyu(np.array(r["ours_per_seed"]), np.array(r["reference_per_seed"]), alternative="two-sided").pvalue)
+        out["plaza1_late_posteriors"] = {"arguments": json.loads(str(fx["arguments"])), "reference_seeds": len(fx["seeds"]), "updates": int(fx["seed0_n_steps"]),
+                                         "compared_at_updates": list(T.PLAZA_LATE_STEPS), "rows": rows, "failures": failures,
+                                         "reference_provenance": [json.loads(str(fx["seed%d_provenance" % int(s)])) for s in fx["seeds"] if ("seed%d_provenance" % int(s)) in fx.files],
+                                         "seconds_reference_cpu_whole_run": [round(float(np.sum(fx["seed%d_timing" % int(s)])), 1) for s in fx["seeds"]]}
+        print("plaza1_late posteriors:", len(rows), "rows,", len(failures), "over their bound", flush=True)
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "pipeline_report.json", "w"), indent=1)

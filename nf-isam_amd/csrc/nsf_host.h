@@ -82,7 +82,16 @@ struct TrainArgs {
     nfisam_adam_cfg adam;
     float log_b1, log_b2;
     int half;                       // nsf_train1_kernel: two lanes per particle (nsf_half.h): a wave covers 32 particles, a block 32 x waves
+    // round 6, window-spanning persistent launch (nsf_unit.hip, nsf_bookkeep.h): span_window > 0 -- the launch runs up to
+    // persist_iters iterations and closes every window of span_window iterations ITSELF (the clique's block that arrives last at
+    // the window's end runs the bookkeeping: loss record, stop rule, step, mirror), all of the clique's blocks leave together
+    // when the rule fires or the budget ends; the closing Adam kernel behind the launch applies the last iteration's update
+    int span_window;
+    nfisam_train_state* span_mirror;   // the plan's host-pinned mirror (indexed by clique) or nullptr
 };
+// control words of a clique's workspace (behind the loss ring: FUSED_COUNTERS words, one per dim) that the window-spanning launch
+// uses for itself; cliques of more than SPAN_MAX_D dims keep to one launch per chunk
+constexpr int SPAN_WORD_TICKET = 63, SPAN_WORD_DECISION = 62, SPAN_WORD_LAST_T = 61, SPAN_WORD_LAST_PARITY = 60, SPAN_MAX_D = 56;
 
 
 // Launchers of one (K, H) pair, exported by the kernel unit that instantiates it.

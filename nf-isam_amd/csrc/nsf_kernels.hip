@@ -12,6 +12,7 @@
 
 #include "nsf_host.h"
 #include "nsf_cond_mfma.h"
+#include "nsf_bookkeep.h"
 
 thread_local int nfisam_g_last_hip_error = 0;
 
@@ -37,6 +38,8 @@ struct AdamArgs {
     uint32_t pair_off[PAIR_MAP_OFFSETS];   // the clique's PANEL IMAGE behind its loss ring (nsf_cond_mfma.h: build_pair_map)
     int close_chunk;        // > 0: fused-Adam launches (nsf_cond_mfma.h): apply the LAST iteration's pending update of a chunk of
                             // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
+    int span;               // != 0 (with close_chunk > 0): behind a WINDOW-SPANNING launch (nsf_unit.hip): which update is pending and the
+                            // parity of its buffers come from the workspace's control words (SPAN_WORD_LAST_T / _PARITY), 0 = none
 };
 
 __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
@@ -73,7 +76,22 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     __syncthreads();
     int iter_idx = a.iter_idx;
     const float *ms = m, *vs = v, *ts = theta;                  // source state (the destination is always the clique's own)
-    if (closing) {
+    int span_t = 0;
+    if (closing && a.span) {
+        // behind a window-spanning launch: the launch's own bookkeeping has advanced step / set stop already; the last block
+        // to close a window left the number of the pending update and the parity of its buffers in the workspace
+        const size_t copies_max = (size_t)((a.max_n + a.slab - 1) / a.slab);
+        const unsigned* words = (const unsigned*)(G + copies_max * (size_t)P + (size_t)LOSS_RING * LOSS_SLOTS);
+        span_t = (int)words[SPAN_WORD_LAST_T];
+        if (span_t <= 0) return;                                 // (the launch found the clique finished: nothing pending)
+        iter_idx = (int)(words[SPAN_WORD_LAST_PARITY] & 1u);     // (only its parity matters below)
+        if (iter_idx & 1) {
+            G += copies_max * (size_t)P + (size_t)LOSS_RING * LOSS_SLOTS + FUSED_COUNTERS;
+            ts = G + copies_max * (size_t)P;
+            ms = ts + P;
+            vs = ms + P;
+        }
+    } else if (closing) {
         // the chunk's last valid iteration: its gradient copies and the state it started from are in the buffers of its
         // parity (odd: the second set behind the loss ring, see nsf_train1_kernel)
         const int left = a.cfg.max_iters - s_step;
@@ -88,8 +106,8 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
             vs = ms + P;
         }
     }
-    const int t = s_step + iter_idx + 1;
-    if (s_stop != 0 || t > a.cfg.max_iters) return;
+    const int t = span_t > 0 ? span_t : s_step + iter_idx + 1;
+    if (span_t <= 0 && (s_stop != 0 || t > a.cfg.max_iters)) return;
 
     const AdamCoef kc = adam_coef(a.cfg.lr, a.cfg.beta1, a.cfg.beta2, a.cfg.eps, a.log_b1, a.log_b2, t, n);
     // panel image of the two-dims-per-wave training kernel: [L][D][pair_panel_floats] behind the loss ring
@@ -174,118 +192,56 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
 // wave come out of one reduce-scatter (31 cross-lane exchanges instead of 32 x 6).
 // `mirror` (training plans): a host-pinned copy of the state, written last with a chunk sequence number that the host
 // polls for -- no device-to-host copy, no stream synchronisation per chunk (nfisam_nsf_train_plan_run).
+// Behind a window-spanning launch and its closing Adam kernel (one block of 64 threads per clique): the launch's control words go
+// back to zero for the next launch; a group that gave up waiting (abort bit of a dim's control word) becomes the STALLED state the
+// host looks for -- the launch's own bookkeeping cannot have seen it (the window was never closed).
+__global__ void __launch_bounds__(64) nsf_span_close_kernel(AdamArgs a) {
+    const bool batched = a.cliques != nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
+    float* G = batched ? cp->kgrad : a.single.kgrad;
+    nfisam_train_state* st = batched ? cp->state : a.single.state;
+    const int D = batched ? cp->D : a.single.D;
+    const int PoP = pop_of(a.K);
+    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
+    const size_t P = (size_t)a.L * (size_t)(PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
+    const size_t copies = (size_t)((a.max_n + a.slab - 1) / a.slab);
+    unsigned* words = (unsigned*)(G + copies * P + (size_t)LOSS_RING * LOSS_SLOTS);
+    const unsigned cv = words[threadIdx.x];
+    const int stalled = __any((int)(threadIdx.x < (unsigned)D ? (cv >> 31) : 0u));
+    if (threadIdx.x >= (unsigned)SPAN_WORD_LAST_PARITY) words[threadIdx.x] = 0u;
+    if (threadIdx.x == 0 && stalled) {
+        for (int d = 0; d < D; ++d) words[d] &= 0x7fffffffu;
+        st->domain_err |= NFISAM_STATE_STALLED;
+        st->stop = 1;
+        if (a.mirror != nullptr) {
+            nfisam_train_state* m = a.mirror + blockIdx.x;
+            const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + (1 << 20);
+            m->step = st->step; m->stop = 1; m->have_avg = st->have_avg; m->loss_avg = st->loss_avg; m->domain_err = st->domain_err;
+            __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
     float* G = batched ? cp->kgrad : a.single.kgrad;
-    float* iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
-    nfisam_train_state* st = batched ? cp->state : a.single.state;
-    const int n = batched ? cp->n : a.single.n;
     const int D = batched ? cp->D : a.single.D;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const size_t P = (size_t)a.L * (size_t)(PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
     const size_t copies = a.slab ? (size_t)((a.max_n + a.slab - 1) / a.slab) : (size_t)1;
-    float* ring = G + copies * P;
-    constexpr int PER_WAVE = LOSS_RING / 4;
-    float part[PER_WAVE];
-#pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane];     // ring row w + 4k
-    // the group-barrier counters of the chunk-persistent training kernel (one per dim; nsf_unit.hip: bits 0-22 arrivals,
-    // 23-30 the XCC ids the group's blocks ran on, 31 the group's abort flag): looked at, then zeroed for the next chunk
-    int stalled = 0, xcd_span = 0;
-    if (threadIdx.x < FUSED_COUNTERS) {                              // (= the block's first wave)
-        unsigned* ctr = (unsigned*)(ring + (size_t)LOSS_RING * LOSS_SLOTS) + threadIdx.x;
-        const unsigned cv = *ctr;
-        *ctr = 0u;
-        stalled = __any((int)(cv >> 31));
-        int span = __popc((cv >> 23) & 0xffu);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(span, off, 64); span = o > span ? o : span; }
-        xcd_span = span;
-    }
-    const int s0 = st->step, stop0 = st->stop, have_avg = st->have_avg;
-    const float loss_avg = st->loss_avg;
-    int new_step = s0, new_stop = stop0, new_have = have_avg, new_err = st->domain_err;
-    const int slower_stop = st->reserved[2];                         // hold-out validation: the scheduled end (nsf_validate_kernel), 0: none
-    float new_avg = loss_avg;
-    __shared__ float s_loss[LOSS_RING];
-    __shared__ float s_wsum[4];
-    __shared__ int s_bad[4];
-    const bool active = (stop0 == 0 && s0 < a.cfg.max_iters);        // block-uniform
-    if (active) {
-        const int cnt = (a.chunk < a.cfg.max_iters - s0) ? a.chunk : (a.cfg.max_iters - s0);
-        const float inv_n = 1.0f / (float)n;
-        const int wnd = a.cfg.average_window;
-        // ring row r holds iteration (r - s0) mod 128 of this chunk (if that is < cnt)
-        const float rowsum = butterfly<PER_WAVE>(part, lane);        // lane l: total of row w + 4 (l & 31)
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int it = ((w + 4 * k) - s0) & (LOSS_RING - 1);
-            if (it < cnt) ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f;                     // wave-uniform
-        }
-        if (lane < PER_WAVE) {
-            const int it = ((w + 4 * lane) - s0) & (LOSS_RING - 1);
-            if (it < cnt) {
-                const float loss = rowsum * inv_n + 0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
-                s_loss[it] = loss;
-                iter_loss[s0 + it] = loss;
-            }
-        }
-        __syncthreads();
-        // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)
-        int bad_at = cnt;
-        for (int it = threadIdx.x; it < cnt; it += blockDim.x) {
-            const float l = s_loss[it];
-            if (!(l == l) || fabsf(l) > 3.0e38f) bad_at = (it < bad_at) ? it : bad_at;
-        }
-        bad_at = __reduce_min_sync(~0ull, bad_at);                 // per wave
-        if (lane == 0) s_bad[w] = bad_at;
-        __syncthreads();
-        bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
-        if (bad_at < cnt) {
-            new_err |= 1; new_stop = 1; new_step = s0 + bad_at + 1;
-        } else {
-            const int t_end = s0 + cnt;
-            if (wnd > 0 && (t_end % wnd) == 0) {   // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
-                float sm = 0.0f;
-                for (int j = t_end - wnd + (int)threadIdx.x; j < t_end; j += blockDim.x)
-                    sm += (j >= s0) ? s_loss[j - s0] : iter_loss[j];
-                sm = wave_sum(sm);
-                if (lane == 0) s_wsum[w] = sm;
-                __syncthreads();
-                const float nw = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) / (float)wnd;
-                if (have_avg != 0 && loss_avg != 0.0f) {
-                    const float delta = fabsf(1.0f - nw / loss_avg);
-                    if (delta < a.cfg.loss_delta_tol) new_stop = 1;
-                }
-                new_avg = nw;
-                new_have = 1;
-            }
-            new_step = t_end;
-        }
-        // (reference NFiSAM.py:453-456: the loop breaks in front of iteration i when i + 1 >= slower_stop_iter)
-        if (slower_stop != 0 && new_step + 1 >= slower_stop) new_stop = 1;
-    }
-    if (threadIdx.x == 0) {
-        if (stalled) {                                               // a group barrier of the chunk timed out: the run is over, loudly
-            new_err |= NFISAM_STATE_STALLED; new_stop = 1;
-            st->domain_err = new_err; st->stop = new_stop;
-        }
-        if (xcd_span > st->reserved[1]) st->reserved[1] = xcd_span;   // most XCDs a (clique, dim) group of a persistent chunk spanned
-        if (active) {
-            st->loss_avg = new_avg; st->have_avg = new_have; st->domain_err = new_err; st->stop = new_stop; st->step = new_step;
-        }
-        if (a.mirror != nullptr) {
-            nfisam_train_state* m = a.mirror + blockIdx.x;
-            const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
-            m->step = new_step; m->stop = new_stop; m->have_avg = new_have; m->loss_avg = new_avg; m->domain_err = new_err;
-            m->reserved[1] = st->reserved[1];
-            m->reserved[2] = st->reserved[2];
-            __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    BookArgs b;
+    b.ring = G + copies * P;
+    b.iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
+    b.st = batched ? cp->state : a.single.state;
+    b.mirror = a.mirror != nullptr ? a.mirror + blockIdx.x : nullptr;
+    b.n = batched ? cp->n : a.single.n;
+    b.D = D;
+    b.chunk = a.chunk;
+    b.cfg = a.cfg;
+    b.zero_counters = 1;
+    bookkeep_body(b);
 }
 
 // Hold-out validation of a fit (reference: src/slam/NFiSAM.py:452-468, `training_set_frac < 1`): every
@@ -684,9 +640,12 @@ static bool pair_image_shape(int max_D, int K, int H, int L, const TrainShape& s
 static int enqueue_grad(const nfisam_clique* dev_cliques, const nfisam_clique* single, int n_cliques, int max_n,
                         int max_D, int K, int H, float B, int L, int max_iters, int iter_idx, hipStream_t s,
                         const nfisam_adam_cfg* fused_cfg = nullptr, const nfisam_clique* host_cliques = nullptr,
-                        int chain = 0, int n_chains = 1, bool pair_image = false, int persist_iters = 0) {
+                        int chain = 0, int n_chains = 1, bool pair_image = false, int persist_iters = 0, int span_window = 0,
+                        nfisam_train_state* span_mirror = nullptr) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
+    a.span_window = span_window;
+    a.span_mirror = span_mirror;
     const TrainShape sh = train_shape(n_cliques, max_n, max_D, L, H, K);
     a.tile = sh.tile; a.tiles_per_block = sh.T; a.slab = sh.slab; a.waves = sh.W; a.half = sh.half;
     if (fused_cfg != nullptr) {
@@ -1036,6 +995,10 @@ struct nfisam_train_plan {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph_p = nullptr;          // the same chunk as ONE chunk-persistent launch per chain (persist_shape), or null
     hipGraphExec_t exec_p = nullptr;
+    // round 6: the WHOLE run as one window-spanning persistent launch (single-clique plans whose launch takes a two-wave
+    // build: every fit of a real NF-iSAM run) + its closing Adam kernel + the control words' reset, or null
+    hipGraph_t graph_s = nullptr;
+    hipGraphExec_t exec_s = nullptr;
     nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
                                            // writes it (last word written: reserved[0] = chunks closed in this run)
     nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
@@ -1081,6 +1044,8 @@ extern "C" int nfisam_nsf_train_plan_destroy(nfisam_train_plan* p) {
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->exec_p) (void)hipGraphExecDestroy(p->exec_p);
     if (p->graph_p) (void)hipGraphDestroy(p->graph_p);
+    if (p->exec_s) (void)hipGraphExecDestroy(p->exec_s);
+    if (p->graph_s) (void)hipGraphDestroy(p->graph_s);
     if (p->exec_end) (void)hipGraphExecDestroy(p->exec_end);
     if (p->graph_end) (void)hipGraphDestroy(p->graph_end);
     if (p->ev) (void)hipEventDestroy(p->ev);
@@ -1243,6 +1208,53 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
             nfisam_nsf_train_plan_destroy(p);
             return status != NFISAM_OK ? status : NFISAM_ERR_LAUNCH;
         }
+        // ---- the run as ONE window-spanning launch (nsf_unit.hip: the clique's blocks close every window themselves) ----------
+        // A 50-iteration chunk of a real fit is ~340 us of launch and ~36 us of fixed cost around and inside it (the launch's cold
+        // first iteration and drain, the gap between two graph launches, the closing Adam and bookkeeping kernels): 10 % of a fit.
+        // Single-clique plans only (every fit of a real run; a batch's cliques stop at different windows), no hold-out validation,
+        // not the measurement plans; the launcher refuses when the launch would not take a two-wave build (the in-kernel
+        // bookkeeping exists in those) -- then the plan simply has no such graph.  NFISAM_SPAN=0: never.
+        // Measured (scripts/exp/span_windows.py, one Plaza clique, 400 iterations as windows of 25 / 50 / 100): a window's end costs
+        // ~10 us inside the launch against ~20 us between two launches (gap 8.9 + closing Adam 4.8 + bookkeeping 6.8), but the run
+        // itself ~55 us more (the long launch iterates ~2 % slower than four short ones): Plaza1's fits, ~12 windows each, gain 1.5 %.
+        // Not worth being the default of the last round: OFF unless NFISAM_SPAN=1 (read per plan: tests switch it in-process).
+        const char* span_env = getenv("NFISAM_SPAN");
+        const bool span_on = span_env != nullptr && span_env[0] == '1';
+        if (span_on && p->exec_p != nullptr && n_cliques == 1 && p->val.empty() && L == 1 && (use_graph & 2) == 0 && p->max_D <= SPAN_MAX_D &&
+            cfg->max_iters > p->chunk && cfg->average_window > 0) {
+            const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
+            hipError_t es = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
+            int ss = NFISAM_ERR_LAUNCH;
+            if (es == hipSuccess) {
+                ss = enqueue_grad(p->dev, single, n_cliques, p->max_n, p->max_D, K, H, B, L, p->cfg.max_iters, 0, p->cap, &p->cfg, p->host.data(),
+                                  0, 1, false, p->cfg.max_iters, p->chunk, p->hst_dev);
+                if (ss == NFISAM_OK) {
+                    AdamArgs ad;
+                    fill_adam_args(ad, p->dev, single, n_cliques, p->max_n, p->max_D, K, H, L, &p->cfg);
+                    ad.close_chunk = p->chunk;
+                    ad.span = 1;
+                    ad.mirror = p->hst_dev;
+                    const size_t Pmax = (size_t)L * kcount(p->max_D, K, H);
+                    ad.few_copies = ((p->max_n + ad.slab - 1) / ad.slab <= 8) ? 1 : 0;
+                    int ablocks = ad.few_copies ? (int)((Pmax + 255) / 256) : (int)((Pmax + 31) / 32);
+                    if (ablocks < 1) ablocks = 1;
+                    if (ablocks > 1024) ablocks = 1024;
+                    hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, p->cap, ad);
+                    hipLaunchKernelGGL(nsf_span_close_kernel, dim3(n_cliques), dim3(64), 0, p->cap, ad);
+                    if (hipGetLastError() != hipSuccess) ss = NFISAM_ERR_LAUNCH;
+                }
+                es = hipStreamEndCapture(p->cap, &p->graph_s);
+            }
+            if (es == hipSuccess && ss == NFISAM_OK) es = hipGraphInstantiate(&p->exec_s, p->graph_s, nullptr, nullptr, 0);
+            if (getenv("NFISAM_SPAN_DEBUG") != nullptr)
+                fprintf(stderr, "nfisam: window-spanning graph of a plan (n %d, D %d, chunk %d, max_iters %d): capture %d, launcher %d\n", p->max_n, p->max_D,
+                        p->chunk, (int)cfg->max_iters, (int)es, ss);
+            if (es != hipSuccess || ss != NFISAM_OK) {             // (not an error of the plan: it keeps to one launch per chunk)
+                if (p->exec_s) { (void)hipGraphExecDestroy(p->exec_s); p->exec_s = nullptr; }
+                if (p->graph_s) { (void)hipGraphDestroy(p->graph_s); p->graph_s = nullptr; }
+                (void)hipGetLastError();
+            }
+        }
     }
     *out = p;
     return NFISAM_OK;
@@ -1364,6 +1376,14 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     __atomic_thread_fence(__ATOMIC_RELEASE);
     const int total_chunks = (p->cfg.max_iters + p->chunk - 1) / p->chunk;
     int launched = 0, closed = 0, status = NFISAM_OK;
+    // the whole run as ONE window-spanning launch (plan_create_impl): every window's bookkeeping inside it publishes the mirror as a
+    // chunk's bookkeeping kernel would, so the loop below simply has all its chunks "launched"
+    const bool span = persist && p->exec_s != nullptr && total_chunks > 1;
+    if (span) {
+        const hipError_t e = hipGraphLaunch(p->exec_s, work);
+        if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }
+        launched = total_chunks;
+    }
     auto launch_chunk = [&]() -> int {
         const int left = p->cfg.max_iters - launched * p->chunk;
         const int todo = left < p->chunk ? left : p->chunk;       // a final partial chunk is enqueued eagerly
@@ -1396,7 +1416,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     // (a chunk behind an early stop is ~chunk empty launches), so the GPU never waits for the host between chunks.
     // NFISAM_RUN_AHEAD=0 restores launch - wait - launch.
     static const bool run_ahead = !(getenv("NFISAM_RUN_AHEAD") != nullptr && getenv("NFISAM_RUN_AHEAD")[0] == '0');
-    if (total_chunks > 0) {
+    if (total_chunks > 0 && !span) {
         int rc = launch_chunk();
         if (rc) return fail(rc);
     }
@@ -1426,7 +1446,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
             if (rc) return fail(rc);
         }
     }
-    p->ahead = closed < launched;      // an enqueued chunk behind the stop: empty launches still draining on `work`
+    p->ahead = closed < launched || span;      // an enqueued chunk behind the stop: empty launches still draining on `work` (span: its closing kernels)
     if (total_chunks == 0) {           // max_iters = 0: report the state as it is
         HIP_TRY(hipMemcpyAsync(p->hst, p->host[0].state, sizeof(nfisam_train_state), hipMemcpyDeviceToHost, work));
         for (int c = 1; c < p->n_cliques; ++c)

@@ -21,6 +21,7 @@
 #include "nsf_host.h"
 #include "nsf_cond_mfma.h"
 #include "nsf_half.h"
+#include "nsf_bookkeep.h"
 
 #ifndef NSF_UNIT
 #error "compile with -DNSF_UNIT=<unit index> (see nsf_units.h)"
@@ -635,6 +636,11 @@ __device__ __forceinline__ void lds_rows_store(unsigned lane_addr, const float (
         lds_rows_store<ROW0 + 1, N - 1, SRC0 + 1, NSRC>(lane_addr, src);
     }
 }
+
+// The bookkeeping of a window-spanning launch's window (nsf_bookkeep.h) as a CALL: inlined into the training kernel its ~60
+// registers would be live next to everything the two-wave builds keep around their loop (54-84 VGPRs spilled, some of them in the
+// loop); as a call the caller's live registers are saved around it once per window, where it does not matter.
+__device__ __attribute__((noinline)) void bookkeep_window(const BookArgs* b) { bookkeep_body(*b); }
 
 // =============================================================================================
 // dim-major training kernel (L == 1, NLL): ONE WAVE = ONE DIM x T TILES, a block = W waves of ONE (clique, dim).
@@ -1892,14 +1898,24 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             // SAME launch -- every word goes out with its tag (the iteration's number in the run) as an 8-byte pair, by
             // agent-scope (sc1) write-through stores that nobody waits for: the readers poll the tags themselves.
             // The chunk's LAST copy is read by the next kernel (nsf_adam_kernel, close_chunk): the plain layout.
-            if (PERSIST && it + 1 < AF(persist_iters)) {
+            // (window-spanning launch, ROOMY builds: an iteration that ends a window may be the run's last -- the rule is evaluated
+            //  behind it -- so it leaves BOTH layouts; an iteration that exhausts the budget leaves the plain one only)
+            bool more_ = PERSIST && it + 1 < AF(persist_iters), plain_ = !more_;
+            if constexpr (ROOMY) {
+                const int sw_ = AF(span_window);
+                if (sw_ > 0) {
+                    const int done_ = st_step + it + 1;
+                    if (done_ >= AF(max_iters)) more_ = false;
+                    plain_ = !more_ || (done_ % sw_) == 0;
+                }
+            }
+            if (more_) {
                 const float tagf = __uint_as_float((uint32_t)(st_step + it + 1));
                 gfloat* dst = tg0 + (size_t)par * tg_set + (size_t)bx * 2 * gstride + 2 * (size_t)(((i == 0) ? 0 : LY::off(i)) + 4 * e);
                 const f32x4 lo = {sum.x, tagf, sum.y, tagf}, hi = {sum.z, tagf, sum.w, tagf};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(dst), "v"(lo), "v"(hi) : "memory");
-            } else {
-                Gc[e] = sum;
             }
+            if (plain_) Gc[e] = sum;
         }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 2
         STAMP(12);
@@ -1954,6 +1970,91 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                                                 ((((bx << ws) + w) * 7 + i * 13) & (LOSS_SLOTS - 1))]
                                       : (gfloat*)AF(loss_sum);
         if (dst != nullptr) gsink(dst, tot, false);
+    }
+    // ---- window-spanning launch (round 6; two-wave builds): the clique's blocks close the window THEMSELVES ---------------------
+    // One launch runs the fit's windows back to back: a 50-iteration chunk of a real fit is 339 us of launch + ~36 us of fixed cost
+    // (the launch's cold first iteration and drain, the gap between two graph launches, the closing Adam and bookkeeping kernels).
+    // At a window's end every wave waits for its stores and the loss atomic to be acknowledged, the block passes a barrier, ONE lane
+    // takes a ticket at a counter of the clique's workspace; the block whose ticket is the window's last runs the bookkeeping
+    // (nsf_bookkeep.h: the code of nsf_bookkeep_kernel -- loss record, stop rule, step, the host's mirror) behind an agent-scope
+    // acquire, and publishes the window's number with the stop bit; everybody polls that word and either goes on to the next
+    // window or leaves.  (MI355X_MICROARCH.md, Valid forms: sc1 / atomic payload, vmcnt(0) in every storing wave, workgroup
+    // barrier, one lane's counter add; the last arriver, told by the value its add returned, reads behind an acquire.)
+    if constexpr (ROOMY) {
+        const int sw_ = AF(span_window);
+        if (sw_ > 0) {
+            const int done_ = st_step + it + 1;                           // iterations of the run this block has finished
+            const bool budget_end = done_ >= AF(max_iters) || it + 1 >= AF(persist_iters);
+            if ((done_ % sw_) == 0 || budget_end) {
+                unsigned* words = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS);
+                const unsigned win_no = (unsigned)((it + sw_) / sw_);     // windows of this launch closed so far, this one included
+                const unsigned total = (unsigned)((int)cpe->D * members);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(&words[SPAN_WORD_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(volatile int*)&smem[2] = (old + 1u == total * win_no) ? 1 : 0;
+                }
+                __syncthreads();
+                if (*(volatile int*)&smem[2] != 0) {                      // (block-uniform) the clique's last block of this window
+                    if (threadIdx.x == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+                    BookArgs bk;
+                    bk.ring = (float*)ring; bk.iter_loss = cpe->iter_loss; bk.st = (nfisam_train_state*)cpe->state;
+                    bk.mirror = nullptr;                                   // (published below, BEHIND the decision: off the clique's critical path)
+                    bk.n = n; bk.D = (int)cpe->D; bk.chunk = sw_; bk.zero_counters = 0;
+                    bk.cfg.lr = AF(adam.lr); bk.cfg.beta1 = AF(adam.beta1); bk.cfg.beta2 = AF(adam.beta2); bk.cfg.eps = AF(adam.eps);
+                    bk.cfg.max_iters = AF(adam.max_iters); bk.cfg.average_window = AF(adam.average_window);
+                    bk.cfg.loss_delta_tol = AF(adam.loss_delta_tol); bk.cfg.reserved = 0;
+                    bookkeep_window(&bk);
+                    nfisam_train_state* sp = (nfisam_train_state*)cpe->state;
+                    int stop_now = 0;
+                    if (threadIdx.x == 0) {
+                        stop_now = sp->stop;                              // (this thread wrote it in the body)
+                        // The decision goes out FIRST: the other blocks need nothing else of what this block wrote (the loss
+                        // record, the state and the zeroed ring rows are next read by the block that closes the NEXT window, which
+                        // takes its ticket behind this block's next one, i.e. behind the release fence below).
+                        __hip_atomic_store(&words[SPAN_WORD_DECISION], (win_no << 1) | (stop_now != 0 ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        words[SPAN_WORD_LAST_T] = (unsigned)done_;        // (for the closing Adam kernel: the update it applies is number done_,
+                        words[SPAN_WORD_LAST_PARITY] = (unsigned)(it & 1);   //  its copies and source state sit in the buffers of this parity)
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the body are acknowledged
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        nfisam_train_state* mir = AF(span_mirror);
+                        if (mir != nullptr) {                             // the host's mirror, as nsf_bookkeep.h publishes it
+                            nfisam_train_state* m = mir + by;
+                            const int seq = __hip_atomic_load(&m->reserved[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+                            m->step = sp->step; m->stop = stop_now; m->have_avg = sp->have_avg; m->loss_avg = sp->loss_avg; m->domain_err = sp->domain_err;
+                            m->reserved[1] = sp->reserved[1];
+                            m->reserved[2] = sp->reserved[2];
+                            __hip_atomic_store(&m->reserved[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
+                }
+                if (threadIdx.x == 0) {
+                    unsigned spins = 0, dec = 0u;
+                    for (;;) {
+                        dec = __hip_atomic_load(&words[SPAN_WORD_DECISION], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((dec >> 1) == win_no) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << (AF(persist_spins) + 5))) {   // a member of the clique never arrived: leave, loudly (STALL)
+                            __hip_atomic_fetch_or(&words[i], 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dec = 1u;
+                            break;
+                        }
+                    }
+                    *(volatile int*)&smem[3] = (int)(dec & 1u);
+                }
+                __syncthreads();
+                if (*(volatile int*)&smem[3] != 0 || budget_end) break;
+            }
+        }
     }
   }
     if constexpr (!PERSIST) {
@@ -3645,6 +3746,8 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
             if (persist && W == 4 && !spl && lone_lean && real_blocks <= 256) lean = lean_launch_fits<KK, HH, true>(real_blocks, max_D);
         }
         if constexpr (lean_plain_v<KK, HH>) { if (!persist && W == 4 && !spl) lean = lean_launch_fits<KK, HH, false>(real_blocks, max_D); }
+        // a window-spanning launch closes its windows in the kernel: that code exists in the two-wave builds (nsf_train1_kernel: ROOMY)
+        if (a.span_window > 0 && !(persist && (spl || lean) && W == 4 && max_D <= SPAN_MAX_D && n_cliques == 1)) return NFISAM_ERR_ARG;
         const bool wide = persist && gx > 8;                   // groups of 9 .. 16 blocks (n > 2048): the WIDE instantiation
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
         if constexpr (half_kh) {

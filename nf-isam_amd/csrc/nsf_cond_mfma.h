@@ -401,7 +401,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
         const int ia = j0 + ca, ib = j0 + cb;
         uint32_t da = map[ca], db = map[cb];
         float ta, tb, ma, va, mb, vb;
-        float ga[8], gb[8];
+        float ga[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (a pass that gives up leaves them unset)
         if (!pending) {                                        // launch-uniform per iteration: the chunk's first iteration
             ta = t_src[ia]; tb = t_src[ib];
             ma = fa.m_src[ia]; va = fa.v_src[ia];
@@ -464,7 +464,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_wide(float* lds0, const 
             }
         }
         STG_STAMP(1, ga[0]);
-        if (pending) {
+        if (pending && !gave_up) {                             // (a thread that gave up has no gradient sum -- nothing is applied or recorded)
             FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
             sum_order.copies = fa.copies < 8 ? fa.copies : 8;  // (more than eight copies: the eight lane partials)
             adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
@@ -653,7 +653,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_split_wide(float* lds0, 
             continue;
         }
         float ta = fa.keep[q], ma = fa.keep[fa.kstride + q], va = fa.keep[2 * fa.kstride + q];
-        float ga[8];
+        float ga[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int passes = fa.copies > 8 ? 2 : 1;                    // (more than eight copies: two passes, lane-partial order -- see stage_cond_panel_persist)
         for (int pass = 0; pass < passes && !gave_up; ++pass) {
         const int c0 = 8 * pass;
@@ -686,6 +686,7 @@ __device__ __forceinline__ int stage_cond_panel_persist_split_wide(float* lds0, 
             if (gave_up || look_again(spins)) { gave_up = 1; break; }
         }
         }
+        if (gave_up) break;                                          // (no gradient sum -- nothing is applied, recorded or published)
         FusedAdam sum_order;
         sum_order.copies = fa.copies < 8 ? fa.copies : 8;
         adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);

@@ -681,7 +681,7 @@ static void fill_adam_args(AdamArgs& ad, const nfisam_clique* dev_cliques, const
 
 // The chunk-persistent form of the dim-major kernel (nsf_unit.hip: nsf_train1_kernel<K, H, true>) needs every block of the
 // launch resident at once: blocks spin at their group's barrier, a member that waits for a CU held by spinning blocks
-// would never arrive (the kernel gives up after 2^22 polls and the run ends with NFISAM_ERR_STALL -- loud, but a lost fit).
+// would never arrive (the kernel gives up after 2^15 looks -- tens of milliseconds, NFISAM_PERSIST_SPINS -- and the run ends with NFISAM_ERR_STALL: loud, but a lost fit).
 // One 4-wave block per (clique, dim, 256 particles); one barrier counter per dim: D <= 64.  How many blocks the device holds
 // is ASKED, not assumed: hipOccupancyMaxActiveBlocksPerMultiprocessor for the launch's LDS size x the device's compute units
 // (MI355X: H <= 8 compiles to three waves per SIMD = three blocks per CU while the four wave tiles + panel stay within
@@ -777,20 +777,20 @@ static bool device_is_quiet(long blocks, long places) {
     static const bool on = !(getenv("NFISAM_PERSIST_PROBE") != nullptr && getenv("NFISAM_PERSIST_PROBE")[0] == '0');
     if (!on || blocks < 1 || places < 1) return true;
     static std::mutex mu;
-    struct Seen { int dev; long blocks; double at; bool quiet; };
+    struct Seen { int dev; long blocks; long per_cu; double at; bool quiet; };   // (an answer is reused for the SAME footprint only)
     static std::vector<Seen> seen;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess) return true;
     const double now = mono_seconds();
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (const Seen& q : seen)
-            if (q.dev == dev && now - q.at < 0.5 && (q.quiet ? q.blocks >= blocks : q.blocks <= blocks)) return q.quiet;
-    }
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return true;
     const long per_cu = places / prop.multiProcessorCount;
     if (per_cu < 1) return true;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Seen& q : seen)
+            if (q.dev == dev && q.per_cu == per_cu && now - q.at < 0.5 && (q.quiet ? q.blocks >= blocks : q.blocks <= blocks)) return q.quiet;
+    }
     // LDS per block such that per_cu blocks fit a CU's 160 KB and per_cu + 1 do not
     size_t lds = (size_t)(160 * 1024) / (size_t)(per_cu + 1) + 1024;
     if (lds > (size_t)(160 * 1024) / (size_t)per_cu) lds = (size_t)(160 * 1024) / (size_t)per_cu;
@@ -821,7 +821,7 @@ static bool device_is_quiet(long blocks, long places) {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t q = 0; q < seen.size();)
         if (seen[q].dev == dev && now - seen[q].at >= 0.5) seen.erase(seen.begin() + (long)q); else ++q;
-    seen.push_back(Seen{dev, blocks, now, quiet});
+    seen.push_back(Seen{dev, blocks, per_cu, now, quiet});
     return quiet;
 }
 

@@ -376,6 +376,186 @@ __device__ __forceinline__ int stage_cond_panel_persist(float* lds0, const float
     return gave_up ? 2 : 0;
 }
 
+// The same staging, ONE parameter per thread (round 6: blocks launched with four helper waves -- nsf_train1_kernel, two-wave
+// builds of a lone clique: the block has a CU to itself, so waves 4 .. 7 cost nothing while waves 0 .. 3 compute and halve every
+// thread's share of the exchange, which is bound by its instructions; up to eight copies).  The same loads, the same sums in the
+// same order, the same update per parameter: which thread applies it does not show in the bits.
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist_solo(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                             int i, int tid, int NT, int st_step, int st_stop, int n, int iter) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    int gave_up = 0;
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    STG_T0();
+    for (int base = 0; base < nj; base += NT) {
+        const int ja = base + tid;
+        const int ca = (ja < nj ? ja : 0);
+        const int ia = j0 + ca;
+        uint32_t da = map[ca];
+        float ta, ma, va;
+        float ga[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!pending) {
+            ta = t_src[ia];
+            ma = fa.m_src[ia]; va = fa.v_src[ia];
+            asm volatile("" : "+v"(ta), "+v"(ma), "+v"(va), "+v"(da));
+        } else {
+            ta = fa.keep[ca]; ma = fa.keep[fa.kstride + ca]; va = fa.keep[2 * fa.kstride + ca];
+            unsigned spins = 0;
+            for (;;) {
+                unsigned long long qa[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) qa[c] = tagged_pair(fa.tagged, c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ia);
+                if (base == 0 && spins == 0u)
+                    fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+                if (spins == 0u) STG_STAMP(0, fa.kc.step_size);
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag;
+                    ga[c] = __uint_as_float((uint32_t)qa[c]);
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+#if defined(NSF_STAMPS)
+                ++fa.looks;
+#endif
+                if ((spins & 63u) == 0u) {
+                    const bool timeout = spins > (1u << fa.spin_log2);
+                    if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) { gave_up = 1; break; }
+                }
+            }
+        }
+        STG_STAMP(1, ga[0]);
+        if (pending && !gave_up) {
+            FusedAdam sum_order;                               // (the summation order of nsf_adam_kernel / stage_cond_panel)
+            sum_order.copies = fa.copies;
+            adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+            if (fa.t_dst != nullptr && ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
+        }
+        STG_STAMP(2, ta);
+        if (ja < nj) {
+            fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
+            lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
+        }
+    }
+    if (i > 0 && !pending) {
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    { float d_ = lds0[4]; STG_STAMP(3, d_); }
+    return gave_up ? 2 : 0;
+}
+
+// ... and its form for groups of nine to sixteen blocks: two passes, nsf_adam_kernel's lane-partial order (see stage_cond_panel_persist_wide)
+template <int K, int H>
+__device__ __forceinline__ int stage_cond_panel_persist_solo_wide(float* lds0, const float* theta_generic, PersistAdam& fa, const uint32_t* map_generic,
+                                                                  int i, int tid, int NT, int st_step, int st_stop, int n, int iter) {
+    using CP = CondPanel<K, H>;
+    using LY = Layout<K, H>;
+    typedef const __attribute__((address_space(1))) float* gp;
+    typedef const __attribute__((address_space(1))) uint32_t* gu;
+    gp t_src = (gp)theta_generic;
+    constexpr int PoP = CP::PoP;
+    const int j0 = (i == 0) ? 0 : LY::off(i), nj = (i == 0) ? PoP : LY::block(i);
+    gu map = (gu)map_generic + j0;
+    const bool pending = fa.tagged != nullptr;
+    int gave_up = 0;
+    if (st_stop != 0 || st_step + iter >= fa.max_iters) return 1;    // block-uniform
+    STG_T0();
+    for (int base = 0; base < nj; base += NT) {
+        const int ja = base + tid;
+        const int ca = (ja < nj ? ja : 0);
+        const int ia = j0 + ca;
+        uint32_t da = map[ca];
+        float ta, ma, va;
+        float ga[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!pending) {
+            ta = t_src[ia];
+            ma = fa.m_src[ia]; va = fa.v_src[ia];
+            asm volatile("" : "+v"(ta), "+v"(ma), "+v"(va), "+v"(da));
+        } else {
+            ta = fa.keep[ca]; ma = fa.keep[fa.kstride + ca]; va = fa.keep[2 * fa.kstride + ca];
+            const int passes = fa.copies > 8 ? 2 : 1;          // block-uniform
+            for (int pass = 0; pass < passes && !gave_up; ++pass) {
+                const int c0 = 8 * pass;
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned long long qa[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) qa[c] = tagged_pair(fa.tagged, c0 + c, fa.copies, (unsigned)fa.cstride * 4u, 8u * (unsigned)ia);
+                    if (base == 0 && spins == 0u && pass == 0)
+                        fa.kc = adam_coef(fa.lr, fa.beta1, fa.beta2, fa.eps, fa.log_b1, fa.log_b2, st_step + iter, n);
+                    if (spins == 0u && pass == 0) STG_STAMP(0, fa.kc.step_size);
+                    bool ok = true;
+                    float la[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        ok = ok && (uint32_t)(qa[c] >> 32) == fa.tag;
+                        la[c] = __uint_as_float((uint32_t)qa[c]);
+                    }
+                    if (ok) {
+                        if (pass == 0) {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) ga[c] = la[c];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c)
+                                if (8 + c < fa.copies) ga[c] += la[c];
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+#if defined(NSF_STAMPS)
+                    ++fa.looks;
+#endif
+                    if ((spins & 63u) == 0u) {
+                        const bool timeout = spins > (1u << fa.spin_log2);
+                        if (timeout) __hip_atomic_fetch_or(fa.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (timeout || (__hip_atomic_load(fa.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0u) { gave_up = 1; break; }
+                    }
+                }
+            }
+        }
+        STG_STAMP(1, ga[0]);
+        if (pending && !gave_up) {
+            FusedAdam sum_order;
+            sum_order.copies = fa.copies < 8 ? fa.copies : 8;  // (more than eight copies: the eight lane partials)
+            adam_update(fa.kc, fused_sum_grads(sum_order, ga), ma, va, ta);
+            if (fa.t_dst != nullptr && ja < nj) { fa.t_dst[ia] = ta; fa.m_dst[ia] = ma; fa.v_dst[ia] = va; }
+        }
+        STG_STAMP(2, ta);
+        if (ja < nj) {
+            fa.keep[ca] = ta; fa.keep[fa.kstride + ca] = ma; fa.keep[2 * fa.kstride + ca] = va;
+            lds0[da & 0x7fffu] = (da & PANEL_SCALED) ? ta * kTanhScale : ta; lds0[da >> 16] = ta;
+        }
+    }
+    if (i > 0 && !pending) {
+        const int s0 = CP::s0_of(i);
+        const int npad = (((i + 7) & ~7) - i) * H;
+        for (int e = tid; e < npad; e += NT) {
+            const int k = i + e / H, j = e % H;
+            lds0[PANEL_BASE + CP::oW0T + j * s0 + k] = 0.0f;
+        }
+    }
+    { float d_ = lds0[4]; STG_STAMP(3, d_); }
+    return gave_up ? 2 : 0;
+}
+
 // The same staging for groups of MORE THAN EIGHT blocks (n > 2048: up to sixteen copies, round 5) -- a second instantiation of the
 // kernel (template flag WIDE), so that the code of the common case stays what round 4 measured (the two-pass loop in ONE function
 // cost the Plaza clique 3.7 % and C3 2.4 %, scripts/ab.py, one box).

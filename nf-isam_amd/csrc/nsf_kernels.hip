@@ -773,6 +773,21 @@ __global__ void __launch_bounds__(256) nsf_coresidency_probe_kernel(unsigned* ct
 }
 // -> true: `blocks` blocks of `per_cu` per compute unit are resident at once right now (or the probe is switched off / failed to run:
 // the occupancy answer stands)
+// compute units of a device, asked once per device (hipGetDeviceProperties is not cheap and plans are created by the hundred)
+static int cu_count(int dev) {
+    static std::mutex mu;
+    static int cus[64] = {};
+    if (dev < 0 || dev >= 64) return 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (cus[dev] != 0) return cus[dev] > 0 ? cus[dev] : 0;
+    }
+    hipDeviceProp_t prop;
+    const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : -1;
+    std::lock_guard<std::mutex> lk(mu);
+    cus[dev] = n;
+    return n > 0 ? n : 0;
+}
 static bool device_is_quiet(long blocks, long places) {
     static const bool on = !(getenv("NFISAM_PERSIST_PROBE") != nullptr && getenv("NFISAM_PERSIST_PROBE")[0] == '0');
     if (!on || blocks < 1 || places < 1) return true;
@@ -780,11 +795,11 @@ static bool device_is_quiet(long blocks, long places) {
     struct Seen { int dev; long blocks; long per_cu; double at; bool quiet; };   // (an answer is reused for the SAME footprint only)
     static std::vector<Seen> seen;
     int dev = 0;
-    hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess) return true;
     const double now = mono_seconds();
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return true;
-    const long per_cu = places / prop.multiProcessorCount;
+    const int cus = cu_count(dev);
+    if (cus < 1) return true;
+    const long per_cu = places / cus;
     if (per_cu < 1) return true;
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -1159,6 +1174,12 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
         // probe before persisting (device_is_quiet): is the device ours right now?  (outside the capture below)
         // (not while a hand-stepped conveyor of this process fills the machine -- slam.ReplicaNFiSAM creates plans by the hundred
         //  next to one: the probe's blocks would queue behind its chunks, and no run takes the persistent graph then anyway)
+        // (a launch of few blocks may take a two-wave build with helper waves -- nsf_unit.hip: unit_train1 -- and then a whole CU per
+        //  block: asked for at that footprint)
+        if (can_persist && p_blocks <= 240) {
+            int dv = 0;
+            if (hipGetDevice(&dv) == hipSuccess && cu_count(dv) > 0 && p_places > cu_count(dv)) p_places = cu_count(dv);
+        }
         if (can_persist && g_hand_stepped.load() == 0 && !device_is_quiet(p_blocks, p_places)) can_persist = false;
         for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
         const bool persist = pass == 1;

@@ -110,7 +110,7 @@ __device__ __forceinline__ unsigned long long g_stamps_t0(int) { return 0ull; }
         __builtin_amdgcn_sched_barrier(0);                                                          \
         unsigned long long t_;                                                                      \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(va), "+v"(vb)::"memory"); \
-        if (lane == 0 && sprev_ != 0ull) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + ((id) & 15)], (unsigned)(t_ - sprev_)); \
+        if (lane == 0 && sprev_ != 0ull && w < 4) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + ((id) & 15)], (unsigned)(t_ - sprev_)); \
         sprev_ = t_;                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
@@ -1300,7 +1300,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     STAMP(0);
 #endif
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
-    if (lane0 < 16) smem[PANEL_BASE - 64 + w * 16 + lane0] = 0.0f;
+    if (lane0 < 16 && w < 4) smem[PANEL_BASE - 64 + w * 16 + lane0] = 0.0f;
 #endif
     f32x4 cacc[NT], c1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f};
     f32x4 cb2[NT], cb1 = {0.f, 0.f, 0.f, 0.f};                 // WIDE_H only
@@ -1389,7 +1389,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const bool merged = (i <= 16 - (H + 1));                  // the two last gradient GEMMs share one operand tile (see phase B)
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
     const int members = (((n + (TP << ts) - 1) >> (PSH + ts)) + W - 1) >> ws;     // blocks of this (clique, dim) group with a tile
-    const bool has_tile = p0 < n;
+    const bool has_tile = p0 < n && w < W;                    // (waves W .. : helper waves of a two-wave build, staging only)
     const unsigned stg_lane = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(stg + lane);   // LDS byte address
     const int r16 = lane & 15, kq = lane >> 4;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
@@ -1491,15 +1491,21 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                         rc_ = stage_cond_panel_persist_split<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it,
                                                                    bx, tg0 + 2 * tg_set);
                 } else {
-                    if constexpr (WIDE)
-                        rc_ = stage_cond_panel_persist_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                    if constexpr (WIDE) {
+                        if (ROOMY && (int)blockDim.x > (64 << ws))    // (helper waves: one parameter per thread)
+                            rc_ = stage_cond_panel_persist_solo_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                        else
+                            rc_ = stage_cond_panel_persist_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
+                    }
+                    else if (ROOMY && (int)blockDim.x > (64 << ws))     // (helper waves: one parameter per thread)
+                        rc_ = stage_cond_panel_persist_solo<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                     else
                         rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                 }
                 if (rc_ == 1) return;
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
                 { float d0_ = smem[PANEL_BASE], d1_ = (float)rc_; PSTAMP(11, d0_, d1_); }   // the staging: loads, looks, Adam, LDS stores
-                if (lane == 0) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + 13], pa_.looks);
+                if (lane == 0 && w < 4) atomicAdd((unsigned*)&smem[PANEL_BASE - 64 + w * 16 + 13], pa_.looks);
 #endif
                 // A thread that gave up (2^persist_spins looks at copies that never came: a member of the group is not on the
                 // machine, somebody else holds its place) has raised the group's abort flag; the block leaves as one, the
@@ -1830,7 +1836,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     if (slab) G += (size_t)bx * gstride;
     gfloat* Gb = G + LY::off(i > 0 ? i : 1);
     const int members = (((n + (TP << ts) - 1) >> (PSH + ts)) + W - 1) >> ws;
-    const bool has_tile = (((bx << ws) + w) << (PSH + ts)) < n;
+    const bool has_tile = (((bx << ws) + w) << (PSH + ts)) < n && w < W;
     if (slab) {
         // One copy per BLOCK: every wave lays its fragment out in parameter order in its own (now free) rows, 16 bytes per
         // store (the accumulators hold four consecutive parameters), the block's threads add the fragments in wave order
@@ -1873,7 +1879,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
         // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
         {
             const float wtot = wave_sum(lossv);
-            if (lane_e == 0) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row
+            if (lane_e == 0 && w < W) xt[64] = has_tile ? wtot : 0.0f;   // a padding word of the tile's first row (helper waves have no rows)
         }
         __syncthreads();                                      // waves without a tile left before the panel barrier
         const int waves_c = (n + (TP << ts) - 1) >> (PSH + ts);
@@ -2064,7 +2070,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     }
   }
 #if defined(NSF_STAMPS) && NSF_STAMPS == 3 && NSF_UNIT == 0
-    if (STAMP_SEL && lane0 < 16) g_stamps[STAMP_SLOT * 32 + 16 + lane0] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane0];
+    if (STAMP_SEL && lane0 < 16 && w < 4) g_stamps[STAMP_SLOT * 32 + 16 + lane0] = (unsigned long long)((unsigned*)smem)[PANEL_BASE - 64 + w * 16 + lane0];
 #endif
 }
 #undef AF
@@ -3749,6 +3755,11 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         // a window-spanning launch closes its windows in the kernel: that code exists in the two-wave builds (nsf_train1_kernel: ROOMY)
         if (a.span_window > 0 && !(persist && (spl || lean) && W == 4 && max_D <= SPAN_MAX_D && n_cliques == 1)) return NFISAM_ERR_ARG;
         const bool wide = persist && gx > 8;                   // groups of 9 .. 16 blocks (n > 2048): the WIDE instantiation
+        // helper waves (round 6): a two-wave build whose blocks get a CU each is launched with eight waves per block -- waves 4 .. 7
+        // own no particles and take part in the staging only (one parameter per thread: stage_cond_panel_persist_solo)
+        static const bool helpers_on = !(getenv("NFISAM_HELPERS") != nullptr && getenv("NFISAM_HELPERS")[0] == '0');
+        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? 240 : 224) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
+        const int BW = helpers ? 2 * W : W;                    // waves per block
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
         if constexpr (half_kh) {
             if (spl) {
@@ -3804,10 +3815,10 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if constexpr (half_kh) {
             if (gz > 0 && spl) {
                 if (persist && wide)
-                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                        dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
                 else if (persist)
-                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                        dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
                 else
                     hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, false, false, false, true>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,
@@ -3819,10 +3830,10 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         if constexpr (lean_persist_inst_v<KK, HH>) {
             if (gz > 0 && persist && lean) {
                 if (wide)
-                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                        dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
                 else
-                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+                    hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                        dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
                 launched = true;
             }

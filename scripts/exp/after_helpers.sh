@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/gpu_tests.txt
+bash scripts/exp/headline.sh > /dev/null 2>&1
+python scripts/run_plaza1.py 1000 gpurun_out/plaza1_a.json 2>&1 | grep -v amdgpu.ids | tail -2 > gpurun_out/plaza_now.txt
+python scripts/run_plaza1.py 1000 gpurun_out/plaza1_b.json 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/plaza_now.txt
+cat gpurun_out/gpu_tests.txt gpurun_out/headline.txt gpurun_out/plaza_now.txt

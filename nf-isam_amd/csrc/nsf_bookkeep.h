@@ -26,8 +26,10 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int PER_WAVE = LOSS_RING / 4;
     float part[PER_WAVE];
+    static_assert(LOSS_SLOTS == 128, "a lane takes slots l and l + 64 of a row");
 #pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane];     // ring row w + 4k
+    for (int k = 0; k < PER_WAVE; ++k)                                                       // ring row w + 4k
+        part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane] + ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane];   // (launches of up to 128 blocks use the lower half only: x + 0)
     // the group-barrier counters of the chunk-persistent training kernel (one per dim; nsf_unit.hip: bits 0-22 arrivals,
     // 23-30 the XCC ids the group's blocks ran on, 31 the group's abort flag): looked at, then zeroed for the next chunk
     int stalled = 0, xcd_span = 0;
@@ -59,7 +61,7 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int it = ((w + 4 * k) - s0) & (LOSS_RING - 1);
-            if (it < cnt) ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f;                     // wave-uniform
+            if (it < cnt) { ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f; ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane] = 0.0f; }   // wave-uniform
         }
         if (lane < PER_WAVE) {
             const int it = ((w + 4 * lane) - s0) & (LOSS_RING - 1);

@@ -36,7 +36,7 @@ constexpr int XS = 66;            // LDS row stride (floats) of every [feature][
 // Per-iteration loss sums live behind the gradient slabs in the kgrad workspace: a ring of LOSS_RING
 // iterations x LOSS_SLOTS words (spread so that hundreds of waves do not serialise on one address).  The
 // bookkeeping kernel that closes a chunk of iterations consumes and clears them.
-constexpr int LOSS_RING = 128, LOSS_SLOTS = 64;
+constexpr int LOSS_RING = 128, LOSS_SLOTS = 128;   // (round 6: 128 slots -- a lone clique of 240 blocks, two per slot, still leaves an order-free sum)
 constexpr int ONES_ROW = 68;       // nsf_train1_kernel: LDS words of 1.0 read as the bias column of the gradient GEMM operands
 // fused Adam (nsf_cond_mfma.h): 64 reserved words behind the loss ring, then the second set of gradient copies and the
 // second state buffer; the workspace is sized for cliques of up to this many 64-particle tiles
@@ -224,8 +224,13 @@ static inline bool half_shape(int n_cliques, int max_n, int max_D, int K, int H,
     if (H != 8 || K < 2 || hp_of(K) != 16 || L != 1 || T != 1 || max_D > 16 || max_D < 1) return false;
     const int per_block = 32 * half_waves();
     const long copies = (max_n + per_block - 1) / per_block;
-    const long most = (e != nullptr && e[0] == '2') ? PERSIST_MAX_COPIES : 8;
-    return copies <= most && (long)n_cliques * max_D * copies <= 256;
+    const long blocks = (long)n_cliques * max_D * copies;
+    // "2": also nine to sixteen copies per group (1025 .. 2048 particles).  Measured with helper waves (nsf_unit.hip: unit_train1 --
+    // at most 240 blocks, a CU each): one Plaza clique 6.71 us per iteration against 6.94 for the 64-particle family, +3 % of
+    // Plaza1's training rate -- but 240 whole-CU blocks fill seven of the eight XCDs to the last CU, so it is not the default
+    // (DESIGN.md 3.1h).  Its loss record is order-free like every other launch's (LOSS_SLOTS = 128: two blocks per slot).
+    if (e != nullptr && e[0] == '2') return copies <= PERSIST_MAX_COPIES && blocks <= 256;
+    return copies <= 8 && blocks <= 256;
 }
 // hidden widths the dim-major kernel is instantiated for (H <= 8: [ga2 | ga1] share one 16-row MFMA operand tile;
 // H = 16: one tile each and separate bias chains)

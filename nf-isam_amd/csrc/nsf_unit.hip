@@ -1088,7 +1088,7 @@ nsf_train1_plain_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_
             for (int e = lane; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
         }
         // the block's loss: the waves' sums added in wave order by ONE thread (below), then one atomic per block into a ring
-        // slot shared by at most two blocks of the clique while D x blocks <= 128 -- a sum of two floats does not depend on
+        // slot shared by at most two blocks of the clique while D x blocks <= 256 (LOSS_SLOTS = 128) -- a sum of two floats does not depend on
         // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
         {
             const float wtot = wave_sum(lossv);
@@ -1875,7 +1875,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
             for (int e = lane_e; e < (i - 15) * H; e += 64) frag[16 * H + e] = ctacc[e];     // D > 16 (rows 16..i)
         }
         // the block's loss: the waves' sums added in wave order by ONE thread (below), then one atomic per block into a ring
-        // slot shared by at most two blocks of the clique while D x blocks <= 128 -- a sum of two floats does not depend on
+        // slot shared by at most two blocks of the clique while D x blocks <= 256 (LOSS_SLOTS = 128) -- a sum of two floats does not depend on
         // their order, so the loss record is the same whichever way the launches and the waves happen to be timed
         {
             const float wtot = wave_sum(lossv);
@@ -2930,7 +2930,7 @@ __global__ void __launch_bounds__(512) nsf_train3_kernel(TrainArgs a, const uint
     STAMP(9);
     if (a.nll_mode) {
         // the block's loss: the waves' sums added in wave order by one thread, ONE atomic per block into a ring slot that two
-        // blocks share while the launch has <= 128 tiles (a sum of two floats does not depend on their order: the loss
+        // blocks share while the launch has <= 256 tiles (a sum of two floats does not depend on their order: the loss
         // record is the same however the blocks happen to be timed; a third of the atomics to drain at the kernel's end)
         __shared__ float s_wave_loss[8];
         const float tot = wave_sum(lossv);

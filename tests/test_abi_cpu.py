@@ -172,9 +172,9 @@ def test_workspace_count_covers_groups_of_up_to_sixteen_blocks():
         for D in (1, 6, 15):
             kc = nh.kparam_count(D, K, H)
             copies = (n + 255) // 256
-            need = (6 * copies + 5) * kc + 128 * 64 + 64
+            need = (6 * copies + 5) * kc + 128 * 128 + 64
             if (n + 127) // 128 <= 16:      # round 6: blocks of 128 particles (two lanes per particle, csrc/nsf_half.h), up to sixteen per group
-                need = max(need, (6 * ((n + 127) // 128) + 5) * kc + 128 * 64 + 64)
+                need = max(need, (6 * ((n + 127) // 128) + 5) * kc + 128 * 128 + 64)
             got = int(lib.nfisam_nsf_grad_workspace_count(n, D, K, H, L))
             assert got >= need, (n, D, got, need)
         now = int(lib.nfisam_nsf_grad_workspace_count(n, 6, K, H, L))

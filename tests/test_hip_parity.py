@@ -460,7 +460,7 @@ def test_large_launch_uses_atomics_and_still_matches_oracle(n):
     """> 128 tiles: single gradient buffer + float atomics (workspace is one copy).  The smaller case still
     runs the two-lanes-per-particle kernel (<= 1280 waves), the larger one the one-lane-per-particle kernel."""
     K, H, B, L, D = 9, 8, 5.0, 1, 4
-    ring = 128 * 64 + 64      # per-iteration loss sums behind the gradient copies (+ 64 reserved words)
+    ring = 128 * 128 + 64      # per-iteration loss sums behind the gradient copies (+ 64 reserved words)
     assert nh.lib().nfisam_nsf_grad_workspace_count(n, D, K, H, L) == nh.kparam_count(D, K, H) + ring
     # <= 32 tiles of 64 particles: room for the fused-Adam launches' second set of copies and second (theta | m | v), and for
     # the chunk-persistent form's two sets of tagged copies (round 6: up to sixteen 128-particle blocks per group, nsf_half.h)

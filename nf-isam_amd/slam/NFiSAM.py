@@ -18,6 +18,7 @@ path to choose.
 """
 import logging
 import time
+from collections.abc import Mapping
 from typing import List
 
 import numpy as np
@@ -48,7 +49,7 @@ class NFiSAMArgs(SolverArgs):
                  flow_iterations: int = 10, num_knots: int = 12, cuda_training: bool = False,
                  adaptive_flow_setup: bool = False, hidden_dim: int = 8, average_window=50, loss_delta_tol=1e-2,
                  training_set_frac=1.0, validation_interval=10, slower_stop_rate=2.0, data_parallel=False,
-                 training_loss_dir=None, device_simulation=True, *args, **kwargs):
+                 training_loss_dir=None, device_simulation=True, lazy_posterior=False, *args, **kwargs):
         super().__init__(elimination_method=elimination_method, posterior_sample_num=posterior_sample_num,
                          local_sample_num=local_sample_num, store_clique_samples=store_clique_samples,
                          local_sampling_method=local_sampling_method, *args, **kwargs)
@@ -72,7 +73,37 @@ class NFiSAMArgs(SolverArgs):
         # Cliques with a factor type the device simulator does not know fall back to the host.  Plaza1: the fused
         # simulator takes ~1.3 s off the 4-5 s spent outside training.
         self.device_simulation = device_simulation
+        # not in the reference: `sample_posterior` / `incremental_inference` return at once with a read-only mapping that waits for
+        # the tree walk and its device-to-host copy when it is first LOOKED AT (LazyPosterior below) -- a caller that adds the next
+        # nodes and factors and updates the graphs before it reads the samples has that host work run under the walk.
+        self.lazy_posterior = lazy_posterior
         self.tl_cnt = 0
+
+
+class LazyPosterior(Mapping):
+    """What `NFiSAM.sample_posterior` returns under `NFiSAMArgs(lazy_posterior=True)`: variable -> samples [n, dim], as the dict
+    of the synchronous call, filled in at the first access (waits for the walk's event; the copy into pinned host memory was
+    enqueued behind the walk on the same stream, so nothing later on that stream is waited for)."""
+
+    def __init__(self, handle, host, done):
+        self._handle, self._host, self._done, self._dict = handle, host, done, None
+
+    def _get(self):
+        if self._dict is None:
+            self._done.synchronize()
+            S = self._host.numpy()
+            pcol = self._handle["pcol"]
+            self._dict = {v: S[:, pcol[v]:pcol[v] + v.dim] for v in self._handle["order"]}
+            self._handle = None                    # (the models the walk read may go now)
+        return self._dict
+
+    def ready(self) -> bool:
+        return self._dict is not None or self._done.query()
+
+    def __getitem__(self, v): return self._get()[v]
+    def __iter__(self): return iter(self._get())
+    def __len__(self): return len(self._get())
+    def __contains__(self, v): return v in self._get()
 
 
 _CIRC_FLAGS = {}     # (device, circular flags as bytes) -> uint8 device tensor, immutable (NormalizingFlowModelWithSeparator._norm_dev)
@@ -618,6 +649,16 @@ class NFiSAM(FactorGraphSolver):
         wave of 64 samples walks all cliques on the device; one D2H copy at the end.  The per-clique
         device pointers are cached on the model (they do not change after training); only the column
         indices, which shift as the elimination ordering grows, are rebuilt per update."""
+        if getattr(self._args, "lazy_posterior", False):
+            handle = self.posterior_launch()
+            S = handle["S"]
+            host = torch.empty(S.shape, dtype=S.dtype, pin_memory=True)
+            host.copy_(S, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream())
+            if timer is not None:
+                timer.append(time.time() - handle["start"])       # (what the caller waited for: table assembly and launch)
+            return LazyPosterior(handle, host, done)
         return self.posterior_collect(self.posterior_launch(), timer)
 
     def posterior_launch(self):

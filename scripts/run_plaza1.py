@@ -20,7 +20,8 @@ steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(o
 args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000")), local_sample_num=2000,
                   learning_rate=.01, hidden_dim=8, cuda_training=True, elimination_method="pose_first",
                   training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50,
-                  device_simulation=os.environ.get("DEVSIM", "1") != "0")
+                  device_simulation=os.environ.get("DEVSIM", "1") != "0",
+                  lazy_posterior=os.environ.get("LAZY", "0") == "1")      # LAZY=1: the samples of update i are read under update i + 1
 replicas = int(os.environ.get("REPLICAS", "1"))
 if replicas > 1:
     # R independent runs (seeds SEED .. SEED+R-1) on one GPU, their cliques in the R slots of one batched training plan
@@ -84,6 +85,28 @@ if replicas > 1:
 solver = NFiSAM(args)
 rows = []
 t_all = time.time()
+lazy = bool(getattr(args, "lazy_posterior", False))
+pending = None                                               # LAZY=1: (row, samples, poses) of the previous update
+lazy_wait = 0.0
+
+
+rmse_seconds = [0.0]
+
+
+def rmse_of(samples, poses_):
+    t_ = time.time()
+    try:
+        return _rmse_of(samples, poses_)
+    finally:
+        rmse_seconds[0] += time.time() - t_
+
+
+def _rmse_of(samples, poses_):
+    # (one mean over the stacked xy columns: a numpy call per variable costs 0.7 s over the run)
+    err_ = np.hstack([samples[v][:, :2] for v in poses_]).mean(0).reshape(-1, 2) - np.array([truth[v][:2] for v in poses_])
+    return float(np.sqrt((err_ ** 2).sum(1).mean()))
+
+
 for i, (vs, fs) in enumerate(steps[:max_updates]):
     for v in vs: solver.add_node(v)
     for f in fs: solver.add_factor(f)
@@ -92,16 +115,23 @@ for i, (vs, fs) in enumerate(steps[:max_updates]):
     solver.update_physical_and_working_graphs(timer=timer)
     samples = solver.incremental_inference(timer=timer)
     dt = time.time() - t0
+    if pending is not None:                                  # the previous update's samples: its walk ran under this update's host work
+        t_r = time.time()
+        pending[1][pending[2][0]]                            # (first access: waits for the walk's event if it is still running)
+        lazy_wait += time.time() - t_r
+        pending[0]["rmse"] = rmse_of(pending[1], pending[2])
+        pending = None
     loss = solver._temp_training_loss
     iters = [int(np.count_nonzero(v)) for v in loss.values()]
     fit = sum(timer[2:-1:2]) if len(timer) > 2 else 0.0      # [graph, (sample, fit)*, posterior]
     samp = sum(timer[1:-1:2])
     poses_ = [v for v in solver.physical_vars if str(v.name).startswith("X")]
-    # (one mean over the stacked xy columns: a numpy call per variable costs 0.7 s over the run)
-    err_ = np.hstack([samples[v][:, :2] for v in poses_]).mean(0).reshape(-1, 2) - np.array([truth[v][:2] for v in poses_])
-    rmse_ = float(np.sqrt((err_ ** 2).sum(1).mean()))
+    last_ = i == min(len(steps), max_updates) - 1
+    rmse_ = float("nan") if (lazy and not last_) else rmse_of(samples, poses_)
     rows.append(dict(update=i, rmse=rmse_, wall=dt, graph=timer[0], sampling=samp, fitting=fit, posterior=timer[-1],
                      cliques_trained=len(iters), iterations=sum(iters), n_vars=len(solver.physical_vars)))
+    if lazy and not last_:
+        pending = (rows[-1], samples, poses_)
     if i % int(os.environ.get('EVERY', '10')) == 0 or i == min(len(steps), max_updates) - 1:
         print("update %3d: %.3f s (graph %.3f, sampling %.3f, fit %.3f [%d cliques, %d it], posterior %.3f) vars %d "
               "traj RMSE %.2f m" % (i, dt, timer[0], samp, fit, len(iters), sum(iters), timer[-1],
@@ -112,7 +142,8 @@ summary = dict(updates=len(rows), total_s=total, wall_per_update_mean=float(w.me
                wall_per_update_max=float(w.max()), fitting_total_s=float(f.sum()), training_sample_iters=float(2000 * it.sum()),
                flow_training_samples_per_s=float(2000 * it.sum() / max(f.sum(), 1e-9)),
                sampling_total_s=float(sum(r["sampling"] for r in rows)), posterior_total_s=float(sum(r["posterior"] for r in rows)),
-               graph_total_s=float(sum(r["graph"] for r in rows)))
+               graph_total_s=float(sum(r["graph"] for r in rows)), lazy_posterior=lazy, lazy_first_access_wait_s=float(lazy_wait),
+               rmse_bookkeeping_of_this_script_s=float(rmse_seconds[0]))
 print(json.dumps(summary))
 if out_json:
     json.dump(dict(summary=summary, rows=rows), open(out_json, "w"))

@@ -560,3 +560,49 @@ def test_late_posteriors_of_plaza1_match_the_reference():
             if not p >= 0.01:
                 failures.append(dict(r, rank_sum_p=p))
     assert not failures, failures
+
+
+def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_path):
+    """`NFiSAMArgs(lazy_posterior=True)` (round 6; not in the reference): `incremental_inference` returns a mapping that waits for
+    the tree walk when it is first read, so the next update's host work runs under the walk.  Same seed, same problem, same
+    kernels in the same order on the same stream: the samples of every update are EQUAL to the synchronous solver's, whether they
+    are read at once or only after the next update's graph work; the mapping behaves like the dict (keys, length, membership)."""
+    from slam.NFiSAM import LazyPosterior, NFiSAM, NFiSAMArgs
+    from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+    fx = np.load(os.path.join(GOLDEN, "pipeline_small_range.npz"), allow_pickle=False)
+    kwargs = json.loads(str(fx["arguments"]))
+    kwargs["cuda_training"] = True
+    path = _graph_path(tmp_path, "small_range", fx)
+
+    def solve(lazy, read_late):
+        random.seed(3); np.random.seed(3); torch.manual_seed(3)
+        nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
+        steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))[:4]
+        solver = NFiSAM(NFiSAMArgs(lazy_posterior=lazy, **kwargs))
+        out, pending = [], None
+        for vs, fs in steps:
+            for v in vs: solver.add_node(v)
+            for f in fs: solver.add_factor(f)
+            solver.update_physical_and_working_graphs()
+            if pending is not None:                               # (the previous update's samples, read under this update)
+                out.append({str(v.name): np.array(a) for v, a in pending.items()})
+                pending = None
+            s = solver.incremental_inference()
+            assert isinstance(s, LazyPosterior) == lazy
+            if read_late:
+                pending = s
+            else:
+                assert len(s) == len(solver.elimination_ordering) and all(v in s for v in solver.elimination_ordering)
+                out.append({str(v.name): np.array(s[v]) for v in solver.elimination_ordering})
+        if pending is not None:
+            out.append({str(v.name): np.array(a) for v, a in pending.items()})
+        return out
+
+    ref = solve(False, False)
+    for lazy, late in ((True, False), (True, True)):
+        got = solve(lazy, late)
+        assert len(got) == len(ref) == 4
+        for a, b in zip(got, ref):
+            assert a.keys() == b.keys()
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)

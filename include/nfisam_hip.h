@@ -244,8 +244,9 @@ typedef struct nfisam_clique {
     int32_t n, D;
 } nfisam_clique;
 
-/* Floats the `kgrad` workspace of a clique must hold (gradient copies + a ring of 128 x 64 per-iteration
- * loss words behind them + 64 counter words: the per-dim group barriers of the chunk-persistent training
+/* Floats the `kgrad` workspace of a clique must hold (gradient copies + a ring of 128 x 128 per-iteration
+ * loss words behind them -- ABI 1600; 128 x 64 before: a lone clique of up to 256 blocks keeps two blocks per word, an
+ * order-free sum -- + 64 counter words: the per-dim group barriers of the chunk-persistent training
  * kernel, which the library keeps zero between chunks -- the caller provides the workspace ZEROED) when the largest clique of its batch has n
  * particles: launches of <= 128 particle tiles write per-tile partial gradients with plain stores and
  * the Adam kernel sums them in tile order (no atomics); larger ones accumulate with float atomics

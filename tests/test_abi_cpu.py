@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nh.EXPORTS), declared ^ set(nh.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nfisam_abi_version() == 1500
+    assert lib.nfisam_abi_version() == 1600
 
 
 def test_struct_sizes_match_header(tmp_path):

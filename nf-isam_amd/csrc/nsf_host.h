@@ -7,6 +7,7 @@
 // parallel, which is what makes K = 2..16 x H in {4, 8, 16} affordable.  The common unit reaches a kernel unit through
 // the `NsfUnitOps` table that unit exports.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -217,6 +218,20 @@ static inline int half_waves() {
     const char* e = getenv("NFISAM_HALF_W");
     const int v = e != nullptr ? atoi(e) : 4;
     return (v == 4 || v == 8) ? v : 4;
+}
+// compute units of the current device, asked once per device and translation unit (first call OUTSIDE a stream capture:
+// unit_prepare / plan creation); 0: unknown
+static inline int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n = 0;
+        v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0 ? v : 0;
 }
 static inline bool half_shape(int n_cliques, int max_n, int max_D, int K, int H, int L, int T) {
     const char* e = getenv("NFISAM_HALF");               // read per call: tests switch families in-process

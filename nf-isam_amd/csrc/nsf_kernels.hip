@@ -1176,10 +1176,7 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
         //  next to one: the probe's blocks would queue behind its chunks, and no run takes the persistent graph then anyway)
         // (a launch of few blocks may take a two-wave build with helper waves -- nsf_unit.hip: unit_train1 -- and then a whole CU per
         //  block: asked for at that footprint)
-        if (can_persist && p_blocks <= 240) {
-            int dv = 0;
-            if (hipGetDevice(&dv) == hipSuccess && cu_count(dv) > 0 && p_places > cu_count(dv)) p_places = cu_count(dv);
-        }
+        if (can_persist && device_cus() > 0 && p_blocks <= device_cus() - device_cus() / 16 && p_places > device_cus()) p_places = device_cus();
         if (can_persist && g_hand_stepped.load() == 0 && !device_is_quiet(p_blocks, p_places)) can_persist = false;
         for (int pass = 0; pass < (can_persist ? 2 : 1) && e == hipSuccess && status == NFISAM_OK; ++pass) {
         const bool persist = pass == 1;

@@ -3639,6 +3639,7 @@ static int unit_prepare(int max_D) {
             if (rc) return rc;
         }
         // (the occupancy answers the launcher will want: asked here, outside the capture of the plan's graph)
+        (void)device_cus();
         if constexpr (lean_persist_inst_v<KK, HH>) (void)lean_launch_fits<KK, HH, true>(1, max_D);
         if constexpr (lean_plain_v<KK, HH>) (void)lean_launch_fits<KK, HH, false>(1, max_D);
         return max_D <= PANEL_MAP_MAX_D ? PanelMap<KK, HH>::get(max_D, nullptr) : NFISAM_OK;
@@ -3758,7 +3759,8 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         // helper waves (round 6): a two-wave build whose blocks get a CU each is launched with eight waves per block -- waves 4 .. 7
         // own no particles and take part in the staging only (one parameter per thread: stage_cond_panel_persist_solo)
         static const bool helpers_on = !(getenv("NFISAM_HELPERS") != nullptr && getenv("NFISAM_HELPERS")[0] == '0');
-        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? 240 : 224) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
+        const long cus = device_cus();                        // (MI355X: 256 -> at most 224 such blocks, 240 for groups of nine to sixteen)
+        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
         const int BW = helpers ? 2 * W : W;                    // waves per block
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
         if constexpr (half_kh) {

@@ -15,7 +15,8 @@ struct BookArgs {
     int n, D;
     int chunk;                      // iterations to close
     nfisam_adam_cfg cfg;
-    int zero_counters;              // != 0: the per-dim control words are zeroed (between chunks: nobody else is running)
+    int zero_counters;              // != 0: the per-dim control words are zeroed (between chunks: nobody else is running); 2: all but
+                                    // CLOSE_WORD_STEP / _STOP, which the Adam blocks of the same kernel are reading (nsf_close_kernel)
 };
 
 __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
@@ -35,8 +36,9 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
     int stalled = 0, xcd_span = 0;
     if (threadIdx.x < FUSED_COUNTERS) {                              // (= the block's first wave)
         unsigned* ctr = (unsigned*)(ring + (size_t)LOSS_RING * LOSS_SLOTS) + threadIdx.x;
-        const unsigned cv = *ctr;
-        if (a.zero_counters) *ctr = 0u;
+        const bool close_word = a.zero_counters == 2 && (threadIdx.x == CLOSE_WORD_STEP || threadIdx.x == CLOSE_WORD_STOP);
+        const unsigned cv = close_word ? 0u : *ctr;
+        if (a.zero_counters && !close_word) *ctr = 0u;
         stalled = __any((int)(cv >> 31));
         int span = __popc((cv >> 23) & 0xffu);
 #pragma unroll

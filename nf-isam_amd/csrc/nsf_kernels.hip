@@ -40,11 +40,14 @@ struct AdamArgs {
                             // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
     int span;               // != 0 (with close_chunk > 0): behind a WINDOW-SPANNING launch (nsf_unit.hip): which update is pending and the
                             // parity of its buffers come from the workspace's control words (SPAN_WORD_LAST_T / _PARITY), 0 = none
+    int fused_close;        // != 0 (nsf_close_kernel): step / stop come from the words the chunk-persistent launch left (CLOSE_WORD_*): the
+                            // bookkeeping block of the same kernel is advancing state->step / stop meanwhile
 };
 
-__global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
+__device__ __forceinline__ void adam_block(const AdamArgs& a) {
     // grid = (ADAM_BLOCKS, n_cliques).  state->step / stop only change in the bookkeeping kernel that closes a
-    // chunk, never during this launch, so every block derives the same iteration number t.
+    // chunk, never during this launch, so every block derives the same iteration number t.  (nsf_close_kernel: the bookkeeping
+    // block runs NEXT TO these blocks; they take step / stop from the copies the chunk-persistent launch left instead.)
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
     float* theta = batched ? cp->kparams : a.single.kparams;
@@ -56,6 +59,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const int D = batched ? cp->D : a.single.D;
 
     __shared__ int s_step, s_stop;
+    const int adam_blocks = (int)gridDim.x - (a.fused_close ? 1 : 0);      // (nsf_close_kernel: the row's last block is the bookkeeping block)
     const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
@@ -70,8 +74,15 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         if (tl0 == 0) { pre_m = m[jf]; pre_v = v[jf]; pre_t = theta[jf]; }
     }
     if (threadIdx.x == 0) {
-        s_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.fused_close) {
+            const size_t copies_max = (size_t)((a.max_n + a.slab - 1) / a.slab);
+            const unsigned* words = (const unsigned*)(G + copies_max * (size_t)P + (size_t)LOSS_RING * LOSS_SLOTS);
+            s_step = (int)__hip_atomic_load(&words[CLOSE_WORD_STEP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_stop = (int)__hip_atomic_load(&words[CLOSE_WORD_STOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            s_step = __hip_atomic_load(&st->step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_stop = __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     int iter_idx = a.iter_idx;
@@ -120,7 +131,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     if (a.slab && n_tiles0 <= 8 && a.few_copies) {
         // few gradient copies (throughput launches: one copy per T tiles): one thread per parameter, the copies summed
         // in copy order (bitwise-reproducible), every load independent of the others
-        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += adam_blocks * blockDim.x) {
             float gv[8];
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) gv[tt] = (tt < n_tiles0) ? G[(size_t)tt * P + j] : 0.0f;
@@ -149,7 +160,7 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
     const int n_tiles = n_tiles0;
     const int pj = threadIdx.x & 31, tl = threadIdx.x >> 5;
     bool first = true;
-    for (int j0 = blockIdx.x * 32; j0 < P; j0 += gridDim.x * 32) {
+    for (int j0 = blockIdx.x * 32; j0 < P; j0 += adam_blocks * 32) {
         const int j = j0 + pj;
         float part = 0.0f;
         if (first && !closing) {
@@ -183,6 +194,8 @@ __global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
         first = false;
     }
 }
+
+__global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) { adam_block(a); }
 
 // Closes a chunk of iterations (one block per clique): turns the ring's loss sums into iter_loss entries
 // (NFiSAM.py:473), evaluates the window early-stop rule (NFiSAM.py:481-491) and advances state->step.
@@ -222,9 +235,9 @@ __global__ void __launch_bounds__(64) nsf_span_close_kernel(AdamArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
+__device__ __forceinline__ void bookkeep_block(const AdamArgs& a, int clique, int zero_counters) {
     const bool batched = a.cliques != nullptr;
-    const nfisam_clique* cp = batched ? (a.cliques + blockIdx.x) : nullptr;
+    const nfisam_clique* cp = batched ? (a.cliques + clique) : nullptr;
     float* G = batched ? cp->kgrad : a.single.kgrad;
     const int D = batched ? cp->D : a.single.D;
     const int PoP = pop_of(a.K);
@@ -235,13 +248,25 @@ __global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) {
     b.ring = G + copies * P;
     b.iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
     b.st = batched ? cp->state : a.single.state;
-    b.mirror = a.mirror != nullptr ? a.mirror + blockIdx.x : nullptr;
+    b.mirror = a.mirror != nullptr ? a.mirror + clique : nullptr;
     b.n = batched ? cp->n : a.single.n;
     b.D = D;
     b.chunk = a.chunk;
     b.cfg = a.cfg;
-    b.zero_counters = 1;
+    b.zero_counters = zero_counters;
     bookkeep_body(b);
+}
+__global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) { bookkeep_block(a, (int)blockIdx.x, 1); }
+
+// The end of a chunk-persistent chunk as ONE kernel (round 6): grid (Adam blocks + 1, cliques) -- blocks 0 .. gridDim.x - 2 of a row
+// apply the chunk's last pending update (adam_block: the blocks of nsf_adam_kernel in close_chunk mode), the row's LAST block closes
+// the chunk (bookkeep_block: loss record, stop rule, step, the host's mirror).  The two need nothing of each other except the clique's
+// step / stop as the chunk FOUND them, which the bookkeeping block is about to change: the Adam blocks read the copies the persistent
+// launch left in the workspace (CLOSE_WORD_STEP / _STOP), written before the launch's first iteration and not touched again until
+// the plan's next launch.  One kernel boundary and the closing Adam's latency less per chunk: ~9 of the ~20 us between two launches.
+__global__ void __launch_bounds__(256) nsf_close_kernel(AdamArgs a) {
+    if (blockIdx.x + 1 == gridDim.x) bookkeep_block(a, (int)blockIdx.y, 2);
+    else adam_block(a);
 }
 
 // Hold-out validation of a fit (reference: src/slam/NFiSAM.py:452-468, `training_set_frac < 1`): every
@@ -899,6 +924,17 @@ static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_cliq
         int ablocks = ad.few_copies ? (int)((Pmax + 255) / 256) : (int)((Pmax + 31) / 32);
         if (ablocks < 1) ablocks = 1;
         if (ablocks > 1024) ablocks = 1024;
+        // behind a chunk-persistent launch of cliques of up to SPAN_MAX_D dims: ONE kernel, the bookkeeping block next to the Adam
+        // blocks (nsf_close_kernel; NFISAM_FUSED_CLOSE=0: two kernels, the same bits)
+        static const bool fuse_on = !(getenv("NFISAM_FUSED_CLOSE") != nullptr && getenv("NFISAM_FUSED_CLOSE")[0] == '0');
+        if (persistent_chunk && fuse_on && max_D <= SPAN_MAX_D) {
+            ad.fused_close = 1;
+            ad.chunk = chunk;
+            ad.mirror = mirror;
+            hipLaunchKernelGGL(nsf_close_kernel, dim3(ablocks + 1, n_cliques), dim3(256), 0, s, ad);
+            HIP_TRY(hipGetLastError());
+            return NFISAM_OK;
+        }
         hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks, n_cliques), dim3(256), 0, s, ad);
         HIP_TRY(hipGetLastError());
     }

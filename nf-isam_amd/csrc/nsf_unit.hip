@@ -3767,8 +3767,13 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         // helper waves (round 6): a two-wave build whose blocks get a CU each is launched with eight waves per block -- waves 4 .. 7
         // own no particles and take part in the staging only (one parameter per thread: stage_cond_panel_persist_solo)
         static const bool helpers_on = !(getenv("NFISAM_HELPERS") != nullptr && getenv("NFISAM_HELPERS")[0] == '0');
-        const long cus = device_cus();                        // (MI355X: 256 -> at most 224 such blocks, 240 for groups of nine to sixteen)
-        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
+        // (MI355X: 256 CUs -> at most 224 such blocks, 240 for groups of nine to sixteen.  The dispatcher deals workgroups round-robin to
+        //  the eight XCDs, so what must fit is the busiest XCD's share -- (octets of groups) x (blocks per group), padding included -- into
+        //  its cus / 8 CUs: at most 7/8 of them by default; the sixteen-copy launches of NFISAM_HALF=2 may fill an XCD)
+        const long cus = device_cus();
+        const long per_xcd = (long)((a.groups + 7) / 8) * gx;
+        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) &&
+                             per_xcd <= (wide ? cus / 8 : cus / 8 - cus / 64) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
         const int BW = helpers ? 2 * W : W;                    // waves per block
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
         if constexpr (half_kh) {

@@ -1500,12 +1500,12 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
                                                                    bx, tg0 + 2 * tg_set);
                 } else {
                     if constexpr (WIDE) {
-                        if (ROOMY && (int)blockDim.x > (64 << ws))    // (helper waves: one parameter per thread)
+                        if ((ROOMY || H == 16) && (int)blockDim.x > (64 << ws))    // (helper waves: one parameter per thread)
                             rc_ = stage_cond_panel_persist_solo_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                         else
                             rc_ = stage_cond_panel_persist_wide<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                     }
-                    else if (ROOMY && (int)blockDim.x > (64 << ws))     // (helper waves: one parameter per thread)
+                    else if ((ROOMY || H == 16) && (int)blockDim.x > (64 << ws))     // (helper waves: one parameter per thread)
                         rc_ = stage_cond_panel_persist_solo<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
                     else
                         rc_ = stage_cond_panel_persist<K, H>(smem, (const float*)own_t, pa_, h_panel_map, i, threadIdx.x, blockDim.x, st_step, st_stop, n, it);
@@ -3772,7 +3772,8 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         //  its cus / 8 CUs: at most 7/8 of them by default; the sixteen-copy launches of NFISAM_HALF=2 may fill an XCD)
         const long cus = device_cus();
         const long per_xcd = (long)((a.groups + 7) / 8) * gx;
-        const bool helpers = helpers_on && persist && (spl || lean) && W == 4 && real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) &&
+        const bool helpers = helpers_on && persist && (spl || lean || HH == 16) && W == 4 &&      // (hidden_dim 16 compiles to two waves per SIMD anyway)
+                             real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) &&
                              per_xcd <= (wide ? cus / 8 : cus / 8 - cus / 64) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
         const int BW = helpers ? 2 * W : W;                    // waves per block
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
@@ -3854,7 +3855,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
             }
         }
         if (!launched && gz > 0 && persist && wide) {
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true, false, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
             launched = true;
         }
@@ -3867,7 +3868,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         }
         if (launched) {
         } else if (gz > 0 && persist)
-            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * W), lds_launch, s,
+            hipLaunchKernelGGL((nsf_train1_kernel<KK, HH, true>), scatter ? dim3(gx, 8, gz) : dim3(8, gx, gz), dim3(64 * BW), lds_launch, s,
                                dev, a.panel_map, a.magic_cliques, a.groups, a.grid_cliques, a.xrows, pshifts, a, few);
         else if (gz > 0)
             hipLaunchKernelGGL((nsf_train1_plain_kernel<KK, HH>), dim3(8, gx, gz), dim3(64 * W), lds_launch, s, dev, a.panel_map,

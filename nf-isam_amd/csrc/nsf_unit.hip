@@ -3638,7 +3638,8 @@ template <int KK, int HH> constexpr bool lean_persist_v = HH <= 8 && KK > NSF_PE
 // round 6: the two-wave build of the chunk-persistent form also serves LONE launches of num_knots 9 (a block per CU at most:
 // nothing to gain from a third wave per SIMD) -- it has the registers to request the first look at the tagged copies at the
 // top of the iteration -- tried and dropped -- and to let the compiler hoist the loop's derivations (nsf_train1_kernel: ROOMY)
-template <int KK, int HH> constexpr bool lean_persist_inst_v = lean_persist_v<KK, HH> || (HH == 8 && hp_of(KK) == 16);
+// (... and of every other num_knots at hidden_dim <= 8: the helper waves need a two-wave build)
+template <int KK, int HH> constexpr bool lean_persist_inst_v = HH <= 8;
 template <int KK, int HH>
 static int unit_prepare(int max_D) {
     if constexpr (HH == 8 || HH == 4 || HH == 16) {

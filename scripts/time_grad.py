@@ -9,6 +9,8 @@ nc, n, D = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 rng = np.random.RandomState(0)
 Hh = int(os.environ.get("TG_H", BM.H))                  # hidden_dim (TG_H=16 | 4)
+if "TG_K" in os.environ:                               # num_knots (TG_K=5 | 12 ...; bench.py's own is 9)
+    BM.K = int(os.environ["TG_K"])
 problem = [(rng.randn(n, D).astype(np.float32), BM.init_blob_np(D, BM.K, Hh, L, c)) for c in range(nc)]
 w = BM.Workload(problem, L, torch.device("cuda:0"), hidden=Hh)
 r, _ = w.record(400, 50, torch.cuda.synchronize)

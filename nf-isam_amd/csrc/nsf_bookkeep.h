@@ -16,7 +16,7 @@ struct BookArgs {
     int chunk;                      // iterations to close
     nfisam_adam_cfg cfg;
     int zero_counters;              // != 0: the per-dim control words are zeroed (between chunks: nobody else is running); 2: all but
-                                    // CLOSE_WORD_STEP / _STOP, which the Adam blocks of the same kernel are reading (nsf_close_kernel)
+                                    // CLOSE_WORD_STEP / _STOP, which the Adam blocks of the same kernel are reading (nsf_adam_kernel with `fused_close`)
 };
 
 __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {

@@ -93,7 +93,7 @@ struct TrainArgs {
 // control words of a clique's workspace (behind the loss ring: FUSED_COUNTERS words, one per dim) that the window-spanning launch
 // uses for itself; cliques of more than SPAN_MAX_D dims keep to one launch per chunk
 constexpr int SPAN_WORD_TICKET = 63, SPAN_WORD_DECISION = 62, SPAN_WORD_LAST_T = 61, SPAN_WORD_LAST_PARITY = 60, SPAN_MAX_D = 56;
-// ... and two words a chunk-persistent launch leaves for the kernel that closes its chunk (nsf_close_kernel, nsf_kernels.hip): the clique's
+// ... and two words a chunk-persistent launch leaves for the kernel that closes its chunk (nsf_adam_kernel with `fused_close`, nsf_kernels.hip): the clique's
 // step and stop AS THE LAUNCH FOUND THEM -- the closing Adam blocks read these while the bookkeeping block of the same kernel advances
 // state->step / stop (cliques of up to SPAN_MAX_D dims; wider ones close a chunk with two kernels)
 constexpr int CLOSE_WORD_STEP = 58, CLOSE_WORD_STOP = 57;

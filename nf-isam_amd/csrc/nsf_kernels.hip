@@ -40,13 +40,49 @@ struct AdamArgs {
                             // this many iterations; its gradient copies / source state sit in the buffers of that iteration's parity
     int span;               // != 0 (with close_chunk > 0): behind a WINDOW-SPANNING launch (nsf_unit.hip): which update is pending and the
                             // parity of its buffers come from the workspace's control words (SPAN_WORD_LAST_T / _PARITY), 0 = none
-    int fused_close;        // != 0 (nsf_close_kernel): step / stop come from the words the chunk-persistent launch left (CLOSE_WORD_*): the
+    int fused_close;        // != 0 (nsf_adam_kernel with `fused_close`): step / stop come from the words the chunk-persistent launch left (CLOSE_WORD_*): the
                             // bookkeeping block of the same kernel is advancing state->step / stop meanwhile
 };
 
-__device__ __forceinline__ void adam_block(const AdamArgs& a) {
+// One block of the bookkeeping (nsf_bookkeep.h) for clique `clique`, from the fields of the KERNEL'S OWN by-value argument `a`: no
+// reference to `a` is formed -- a reference to a by-value kernel argument makes the compiler copy the argument block to scratch (248 bytes
+// per thread and +5 us per launch of the multi-layer path's Adam kernel, measured when this code briefly lived in device functions)
+#define NSF_BOOKKEEP_BLOCK(a, clique, zc)                                                                            \
+    do {                                                                                                             \
+        const bool batched_ = (a).cliques != nullptr;                                                                \
+        const nfisam_clique* cp_ = batched_ ? ((a).cliques + (clique)) : nullptr;                                    \
+        float* G_ = batched_ ? cp_->kgrad : (a).single.kgrad;                                                        \
+        const int D_ = batched_ ? cp_->D : (a).single.D;                                                             \
+        const int PoP_ = pop_of((a).K);                                                                              \
+        const int kfixed_ = (a).H + (a).H * (a).H + (a).H + (a).H * PoP_ + PoP_;                                     \
+        const size_t P_ = (size_t)(a).L * (size_t)(PoP_ + (D_ - 1) * kfixed_ + (a).H * ((D_ - 1) * D_ / 2));        \
+        const size_t copies_ = (a).slab ? (size_t)(((a).max_n + (a).slab - 1) / (a).slab) : (size_t)1;              \
+        BookArgs b_;                                                                                                 \
+        b_.ring = G_ + copies_ * P_;                                                                                 \
+        b_.iter_loss = batched_ ? cp_->iter_loss : (a).single.iter_loss;                                             \
+        b_.st = batched_ ? cp_->state : (a).single.state;                                                            \
+        b_.mirror = (a).mirror != nullptr ? (a).mirror + (clique) : nullptr;                                         \
+        b_.n = batched_ ? cp_->n : (a).single.n;                                                                     \
+        b_.D = D_;                                                                                                   \
+        b_.chunk = (a).chunk;                                                                                        \
+        b_.cfg = (a).cfg;                                                                                            \
+        b_.zero_counters = (zc);                                                                                     \
+        bookkeep_body(b_);                                                                                           \
+    } while (0)
+
+// The end of a chunk-persistent chunk as ONE launch of this kernel (round 6, `fused_close`): grid (Adam blocks + 1, cliques) -- blocks
+// 0 .. gridDim.x - 2 of a row apply the chunk's last pending update (close_chunk mode), the row's LAST block closes the chunk (loss record,
+// stop rule, step, the host's mirror).  The two need nothing of each other except the clique's step / stop as the chunk FOUND them, which
+// the bookkeeping block is about to change: the Adam blocks read the copies the persistent launch left in the workspace (CLOSE_WORD_STEP /
+// _STOP, written before the launch's first iteration and not touched again until the plan's next launch).  One kernel boundary and the
+// closing Adam's latency less per chunk: ~8 of the ~20 us between two launches.
+__global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) {
+    if (a.fused_close && blockIdx.x + 1 == gridDim.x) {
+        NSF_BOOKKEEP_BLOCK(a, (int)blockIdx.y, 2);
+        return;
+    }
     // grid = (ADAM_BLOCKS, n_cliques).  state->step / stop only change in the bookkeeping kernel that closes a
-    // chunk, never during this launch, so every block derives the same iteration number t.  (nsf_close_kernel: the bookkeeping
+    // chunk, never during this launch, so every block derives the same iteration number t.  (`fused_close`: the bookkeeping
     // block runs NEXT TO these blocks; they take step / stop from the copies the chunk-persistent launch left instead.)
     const bool batched = a.cliques != nullptr;
     const nfisam_clique* cp = batched ? (a.cliques + blockIdx.y) : nullptr;
@@ -59,7 +95,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a) {
     const int D = batched ? cp->D : a.single.D;
 
     __shared__ int s_step, s_stop;
-    const int adam_blocks = (int)gridDim.x - (a.fused_close ? 1 : 0);      // (nsf_close_kernel: the row's last block is the bookkeeping block)
+    const int adam_blocks = (int)gridDim.x - (a.fused_close ? 1 : 0);      // (`fused_close`: the row's last block is the bookkeeping block)
     const int PoP = pop_of(a.K);
     const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
     const int P = a.L * (PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
@@ -195,8 +231,6 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a) {
     }
 }
 
-__global__ void __launch_bounds__(256) nsf_adam_kernel(AdamArgs a) { adam_block(a); }
-
 // Closes a chunk of iterations (one block per clique): turns the ring's loss sums into iter_loss entries
 // (NFiSAM.py:473), evaluates the window early-stop rule (NFiSAM.py:481-491) and advances state->step.
 // It is the only writer of step / stop, and it runs alone between chunks: the training and Adam kernels of a
@@ -235,39 +269,7 @@ __global__ void __launch_bounds__(64) nsf_span_close_kernel(AdamArgs a) {
     }
 }
 
-__device__ __forceinline__ void bookkeep_block(const AdamArgs& a, int clique, int zero_counters) {
-    const bool batched = a.cliques != nullptr;
-    const nfisam_clique* cp = batched ? (a.cliques + clique) : nullptr;
-    float* G = batched ? cp->kgrad : a.single.kgrad;
-    const int D = batched ? cp->D : a.single.D;
-    const int PoP = pop_of(a.K);
-    const int kfixed = a.H + a.H * a.H + a.H + a.H * PoP + PoP;
-    const size_t P = (size_t)a.L * (size_t)(PoP + (D - 1) * kfixed + a.H * ((D - 1) * D / 2));
-    const size_t copies = a.slab ? (size_t)((a.max_n + a.slab - 1) / a.slab) : (size_t)1;
-    BookArgs b;
-    b.ring = G + copies * P;
-    b.iter_loss = batched ? cp->iter_loss : a.single.iter_loss;
-    b.st = batched ? cp->state : a.single.state;
-    b.mirror = a.mirror != nullptr ? a.mirror + clique : nullptr;
-    b.n = batched ? cp->n : a.single.n;
-    b.D = D;
-    b.chunk = a.chunk;
-    b.cfg = a.cfg;
-    b.zero_counters = zero_counters;
-    bookkeep_body(b);
-}
-__global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) { bookkeep_block(a, (int)blockIdx.x, 1); }
-
-// The end of a chunk-persistent chunk as ONE kernel (round 6): grid (Adam blocks + 1, cliques) -- blocks 0 .. gridDim.x - 2 of a row
-// apply the chunk's last pending update (adam_block: the blocks of nsf_adam_kernel in close_chunk mode), the row's LAST block closes
-// the chunk (bookkeep_block: loss record, stop rule, step, the host's mirror).  The two need nothing of each other except the clique's
-// step / stop as the chunk FOUND them, which the bookkeeping block is about to change: the Adam blocks read the copies the persistent
-// launch left in the workspace (CLOSE_WORD_STEP / _STOP), written before the launch's first iteration and not touched again until
-// the plan's next launch.  One kernel boundary and the closing Adam's latency less per chunk: ~9 of the ~20 us between two launches.
-__global__ void __launch_bounds__(256) nsf_close_kernel(AdamArgs a) {
-    if (blockIdx.x + 1 == gridDim.x) bookkeep_block(a, (int)blockIdx.y, 2);
-    else adam_block(a);
-}
+__global__ void __launch_bounds__(256) nsf_bookkeep_kernel(AdamArgs a) { NSF_BOOKKEEP_BLOCK(a, (int)blockIdx.x, 1); }
 
 // Hold-out validation of a fit (reference: src/slam/NFiSAM.py:452-468, `training_set_frac < 1`): every
 // `validation_interval` iterations the NLL of the held-out batch is evaluated with the CURRENT parameters (before the
@@ -925,13 +927,13 @@ static int enqueue_chunk_end(const nfisam_clique* dev_cliques, const nfisam_cliq
         if (ablocks < 1) ablocks = 1;
         if (ablocks > 1024) ablocks = 1024;
         // behind a chunk-persistent launch of cliques of up to SPAN_MAX_D dims: ONE kernel, the bookkeeping block next to the Adam
-        // blocks (nsf_close_kernel; NFISAM_FUSED_CLOSE=0: two kernels, the same bits)
+        // blocks (nsf_adam_kernel with `fused_close`; NFISAM_FUSED_CLOSE=0: two kernels, the same bits)
         static const bool fuse_on = !(getenv("NFISAM_FUSED_CLOSE") != nullptr && getenv("NFISAM_FUSED_CLOSE")[0] == '0');
         if (persistent_chunk && fuse_on && max_D <= SPAN_MAX_D) {
             ad.fused_close = 1;
             ad.chunk = chunk;
             ad.mirror = mirror;
-            hipLaunchKernelGGL(nsf_close_kernel, dim3(ablocks + 1, n_cliques), dim3(256), 0, s, ad);
+            hipLaunchKernelGGL(nsf_adam_kernel, dim3(ablocks + 1, n_cliques), dim3(256), 0, s, ad);
             HIP_TRY(hipGetLastError());
             return NFISAM_OK;
         }

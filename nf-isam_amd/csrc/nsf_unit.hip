@@ -1364,7 +1364,7 @@ nsf_train1_kernel(const nfisam_clique* h_cliques, const uint32_t* h_panel_map, u
     const size_t gstride = (size_t)LY::count(D);
     gfloat* ring = G + (slab ? (size_t)ta.n_copies : (size_t)1) * gstride;
     if constexpr (PERSIST) {
-        // for the kernel that closes this chunk (nsf_close_kernel, nsf_kernels.hip): the clique's step / stop as this launch found them
+        // for the kernel that closes this chunk (nsf_adam_kernel with `fused_close`, nsf_kernels.hip): the clique's step / stop as this launch found them
         if (it == 0 && i == 0 && bx == 0 && tl_ == 0 && h_xrows <= SPAN_MAX_D) {
             unsigned* cw = (unsigned*)(ring + LOSS_RING * LOSS_SLOTS);
             cw[CLOSE_WORD_STEP] = (unsigned)st_step;

@@ -356,6 +356,15 @@ class NFiSAM(FactorGraphSolver):
     # since the last look instead of one blocking copy per fit (a fit's curve is ready on the device long before that).
     @property
     def _temp_training_loss(self) -> dict:
+        inflight = self.__dict__.pop("_loss_inflight", None)
+        if inflight is not None:                 # (lazy posterior: the copy was enqueued in front of the walk, see _prefetch_loss_record)
+            names, host, done = inflight
+            done.synchronize()
+            flat = host.numpy().astype(np.float64)
+            off = 0
+            for name, cnt in names:
+                self.__dict__["_loss_record"][name] = flat[off:off + cnt].tolist()
+                off += cnt
         pending = self.__dict__.get("_loss_pending")
         if pending:
             self.__dict__["_loss_pending"] = []
@@ -370,6 +379,22 @@ class NFiSAM(FactorGraphSolver):
     def _temp_training_loss(self, value: dict):
         self.__dict__["_loss_record"] = value
         self.__dict__["_loss_pending"] = []
+        self.__dict__.pop("_loss_inflight", None)
+
+    def _prefetch_loss_record(self):
+        """Lazy posterior: the device-to-host copy of the update's loss curves is enqueued NOW, in front of the tree walk (pinned
+        memory, its own event), so that a look at `_temp_training_loss` after `incremental_inference` waits for the fits only --
+        a blocking copy behind the walk would wait for the walk."""
+        pending = self.__dict__.get("_loss_pending")
+        if not pending or self.__dict__.get("_loss_inflight") is not None:
+            return
+        self.__dict__["_loss_pending"] = []
+        flat = torch.cat([t for _, t in pending])
+        host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        self.__dict__["_loss_inflight"] = ([(name, int(t.numel())) for name, t in pending], host, done)
 
     def _simulation_backend(self):
         if not getattr(self._args, "device_simulation", False) or not torch.cuda.is_available():
@@ -650,6 +675,7 @@ class NFiSAM(FactorGraphSolver):
         device pointers are cached on the model (they do not change after training); only the column
         indices, which shift as the elimination ordering grows, are rebuilt per update."""
         if getattr(self._args, "lazy_posterior", False):
+            self._prefetch_loss_record()
             handle = self.posterior_launch()
             S = handle["S"]
             host = torch.empty(S.shape, dtype=S.dtype, pin_memory=True)

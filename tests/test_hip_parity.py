@@ -1290,6 +1290,70 @@ tb.close()
 '''
 
 
+KNOB_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "nf-isam_amd")); sys.path.insert(0, %(root)r)
+import nfisam_hip as nh
+dev = torch.device("cuda", 0)
+K, B = 9, 5.0
+out = {}
+for name, shapes, iters, window, tol, H, Kk in (("plaza", [(2000, 15)], 230, 50, 0.0, 8, 9), ("n1500", [(1500, 12)], 120, 40, 0.0, 8, 9),
+                                                ("n1000", [(1000, 15)], 130, 50, 0.0, 8, 9), ("early_stop", [(2000, 7)], 600, 50, 0.05, 8, 9),
+                                                ("k5", [(2000, 9)], 120, 40, 0.0, 8, 5), ("k12", [(1200, 10)], 120, 40, 0.0, 8, 12),
+                                                ("h16", [(2000, 11)], 120, 40, 0.0, 16, 9), ("h4", [(900, 9)], 100, 50, 0.0, 4, 9)):
+    gen = torch.Generator().manual_seed(len(name))
+    xs = [(1.3 * torch.randn(n, D, generator=gen)).clamp_(-4, 4).to(dev) for n, D in shapes]
+    kp = [nh.pack((0.2 * torch.randn(nh.param_count(D, Kk, H), generator=gen)).to(dev), D, Kk, H, 1) for n, D in shapes]
+    tb = nh.TrainBatch(xs, kp, Kk, H, B, 1, lr=0.01, max_iters=iters, average_window=window, loss_delta_tol=tol, early_stop=True)
+    done = tb.run()
+    for c in range(len(shapes)):
+        out["%%s_%%d_params" %% (name, c)] = tb.kparams[c].cpu().numpy()
+        out["%%s_%%d_loss" %% (name, c)] = tb.iter_loss[c].cpu().numpy()
+        out["%%s_%%d_iters" %% (name, c)] = np.array(done[c])
+    out["span_%%s" %% name] = np.array(tb.xcd_span())
+    tb.close()
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.timeout(600)
+def test_round6_launch_forms_are_bit_identical_to_one_launch_per_iteration(tmp_path):
+    """Round 6's forms of a lone clique's chunk-persistent launch, each against ITS kernel family's one-launch-per-iteration form
+    (NFISAM_PERSIST=0; the two families -- 64 particles per wave / two lanes per particle -- differ from each other in rounding, a form
+    of one family does not): the default (two lanes per particle up to 1024 particles, helper waves, one kernel closing a chunk),
+    NFISAM_HELPERS=0 (four waves per block), NFISAM_FUSED_CLOSE=0 (closing Adam and bookkeeping as two kernels), and NFISAM_HALF=2
+    (two lanes per particle with nine to sixteen copies: 240 blocks of one clique, two per slot of the 128-slot loss ring -- with 64
+    slots up to four blocks shared a slot and the loss record depended on their order).  Shapes: a Plaza clique, 1500 and 1000
+    particles, a run that stops early, num_knots 5 and 12 (two-wave builds added at the round's end), hidden_dim 16 and 4.
+    Parameters, loss records and stop iterations equal bit for bit; every persistent run really took that form (XCD span 1)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "knob_worker.py"
+    script.write_text(KNOB_WORKER % dict(root=root))
+
+    def run(tag, **env):
+        out = str(tmp_path / ("knob_%s.npz" % tag))
+        p = subprocess.run([sys.executable, str(script), out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return dict(np.load(out))
+
+    plain = run("plain", NFISAM_PERSIST="0")
+    plain_half2 = run("plain_half2", NFISAM_PERSIST="0", NFISAM_HALF="2")
+    for tag, env, ref in (("default", dict(NFISAM_PERSIST="1"), plain),
+                          ("no_helpers", dict(NFISAM_PERSIST="1", NFISAM_HELPERS="0"), plain),
+                          ("two_kernel_close", dict(NFISAM_PERSIST="1", NFISAM_FUSED_CLOSE="0"), plain),
+                          ("half2", dict(NFISAM_PERSIST="1", NFISAM_HALF="2"), plain_half2),
+                          ("half2_no_helpers", dict(NFISAM_PERSIST="1", NFISAM_HALF="2", NFISAM_HELPERS="0"), plain_half2)):
+        got = run(tag, **env)
+        assert got.keys() == ref.keys()
+        for k in got:
+            if k.startswith("span_"):
+                assert int(got[k]) == 1, (tag, k, got[k])
+                continue
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="%s: %s" % (tag, k))
+
+
 @pytest.mark.timeout(400)
 def test_oversubscribed_persistent_launch_stalls_loudly_and_the_rerun_is_exact(tmp_path):
     """A chunk-persistent launch whose blocks do not all arrive must not hang and must not pass for a numerical failure.

@@ -566,7 +566,8 @@ def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_pat
     """`NFiSAMArgs(lazy_posterior=True)` (round 6; not in the reference): `incremental_inference` returns a mapping that waits for
     the tree walk when it is first read, so the next update's host work runs under the walk.  Same seed, same problem, same
     kernels in the same order on the same stream: the samples of every update are EQUAL to the synchronous solver's, whether they
-    are read at once or only after the next update's graph work; the mapping behaves like the dict (keys, length, membership)."""
+    are read at once or only after the next update's graph work; the mapping behaves like the dict (keys, length, membership);
+    the update's loss curves (`_temp_training_loss`, which the lazy path copies to the host in front of the walk) are equal too."""
     from slam.NFiSAM import LazyPosterior, NFiSAM, NFiSAMArgs
     from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
     fx = np.load(os.path.join(GOLDEN, "pipeline_small_range.npz"), allow_pickle=False)
@@ -579,7 +580,7 @@ def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_pat
         nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
         steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))[:4]
         solver = NFiSAM(NFiSAMArgs(lazy_posterior=lazy, **kwargs))
-        out, pending = [], None
+        out, pending, curves = [], None, []
         for vs, fs in steps:
             for v in vs: solver.add_node(v)
             for f in fs: solver.add_factor(f)
@@ -589,6 +590,7 @@ def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_pat
                 pending = None
             s = solver.incremental_inference()
             assert isinstance(s, LazyPosterior) == lazy
+            curves.append({k: list(v) for k, v in solver._temp_training_loss.items()})   # (lazy: copied in front of the walk)
             if read_late:
                 pending = s
             else:
@@ -596,11 +598,13 @@ def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_pat
                 out.append({str(v.name): np.array(s[v]) for v in solver.elimination_ordering})
         if pending is not None:
             out.append({str(v.name): np.array(a) for v, a in pending.items()})
-        return out
+        return out, curves
 
-    ref = solve(False, False)
+    ref, ref_curves = solve(False, False)
+    assert all(len(c) > 0 for c in ref_curves)
     for lazy, late in ((True, False), (True, True)):
-        got = solve(lazy, late)
+        got, got_curves = solve(lazy, late)
+        assert got_curves == ref_curves                          # the loss record of every update's fits, to the bit
         assert len(got) == len(ref) == 4
         for a, b in zip(got, ref):
             assert a.keys() == b.keys()

@@ -188,7 +188,10 @@ def provenance(started):
         dirty = bool(subprocess.check_output(["git", "-C", HERE, "status", "--porcelain", "--", __file__], text=True).strip())
     except Exception:
         commit, dirty = "unknown", True
-    return dict(generator_commit=commit, generator_modified=dirty, PYTHONHASHSEED=os.environ.get("PYTHONHASHSEED", "unset"),
+    import hashlib
+    with open(os.path.abspath(__file__), "rb") as f:          # (the commit is HEAD when the run ENDS: the file's own hash says which generator ran)
+        file_hash = hashlib.sha256(f.read()).hexdigest()[:16]
+    return dict(generator_commit=commit, generator_modified=dirty, generator_sha256_16=file_hash, PYTHONHASHSEED=os.environ.get("PYTHONHASHSEED", "unset"),
                 REF_THREADS=int(os.environ.get("REF_THREADS", "2")), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "unset"),
                 niceness=os.nice(0), torch_threads=torch.get_num_threads(),
                 host=platform.node(), cpus=os.cpu_count(), python=platform.python_version(), torch=torch.__version__,

@@ -11,6 +11,8 @@ class FactorGraph(object):
         self._vars: List[Variable] = []       # insertion order (the orderings are derived from it)
         self._var_set: Set[Variable] = set()  # membership: the incremental solver rebuilds sub graphs of hundreds of variables
         self._factors: List = []              # every update -- a list scan per add was 11 M __eq__ calls on Plaza1
+        self._by_var: Dict[Variable, List[int]] = {}   # variable -> indices of its factors (round 6: the sub graph of an update is cut
+                                                       # out of the factors of the AFFECTED variables, not out of all of them)
 
     def add_node(self, var: Variable) -> "FactorGraph":
         if var in self._var_set:
@@ -23,6 +25,8 @@ class FactorGraph(object):
         for v in factor.vars:
             if v not in self._var_set:
                 raise KeyError("factor %s refers to a variable that is not in the graph: %s" % (factor, v.name))
+        for v in factor.vars:
+            self._by_var.setdefault(v, []).append(len(self._factors))
         self._factors.append(factor)
         return self
 
@@ -89,7 +93,11 @@ class FactorGraph(object):
         for v in self._vars:
             if v in variables:
                 sub.add_node(v)
-        for f in self._factors:
+        # (a factor among `variables` touches one of them: the candidates are the factors of those variables, in the graph's own order)
+        by_var = self._by_var
+        candidates = sorted({i for v in variables for i in by_var.get(v, ())})
+        for i in candidates:
+            f = self._factors[i]
             fv = set(f.vars)
             if fv.issubset(variables) and not any(fv.issubset(t.root.vars) for t in sub_trees):
                 sub.add_factor(f)

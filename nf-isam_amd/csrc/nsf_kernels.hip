@@ -1450,8 +1450,20 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
             if (e == hipSuccess) e = hipGraphLaunch(p->exec_end, work);
             if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
         } else if (exec && todo == p->chunk) {
-            const hipError_t e = hipGraphLaunch(exec, work);
-            if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+            // A chunk-persistent chunk is TWO kernels (the launch, the kernel that closes it): launched as such, not as a graph (round 6:
+            // hipGraphLaunch of a two-node graph costs more host time than the two launches -- Plaza1's fits 3.45 -> 3.41 s, the 20-step
+            // bench line -0.1 us per step, same bits; NFISAM_PERSIST_DIRECT=0 replays the captured graph as before).  The plain form's
+            // chunk (up to 2 x 128 kernels) stays a graph.
+            static const bool direct = !(getenv("NFISAM_PERSIST_DIRECT") != nullptr && getenv("NFISAM_PERSIST_DIRECT")[0] == '0');
+            if (direct && persist && p->val.empty()) {
+                int rc = enqueue_step(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->B, p->L, &p->cfg, 0, work, p->host.data(), 0, 1, p->chunk);
+                if (rc == NFISAM_OK)
+                    rc = enqueue_chunk_end(p->dev, single, p->n_cliques, p->max_n, p->max_D, p->K, p->H, p->L, &p->cfg, p->chunk, work, p->hst_dev, true);
+                if (rc) return rc;
+            } else {
+                const hipError_t e = hipGraphLaunch(exec, work);
+                if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+            }
         } else if (!p->val.empty() && todo == p->chunk) {       // a validated plan without a graph: the same period, launch by launch
             int rcv = enqueue_validated_period(p, work, false);
             if (rcv) return rcv;

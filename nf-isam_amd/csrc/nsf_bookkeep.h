@@ -3,7 +3,9 @@
 // state->step / stop, the host-pinned mirror.  ONE copy of the arithmetic for `nsf_bookkeep_kernel` (nsf_kernels.hip: one block per
 // clique between two chunks) and for the block of `nsf_train1_kernel` that arrives last at a window's end (nsf_unit.hip): the same
 // sums in the same order, so the loss record and the stop decision do not depend on which of the two closed the window.
-// 256 threads (four waves) call it together; it contains workgroup barriers.
+// The block's first 256 threads (four waves) do the work; it contains workgroup barriers, which EVERY thread of the block passes (a
+// block of the training kernel may have eight waves: its helper waves call this too and only take part in the barriers -- the sums are
+// partitioned over 256 threads whoever calls, so the bits do not depend on the caller's block size).
 #pragma once
 #include "nsf_host.h"
 
@@ -24,13 +26,16 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
     float* iter_loss = a.iter_loss;
     nfisam_train_state* st = a.st;
     const int n = a.n, D = a.D;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool worker = threadIdx.x < 256;                           // (block-size independent: see the header)
+    const int w = worker ? (int)(threadIdx.x >> 6) : 0;
+    constexpr int NTW = 256;                                         // threads that share the sums
     constexpr int PER_WAVE = LOSS_RING / 4;
     float part[PER_WAVE];
     static_assert(LOSS_SLOTS == 128, "a lane takes slots l and l + 64 of a row");
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k)                                                       // ring row w + 4k
-        part[k] = ring[(w + 4 * k) * LOSS_SLOTS + lane] + ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane];   // (launches of up to 128 blocks use the lower half only: x + 0)
+        part[k] = worker ? ring[(w + 4 * k) * LOSS_SLOTS + lane] + ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane] : 0.0f;   // (launches of up to 128 blocks use the lower half only: x + 0)
     // the group-barrier counters of the chunk-persistent training kernel (one per dim; nsf_unit.hip: bits 0-22 arrivals,
     // 23-30 the XCC ids the group's blocks ran on, 31 the group's abort flag): looked at, then zeroed for the next chunk
     int stalled = 0, xcd_span = 0;
@@ -63,9 +68,9 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int it = ((w + 4 * k) - s0) & (LOSS_RING - 1);
-            if (it < cnt) { ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f; ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane] = 0.0f; }   // wave-uniform
+            if (it < cnt && worker) { ring[(w + 4 * k) * LOSS_SLOTS + lane] = 0.0f; ring[(w + 4 * k) * LOSS_SLOTS + 64 + lane] = 0.0f; }   // wave-uniform
         }
-        if (lane < PER_WAVE) {
+        if (lane < PER_WAVE && worker) {
             const int it = ((w + 4 * lane) - s0) & (LOSS_RING - 1);
             if (it < cnt) {
                 const float loss = rowsum * inv_n + 0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
@@ -76,12 +81,12 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
         __syncthreads();
         // a non-finite loss ends the run at its iteration (the rule below can only fire on the chunk's last one)
         int bad_at = cnt;
-        for (int it = threadIdx.x; it < cnt; it += blockDim.x) {
+        for (int it = threadIdx.x; it < cnt && worker; it += NTW) {
             const float l = s_loss[it];
             if (!(l == l) || fabsf(l) > 3.0e38f) bad_at = (it < bad_at) ? it : bad_at;
         }
         bad_at = __reduce_min_sync(~0ull, bad_at);                 // per wave
-        if (lane == 0) s_bad[w] = bad_at;
+        if (lane == 0 && worker) s_bad[w] = bad_at;
         __syncthreads();
         bad_at = min(min(s_bad[0], s_bad[1]), min(s_bad[2], s_bad[3]));
         if (bad_at < cnt) {
@@ -90,10 +95,10 @@ __device__ __forceinline__ void bookkeep_body(const BookArgs& a) {
             const int t_end = s0 + cnt;
             if (wnd > 0 && (t_end % wnd) == 0) {   // window mean over iter_loss[t_end - wnd, t_end): this chunk's part from LDS
                 float sm = 0.0f;
-                for (int j = t_end - wnd + (int)threadIdx.x; j < t_end; j += blockDim.x)
+                for (int j = t_end - wnd + (int)threadIdx.x; j < t_end && worker; j += NTW)
                     sm += (j >= s0) ? s_loss[j - s0] : iter_loss[j];
                 sm = wave_sum(sm);
-                if (lane == 0) s_wsum[w] = sm;
+                if (lane == 0 && worker) s_wsum[w] = sm;
                 __syncthreads();
                 const float nw = (s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3]) / (float)wnd;
                 if (have_avg != 0 && loss_avg != 0.0f) {

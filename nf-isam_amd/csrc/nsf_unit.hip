@@ -3775,7 +3775,7 @@ static int unit_train1(TrainArgs a, int n_cliques, int max_n, int max_D, hipStre
         const long per_xcd = (long)((a.groups + 7) / 8) * gx;
         const bool helpers = helpers_on && persist && (spl || lean || HH == 16) && W == 4 &&      // (hidden_dim 16 compiles to two waves per SIMD anyway)
                              real_blocks <= (wide ? cus - cus / 16 : cus - cus / 8) &&
-                             per_xcd <= (wide ? cus / 8 : cus / 8 - cus / 64) && a.span_window == 0;   // (the in-kernel bookkeeping is written for four waves)
+                             per_xcd <= (wide ? cus / 8 : cus / 8 - cus / 64);       // (also the window-spanning launch: the in-kernel bookkeeping's work is its first four waves')
         const int BW = helpers ? 2 * W : W;                    // waves per block
         if (persist && gx > PERSIST_MAX_COPIES) return NFISAM_ERR_ARG;
         if constexpr (half_kh) {

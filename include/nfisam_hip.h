@@ -368,6 +368,15 @@ int nfisam_nsf_train_plan_create_validated(const nfisam_clique* host_cliques, co
 /* ABI 1400.  Most XCDs one (clique, dim) group of the plan's chunk-persistent launches ran on (0: none has run; 1: what
  * the grid asks for; > 1: slower, equally correct -- the group's exchange uses agent-scope write-through stores).  */
 int nfisam_nsf_train_plan_xcd_span(const nfisam_train_plan* plan);
+
+/* ABI 1600 (round 6), not in the reference: the whole run of a SINGLE-CLIQUE plan enqueued on `stream` as one window-spanning launch
+ * that evaluates the reference's window rule (src/slam/NFiSAM.py:481-491) itself, without the host -- the call returns at once.  The
+ * plan must have been created with bit 2 (value 4) of `use_graph` set.  Outcome, once the stream has drained: `state->step` =
+ * iterations run, `state->stop`, `state->domain_err` (bit 0 non-finite loss, NFISAM_STATE_STALLED), `iter_loss`; parameters and moments
+ * are the trained ones -- the same bits nfisam_nsf_train_plan_run leaves.  -> NFISAM_ERR_ARG: this plan / this moment does not allow
+ * it (no such graph; hidden_dim or width without the two-wave build; another run holds the chunk-persistent form): use
+ * nfisam_nsf_train_plan_run. */
+int nfisam_nsf_train_plan_launch_async(nfisam_train_plan* plan, nfisam_stream_t stream);
 int nfisam_nsf_train_plan_feed(nfisam_train_plan* plan, int depth);
 long nfisam_nsf_train_plan_enqueued(const nfisam_train_plan* plan);
 int nfisam_nsf_train_plan_peek(const nfisam_train_plan* plan, nfisam_train_state* out);

@@ -1052,6 +1052,7 @@ struct nfisam_train_plan {
     // build: every fit of a real NF-iSAM run) + its closing Adam kernel + the control words' reset, or null
     hipGraph_t graph_s = nullptr;
     hipGraphExec_t exec_s = nullptr;
+    bool span_run = false;                // nfisam_nsf_train_plan_run takes the window-spanning graph (NFISAM_SPAN=1); else it serves nfisam_nsf_train_plan_launch_async only
     nfisam_train_state* hst = nullptr;     // pinned, device-mapped host copy of the cliques' states: the bookkeeping kernel
                                            // writes it (last word written: reserved[0] = chunks closed in this run)
     nfisam_train_state* hst_dev = nullptr; // the same memory as the device addresses it
@@ -1275,7 +1276,8 @@ static int plan_create_impl(const nfisam_clique* host_cliques, const nfisam_cliq
         // itself ~55 us more (the long launch iterates ~2 % slower than four short ones): Plaza1's fits, ~12 windows each, gain 1.5 %.
         // Not worth being the default of the last round: OFF unless NFISAM_SPAN=1 (read per plan: tests switch it in-process).
         const char* span_env = getenv("NFISAM_SPAN");
-        const bool span_on = span_env != nullptr && span_env[0] == '1';
+        const bool span_on = (span_env != nullptr && span_env[0] == '1') || (use_graph & 4) != 0;      // (bit 2 of use_graph: the caller wants nfisam_nsf_train_plan_launch_async)
+        p->span_run = span_env != nullptr && span_env[0] == '1';
         if (span_on && p->exec_p != nullptr && n_cliques == 1 && p->val.empty() && L == 1 && (use_graph & 2) == 0 && p->max_D <= SPAN_MAX_D &&
             cfg->max_iters > p->chunk && cfg->average_window > 0) {
             const nfisam_clique* single = (p->dev == nullptr) ? p->host.data() : nullptr;
@@ -1382,6 +1384,25 @@ static int wait_chunk(const nfisam_train_plan* p, int k, hipStream_t work, bool*
     return NFISAM_OK;
 }
 
+// The WHOLE run of a single-clique plan enqueued as one window-spanning launch (+ the closing Adam kernel and the reset of its control
+// words) -- and back to the caller at once: the launch closes its windows itself (nsf_unit.hip), so nothing of the run needs the host.
+// The outcome is in the clique's `state` (step = iterations run, stop, domain_err incl. NFISAM_STATE_STALLED) and `iter_loss` when the
+// stream has drained; the caller looks when it wants to (slam.NFiSAM with `async_fits`: once per update).  -> NFISAM_ERR_ARG when the
+// plan has no such graph (created without bit 2 of `use_graph`, or its shape does not take the window-spanning form) or the
+// chunk-persistent form is not available to this process right now: the caller falls back to nfisam_nsf_train_plan_run.
+extern "C" int nfisam_nsf_train_plan_launch_async(nfisam_train_plan* p, nfisam_stream_t stream) {
+    if (p == nullptr || p->exec_s == nullptr || p->feeder.joinable() || p->stepping) return NFISAM_ERR_ARG;
+    if (g_persist_broken.load() || g_hand_stepped.load() != 0 || g_persist_busy.load()) return NFISAM_ERR_ARG;
+    hipStream_t work = (hipStream_t)stream;
+    if (p->ahead && p->ran && p->last_work != work) HIP_TRY(hipStreamSynchronize(p->last_work));   // (an earlier run left work on ANOTHER stream)
+    p->last_work = work;
+    p->ran = true;
+    p->ahead = true;                                   // a later synchronous run, and plan_destroy, drain this stream first
+    const hipError_t e = hipGraphLaunch(p->exec_s, work);
+    if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return NFISAM_ERR_LAUNCH; }
+    return NFISAM_OK;
+}
+
 extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_run, nfisam_stream_t stream) {
     if (p == nullptr) return NFISAM_ERR_ARG;
     if (p->feeder.joinable()) {                          // a hand-stepped run's feeder must not launch into this one
@@ -1434,7 +1455,7 @@ extern "C" int nfisam_nsf_train_plan_run(nfisam_train_plan* p, int32_t* iters_ru
     int launched = 0, closed = 0, status = NFISAM_OK;
     // the whole run as ONE window-spanning launch (plan_create_impl): every window's bookkeeping inside it publishes the mirror as a
     // chunk's bookkeeping kernel would, so the loop below simply has all its chunks "launched"
-    const bool span = persist && p->exec_s != nullptr && total_chunks > 1;
+    const bool span = persist && p->exec_s != nullptr && p->span_run && total_chunks > 1;
     if (span) {
         const hipError_t e = hipGraphLaunch(p->exec_s, work);
         if (e != hipSuccess) { nfisam_g_last_hip_error = (int)e; return fail(NFISAM_ERR_LAUNCH); }

@@ -26,7 +26,7 @@ EXPORTS = [
     "nfisam_nsf_train_plan_run", "nfisam_nsf_train_plan_destroy", "nfisam_rqs", "nfisam_nsf_posterior_walk", "nfisam_nsf_grad_workspace_count", "nfisam_nsf_train_gradient", "nfisam_nsf_train_chains", "nfisam_nsf_train_gradient_part",
     "nfisam_nsf_train_plan_begin", "nfisam_nsf_train_plan_enqueue", "nfisam_nsf_train_plan_peek", "nfisam_nsf_train_plan_stream",
     "nfisam_nsf_train_plan_end", "nfisam_nsf_train_plan_xcd_span", "nfisam_nsf_train_plan_kernel_ms", "nfisam_nsf_train_plan_create_validated", "nfisam_nsf_train_plan_feed", "nfisam_nsf_train_plan_enqueued", "nfisam_nsf_train_plan_refill",
-    "nfisam_normalize_columns", "nfisam_simulate_clique",
+    "nfisam_normalize_columns", "nfisam_simulate_clique", "nfisam_nsf_train_plan_launch_async",
 ]
 
 
@@ -453,23 +453,26 @@ class TrainBatch:
                                                  self.max_D, self.K, self.H, C.c_float(self.B), self.L, _stream())
         _check(rc, "nfisam_nsf_train_gradient")
 
-    def prepare(self, use_graph=True, timing=False):
+    def prepare(self, use_graph=True, timing=False, span=False):
         """Validate descriptors and (optionally) capture + instantiate the hipGraph of one chunk of
         iterations.  One-time set-up; `run` calls it on first use.  `timing`: the graph carries two timing events around
-        the chunk's training launches (`kernel_ms`; measurement only)."""
-        if getattr(self, "_plan", None) is not None and self._plan_graph == bool(use_graph) and (not timing or getattr(self, "_plan_timing", False)):
+        the chunk's training launches (`kernel_ms`; measurement only).  `span`: the plan also gets the window-spanning graph
+        that `launch_async` needs (single-clique plans)."""
+        if getattr(self, "_plan", None) is not None and self._plan_graph == bool(use_graph) and (not timing or getattr(self, "_plan_timing", False)) \
+                and (not span or getattr(self, "_plan_span", False)):
             return
         self._plan_timing = bool(timing) and bool(use_graph)
+        self._plan_span = (bool(span) or getattr(self, "_plan_span", False)) and bool(use_graph) and not self._plan_timing
         self.close()
         plan = C.c_void_p(0)
         dev_desc = C.c_void_p(self.dev_desc.data_ptr()) if self.nc > 1 else None
         if self.x_val is not None:
             rc = lib().nfisam_nsf_train_plan_create_validated(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
                                                               C.byref(self.cfg), self.val_desc, self.validation_interval,
-                                                              C.c_float(self.slower_stop_rate), int(bool(use_graph)) | (2 if self._plan_timing else 0), C.byref(plan))
+                                                              C.c_float(self.slower_stop_rate), int(bool(use_graph)) | (2 if self._plan_timing else 0) | (4 if self._plan_span else 0), C.byref(plan))
         else:
             rc = lib().nfisam_nsf_train_plan_create(self.host_desc, dev_desc, self.nc, self.K, self.H, C.c_float(self.B), self.L,
-                                                    C.byref(self.cfg), int(bool(use_graph)) | (2 if self._plan_timing else 0), C.byref(plan))
+                                                    C.byref(self.cfg), int(bool(use_graph)) | (2 if self._plan_timing else 0) | (4 if self._plan_span else 0), C.byref(plan))
         _check(rc, "nfisam_nsf_train_plan_create")
         self._plan, self._plan_graph = plan, bool(use_graph)
 
@@ -483,6 +486,20 @@ class TrainBatch:
         self.last_iters = [int(v) for v in iters]          # valid also when a clique hit a domain error
         _check(rc, "nfisam_nsf_train_plan_run")
         return self.last_iters
+
+    def launch_async(self):
+        """Enqueue the WHOLE run of a single-clique plan on the current stream as one window-spanning launch that evaluates the
+        early-stop rule itself, and return at once (nfisam_nsf_train_plan_launch_async).  -> True: enqueued -- the outcome is in
+        `states[0]` (step = iterations run, stop, domain_err) / `iter_loss[0]` / `kparams[0]` when the stream has drained;
+        False: this plan or this moment does not allow it (call `run`)."""
+        if self.nc != 1 or self.x_val is not None:
+            return False
+        self.prepare(True, span=True)
+        rc = lib().nfisam_nsf_train_plan_launch_async(self._plan, _stream())
+        if rc == ERR_ARG:
+            return False
+        _check(rc, "nfisam_nsf_train_plan_launch_async")
+        return True
 
     def kernel_ms(self):
         """GPU milliseconds of the training launches of the most recent chunk replay (plans prepared with `timing=True`;

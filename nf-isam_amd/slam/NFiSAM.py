@@ -49,7 +49,7 @@ class NFiSAMArgs(SolverArgs):
                  flow_iterations: int = 10, num_knots: int = 12, cuda_training: bool = False,
                  adaptive_flow_setup: bool = False, hidden_dim: int = 8, average_window=50, loss_delta_tol=1e-2,
                  training_set_frac=1.0, validation_interval=10, slower_stop_rate=2.0, data_parallel=False,
-                 training_loss_dir=None, device_simulation=True, lazy_posterior=False, *args, **kwargs):
+                 training_loss_dir=None, device_simulation=True, lazy_posterior=False, async_fits=False, *args, **kwargs):
         super().__init__(elimination_method=elimination_method, posterior_sample_num=posterior_sample_num,
                          local_sample_num=local_sample_num, store_clique_samples=store_clique_samples,
                          local_sampling_method=local_sampling_method, *args, **kwargs)
@@ -77,6 +77,14 @@ class NFiSAMArgs(SolverArgs):
         # the tree walk and its device-to-host copy when it is first LOOKED AT (LazyPosterior below) -- a caller that adds the next
         # nodes and factors and updates the graphs before it reads the samples has that host work run under the walk.
         self.lazy_posterior = lazy_posterior
+        # not in the reference: a clique's whole fit is ENQUEUED (one window-spanning launch that evaluates the early-stop rule on the
+        # device: nfisam_nsf_train_plan_launch_async) and `fit_clique_density_model` returns without waiting -- the next clique's
+        # simulation, normalisation and fit read the trained model on the device, in stream order, so the host runs ahead of the GPU
+        # through the whole upward pass and looks at the fits' outcomes ONCE, behind it.  What it gives up: the reference-deviating
+        # "retry a non-finite fit once" of the synchronous path (an async update with a failed fit raises instead), and per-fit
+        # timers (they time the enqueue; the wait is added to the update's last fit).  Fits whose shape has no window-spanning
+        # form (hold-out validation, several layers, hidden_dim / width without the two-wave build) run synchronously as before.
+        self.async_fits = async_fits
         self.tl_cnt = 0
 
 
@@ -417,11 +425,37 @@ class NFiSAM(FactorGraphSolver):
         if prep["testing_data"] is not None:
             return self._fit_holdout(prep, timer)
         opt_start = time.time()
+        # (only from here, and only when THIS class's upward pass will collect the outcome: ParallelNFiSAM / ReplicaNFiSAM have their own)
+        prep["allow_async"] = bool(getattr(self._args, "async_fits", False)) and \
+            type(self).fit_tree_density_models is NFiSAM.fit_tree_density_models
         self.train_prepared([prep])
-        torch.cuda.synchronize()
+        if prep.get("state_dev") is None:              # (async_fits: the fit is in flight; `fit_tree_density_models` collects it)
+            torch.cuda.synchronize()
         if timer is not None:
             timer.append(time.time() - opt_start)
         return self.finish_fit(prep)
+
+    def fit_tree_density_models(self, timer: List[float] = None, clique_dim_timer: List[List[float]] = None, *args, **kwargs):
+        """The reference's upward pass (FactorGraphSolver.fit_tree_density_models); with `async_fits` the outcomes of the fits that
+        were only enqueued are looked at here, once: ONE device-to-host copy of their state words behind the pass."""
+        try:
+            super().fit_tree_density_models(timer=timer, clique_dim_timer=clique_dim_timer, *args, **kwargs)
+        finally:
+            pend = self.__dict__.pop("_async_fits", [])
+        if pend:
+            t0 = time.time()
+            states = torch.stack([p["state_dev"] for p in pend]).cpu().numpy()
+            for p, s in zip(pend, states):
+                p["iters"] = int(s[0])
+                if int(s[4]) & 2:                      # NFISAM_STATE_STALLED
+                    raise _nh.PersistentStall("an enqueued fit stalled (a block of its persistent launch never became resident): "
+                                              "run the update again with async_fits=False")
+                if int(s[4]) != 0:
+                    raise _nh.DomainError("non-finite loss in an enqueued fit (async_fits has no retry: the update's later fits "
+                                          "were computed from it)")
+            self.last_fit_iterations = pend[-1]["iters"]
+            if timer is not None and len(timer) > 0:
+                timer[-1] += time.time() - t0          # (the update's last fit timer carries the wait for all of them)
 
     def prepare_fit(self, clique, samples, var_ordering) -> dict:
         """Everything of `fit_clique_density_model` in front of the training loop (NFiSAM.py:323-449): circular flags,
@@ -510,6 +544,14 @@ class NFiSAM(FactorGraphSolver):
             x.copy_(p["training_data"])
         tb.reset(kparams=[p["kp0"] for p in preps])
         logger = logging.getLogger("flows on clique")
+        if preps[0].get("allow_async") and len(preps) == 1 and retry and tb.launch_async():
+            # the whole fit is enqueued; what the caller needs of it is copied out behind it, in stream order (the plan and its
+            # buffers serve the next clique of this shape)
+            p = preps[0]
+            p["trained"], p["iter_loss"], p["state_dev"], p["iters"] = tb.kparams[0].clone(), tb.iter_loss[0].clone(), tb.states[0].clone(), -1
+            self.__dict__.setdefault("_async_fits", []).append(p)
+            self.async_fits_enqueued = getattr(self, "async_fits_enqueued", 0) + 1       # (diagnostic: fits that took this path)
+            return
         try:
             try:
                 iters = tb.run(use_graph=True)

@@ -21,7 +21,8 @@ args = NFiSAMArgs(num_knots=9, flow_iterations=int(os.environ.get("ITERS", "2000
                   learning_rate=.01, hidden_dim=8, cuda_training=True, elimination_method="pose_first",
                   training_set_frac=1.0, loss_delta_tol=float(os.environ.get("TOL", ".01")), average_window=50,
                   device_simulation=os.environ.get("DEVSIM", "1") != "0",
-                  lazy_posterior=os.environ.get("LAZY", "0") == "1")      # LAZY=1: the samples of update i are read under update i + 1
+                  lazy_posterior=os.environ.get("LAZY", "0") == "1",      # LAZY=1: the samples of update i are read under update i + 1
+                  async_fits=os.environ.get("ASYNC", "0") == "1")         # ASYNC=1: the fits of an update are enqueued, their outcomes read once
 replicas = int(os.environ.get("REPLICAS", "1"))
 if replicas > 1:
     # R independent runs (seeds SEED .. SEED+R-1) on one GPU, their cliques in the R slots of one batched training plan

@@ -610,3 +610,44 @@ def test_lazy_posterior_returns_the_same_samples_as_the_synchronous_call(tmp_pat
             assert a.keys() == b.keys()
             for k in a:
                 np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_async_fits_leave_the_same_posteriors_and_loss_curves_as_the_synchronous_solver(tmp_path):
+    """`NFiSAMArgs(async_fits=True)` (round 6; not in the reference): every fit of an update is ENQUEUED as one window-spanning launch
+    that evaluates the early-stop rule on the device (`nfisam_nsf_train_plan_launch_async`), the host runs ahead through the upward
+    pass and reads the fits' outcomes once behind it.  The window-spanning launch is bit-identical to one launch per chunk
+    (tests/test_hip_parity.py), the later cliques read the trained models on the device in stream order, so the whole run is EQUAL to
+    the synchronous solver's: posterior samples of every update, the loss curves (hence the iterations run) of every fit -- also
+    together with the lazy posterior.  The fits really took the asynchronous path (counted)."""
+    from slam.NFiSAM import NFiSAM, NFiSAMArgs
+    from slam.RunBatch import graph_file_parser, group_nodes_factors_incrementally
+    fx = np.load(os.path.join(GOLDEN, "pipeline_small_range.npz"), allow_pickle=False)
+    kwargs = json.loads(str(fx["arguments"]))
+    kwargs["cuda_training"] = True
+    path = _graph_path(tmp_path, "small_range", fx)
+
+    def solve(**extra):
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        nodes, truth, factors = graph_file_parser(path, "fg", prior_cov_scale=0.1)
+        steps = group_nodes_factors_incrementally(nodes, factors, incremental_step=int(fx["incremental_step"]))[:5]
+        solver = NFiSAM(NFiSAMArgs(**extra, **kwargs))
+        out, curves = [], []
+        for vs, fs in steps:
+            for v in vs: solver.add_node(v)
+            for f in fs: solver.add_factor(f)
+            solver.update_physical_and_working_graphs()
+            s = solver.incremental_inference()
+            curves.append({k: list(v) for k, v in solver._temp_training_loss.items()})
+            out.append({str(v.name): np.array(s[v]) for v in solver.elimination_ordering})
+        return out, curves, getattr(solver, "async_fits_enqueued", 0), solver.last_fit_iterations
+
+    ref, ref_curves, n0, it0 = solve()
+    assert n0 == 0 and sum(len(c) for c in ref_curves) > 0
+    for extra in (dict(async_fits=True), dict(async_fits=True, lazy_posterior=True)):
+        got, curves, n_async, it1 = solve(**extra)
+        assert n_async == sum(len(c) for c in ref_curves), (n_async, [len(c) for c in ref_curves])     # every fit was enqueued
+        assert curves == ref_curves and it1 == it0
+        for a, b in zip(got, ref):
+            assert a.keys() == b.keys()
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
